@@ -1,0 +1,176 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, see oracle/ref_harness.py for the shims).
+The goldens are data (inputs + reference outputs); no reference source is copied.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Decoder weights are not stored: they are the seed-defined fixture of
+dist-renderer_amd/distr/fixture.py (sha256 recorded in every file).
+Loss used for the gradients: L = sum(wd*depth[mask]) + sum(wq*min_abs_query) + sum(wn*normal)
+with seeded uniform weights (loss_seed) so that every pixel has a distinct upstream gradient.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, '..', 'dist-renderer_amd'))
+sys.path.insert(0, _HERE)
+from distr import fixture  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(_HERE, '..', 'tests', 'golden')
+
+
+def loss_weights(H, W, seed):
+    rs = np.random.RandomState(seed)
+    return (rs.rand(H, W).astype(np.float32), rs.rand(H, W).astype(np.float32), rs.rand(H, W, 3).astype(np.float32))
+
+
+def render_case(dec, latent, K, R, T, H, W, march_step, bs, marcher, d2n, loss_seed=5, ratio=1.5):
+    SDFRenderer = rh.reference_modules()[0]
+    r = SDFRenderer(dec, K, img_hw=(H, W), march_step=march_step, buffer_size=bs, ray_marching_ratio=ratio,
+                    use_gpu=False, use_depth2normal=d2n)
+    lat = torch.from_numpy(latent).clone().requires_grad_(True)
+    Rt = torch.from_numpy(R).clone().requires_grad_(True)
+    Tt = torch.from_numpy(T).clone().requires_grad_(True)
+    depth, normal, mask, mq = r.render(lat, Rt, Tt, ray_marching_type=marcher)
+    wd, wq, wn = loss_weights(H, W, loss_seed)
+    mb = mask.bool()
+    L = (depth * torch.from_numpy(wd))[mb].sum() + (mq * torch.from_numpy(wq)).sum() + (normal * torch.from_numpy(wn)).sum()
+    L.backward()
+    with torch.no_grad():
+        Zdepth, vmask, _ = r.render_depth(lat, Rt, Tt, ray_marching_type=marcher, no_grad=True)
+    return dict(depth=depth.detach().numpy(), normal=normal.detach().numpy(), mask=mask.numpy(),
+                min_abs_query=mq.detach().numpy(), zdepth=Zdepth.numpy(), loss=np.float64(L.item()),
+                g_latent=lat.grad.numpy(), g_R=Rt.grad.numpy(), g_T=Tt.grad.numpy())
+
+
+def meta(Ws, bs, latent, K, R, T, H, W, march_step, bsz, marcher, d2n, loss_seed=5, ratio=1.5, weight_norm=False):
+    return dict(weights_sha256=fixture.weights_sha256(Ws, bs), fixture_seed=1234, latent=latent, K=K, R=R, T=T,
+                H=H, W=W, march_step=march_step, buffer_size=bsz, marcher=marcher, use_depth2normal=d2n,
+                loss_seed=loss_seed, ratio=ratio, weight_norm=weight_norm)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs, weight_norm=False)
+    du = rh.reference_modules()[3]
+
+    # ---- G2: decode_sdf / decode_sdf_gradient on fixed points (decoder_utils.py:53-92)
+    rs = np.random.RandomState(7)
+    pts = (rs.rand(4096, 3) * 1.6 - 0.8).astype(np.float32)
+    pts[:8] = 0.0                                             # origin (pad-row sample point)
+    with torch.no_grad():
+        sdf = du.decode_sdf(dec, torch.from_numpy(latent), torch.from_numpy(pts), clamp_dist=None).squeeze(-1).numpy()
+        sdf_c = du.decode_sdf(dec, torch.from_numpy(latent), torch.from_numpy(pts), clamp_dist=0.1).squeeze(-1).numpy()
+    p = torch.from_numpy(pts).clone().requires_grad_(True)
+    grad3 = du.decode_sdf_gradient(dec, torch.from_numpy(latent), p, clamp_dist=0.1).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'g2_decode_sdf.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent,
+                        points=pts, sdf=sdf, sdf_clamped=sdf_c, gradient_x3_clamped=grad3)
+    print('g2 done', sdf.min(), sdf.max())
+
+    # ---- G1: C1 = 64x64, 20 steps, bs=3, rotated camera; 3 marchers x {autograd normal, depth2normal}
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(30, 20, 1.6, 10)
+    for marcher in ['trivial', 'recursive', 'pyramid_recursive']:
+        for d2n in [False, True]:
+            out = render_case(dec, latent, K, R, T, H, W, 20, 3, marcher, d2n)
+            out.update(meta(Ws, bs, latent, K, R, T, H, W, 20, 3, marcher, d2n))
+            name = 'g1_c1_%s_%s.npz' % (marcher, 'd2n' if d2n else 'agn')
+            np.savez_compressed(os.path.join(OUT, name), **out)
+            print(name, 'valid', int(out['mask'].sum()), 'glat', float(np.linalg.norm(out['g_latent'])))
+
+    # ---- G1b: odd image size (pyramid ceil paths), identity camera, ratio 1.0, bs=5, 30 steps
+    H, W = 50, 70
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(0, 0, 1.6, 0)
+    out = render_case(dec, latent, K, R, T, H, W, 30, 5, 'pyramid_recursive', False, ratio=1.0)
+    out.update(meta(Ws, bs, latent, K, R, T, H, W, 30, 5, 'pyramid_recursive', False, ratio=1.0))
+    np.savez_compressed(os.path.join(OUT, 'g1b_odd_pyramid.npz'), **out)
+    print('g1b', int(out['mask'].sum()))
+
+    # ---- G1c: DeepSDF's weight_norm decoder configuration (packer path), C1 pyramid, depth2normal
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(30, 20, 1.6, 10)
+    dec_wn = rh.build_reference_decoder(Ws, bs, weight_norm=True)
+    out = render_case(dec_wn, latent, K, R, T, H, W, 20, 3, 'pyramid_recursive', True)
+    out.update(meta(Ws, bs, latent, K, R, T, H, W, 20, 3, 'pyramid_recursive', True, weight_norm=True))
+    with torch.no_grad():
+        dec_wn.inference(torch.zeros(1, 259))
+    sd = dec_wn.state_dict()
+    out['lin1_weight_g'] = sd['lin1.weight_g'].numpy()
+    out['lin1_effective_row0'] = dec_wn.lin1.weight.detach().numpy()[0]
+    np.savez_compressed(os.path.join(OUT, 'g1c_weightnorm.npz'), **out)
+    print('g1c', int(out['mask'].sum()))
+
+    # ---- G3: C2 = 256x256, 50 steps: 32x32 crop + scalar summaries, both default marchers
+    H = W = 256
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-40, 25, 1.6, 0)
+    y0, x0 = 96, 112
+    for marcher in ['recursive', 'pyramid_recursive']:
+        out = render_case(dec, latent, K, R, T, H, W, 50, 3, marcher, True)
+        full_mask = out['mask']
+        summ = dict(valid_count=int(full_mask.sum()), sum_depth=float(out['depth'][full_mask.astype(bool)].sum()),
+                    sum_q=float(out['min_abs_query'].sum()))
+        crop = {k: out[k][y0:y0 + 32, x0:x0 + 32] for k in ['depth', 'normal', 'mask', 'min_abs_query']}
+        crop['zdepth'] = out['zdepth'].reshape(H, W)[y0:y0 + 32, x0:x0 + 32]
+        crop.update(g_latent=out['g_latent'], g_R=out['g_R'], g_T=out['g_T'], loss=out['loss'], crop_y0=y0, crop_x0=x0, **summ)
+        crop.update(meta(Ws, bs, latent, K, R, T, H, W, 50, 3, marcher, True))
+        np.savez_compressed(os.path.join(OUT, 'g3_c2_%s_d2n.npz' % marcher), **crop)
+        print('g3', marcher, summ)
+
+    # ---- noise floor of the reference itself: weights perturbed by 1e-7 relative
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(30, 20, 1.6, 10)
+    rsn = np.random.RandomState(99)
+    Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
+    dec_n = rh.build_reference_decoder(Wn, bs, weight_norm=False)
+    floor = {}
+    for marcher in ['recursive', 'pyramid_recursive']:
+        a = render_case(dec, latent, K, R, T, H, W, 20, 3, marcher, False)
+        b = render_case(dec_n, latent, K, R, T, H, W, 20, 3, marcher, False)
+        both = a['mask'].astype(bool) & b['mask'].astype(bool)
+        floor[marcher + '_flips'] = int((a['mask'] != b['mask']).sum())
+        floor[marcher + '_depth'] = float(np.abs(a['depth'] - b['depth'])[both].max())
+        floor[marcher + '_min_sdf'] = float(np.abs(a['min_abs_query'] - b['min_abs_query']).max())
+        floor[marcher + '_normal'] = float(np.abs(a['normal'] - b['normal'])[both].max())
+        floor[marcher + '_g_latent_rel'] = float(np.abs(a['g_latent'] - b['g_latent']).max() / np.abs(a['g_latent']).max())
+    np.savez_compressed(os.path.join(OUT, 'noise_floor_c1.npz'), **floor)
+    print('noise floor', floor)
+    noise_floor_c2(dec, dec_n, latent)
+
+
+def noise_floor_c2(dec, dec_n, latent):
+    # C2 with depth2normal: the finite-difference normal loss amplifies per-pixel depth noise by fx/2, so the
+    # reference's own gradients move by ~3e-3 relative under 1e-7 weight noise -- the bar for test_c2_*.
+    H = W = 256
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-40, 25, 1.6, 0)
+    a = render_case(dec, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
+    b = render_case(dec_n, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
+    floor = {'flips': int((a['mask'] != b['mask']).sum())}
+    for k in ['g_latent', 'g_R', 'g_T']:
+        floor[k + '_rel'] = float(np.abs(a[k] - b[k]).max() / np.abs(a[k]).max())
+    np.savez_compressed(os.path.join(OUT, 'noise_floor_c2_pyramid_d2n.npz'), **floor)
+    print('noise floor c2', floor)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '--noise-c2':
+        Ws, bs, latent = fixture.make_decoder_weights()
+        rsn = np.random.RandomState(99)
+        Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
+        noise_floor_c2(rh.build_reference_decoder(Ws, bs), rh.build_reference_decoder(Wn, bs), latent)
+    else:
+        main()

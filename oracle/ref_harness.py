@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE -- runs ONLY in the build container (needs /root/reference).
+
+Imports the reference renderer (B1ueber2y/DIST-Renderer, unmodified source under
+/root/reference) on CPU so that golden vectors can be generated for tests/golden/.
+Nothing here ships to the GPU box and nothing in the product imports it.
+
+The reference targets torch 1.1 / CUDA; to run on today's CPU torch it needs the
+harness-side shims below (none of them edits reference code):
+  1. stub modules for imports that are absent here (cv2, trimesh, ...),
+     with torch_scatter.scatter_max restated through Tensor.scatter_reduce('amax')
+     (call site core/sdfrenderer/renderer.py:677-679);
+  2. torch.cuda.synchronize -> no-op (core/visualize/profiler.py:8);
+  3. Tensor.get_device -> .device (renderer.py:352,618,700 do `.to(x.get_device())`, -1 on CPU);
+  4. Tensor.__setitem__ clones a mask that indexes itself (renderer.py:874);
+  5. autograd.grad sums grad_outputs to the output shape (decoder_utils.py:84; torch 1.1
+     accepted the (n,3) grad_outputs for an (n,1) output and summed it => 3x gradient);
+  6. Tensor.cuda -> identity (renderer_warp.py:43);
+  7. F.grid_sample forced to align_corners=True (torch 1.1 behaviour, loss_utils.py:24);
+  8. Tensor.type() reports 'torch.cuda.ByteTensor' for uint8 (loss_utils.py:43-47).
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = '/root/reference'
+_installed = False
+
+
+def install_shims():
+    global _installed
+    if _installed:
+        return
+    _installed = True
+    warnings.filterwarnings('ignore')
+    for n in ['cv2', 'trimesh', 'plyfile', 'easydict', 'mathutils', 'skimage', 'skimage.measure',
+              'torch_scatter', 'OpenEXR', 'Imath']:
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules['skimage'].measure = sys.modules['skimage.measure']
+    sys.modules['easydict'].EasyDict = dict
+
+    def scatter_max(src, index, dim=-1, dim_size=None):
+        n = int(index.max()) + 1 if dim_size is None else dim_size
+        out = torch.zeros(n, dtype=src.dtype).scatter_reduce(0, index, src, reduce='amax', include_self=True)
+        return out, None
+    sys.modules['torch_scatter'].scatter_max = scatter_max
+
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.Tensor.get_device = lambda self: self.device
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    _si = torch.Tensor.__setitem__
+
+    def _setitem(s, i, v):
+        if isinstance(i, torch.Tensor) and i is s:
+            i = i.clone()
+        return _si(s, i, v)
+    torch.Tensor.__setitem__ = _setitem
+
+    _g = torch.autograd.grad
+
+    def grad(outputs, inputs, grad_outputs=None, **kw):
+        if isinstance(outputs, torch.Tensor) and isinstance(grad_outputs, torch.Tensor) \
+                and grad_outputs.shape != outputs.shape:
+            grad_outputs = grad_outputs.sum_to_size(outputs.shape)
+        return _g(outputs, inputs, grad_outputs=grad_outputs, **kw)
+    torch.autograd.grad = grad
+
+    import torch.nn.functional as F
+    _gs = F.grid_sample
+
+    def grid_sample(inp, grid, mode='bilinear', padding_mode='zeros', align_corners=None):
+        return _gs(inp, grid, mode=mode, padding_mode=padding_mode, align_corners=True)
+    F.grid_sample = grid_sample
+
+    _type = torch.Tensor.type
+
+    def type_(self, *a, **k):
+        if not a and not k and self.dtype == torch.uint8:
+            return 'torch.cuda.ByteTensor'
+        return _type(self, *a, **k)
+    torch.Tensor.type = type_
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+
+
+def reference_modules():
+    """Returns (SDFRenderer, SDFRenderer_warp, Decoder, decoder_utils module) of the reference."""
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError('reference tree not present; goldens can only be generated in the build container')
+    install_shims()
+    # make sure `core` resolves to the reference, not to this repo's drop-in mirror
+    for k in [k for k in sys.modules if k == 'core' or k.startswith('core.')]:
+        del sys.modules[k]
+    sys.path = [p for p in sys.path if not p.rstrip('/').endswith('dist-renderer_amd')]
+    if sys.path[0] != REFERENCE_ROOT:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from core.sdfrenderer.renderer import SDFRenderer
+    from core.sdfrenderer.renderer_warp import SDFRenderer_warp
+    from core.graph.deep_sdf_decoder import Decoder
+    import core.utils.decoder_utils as decoder_utils
+    assert SDFRenderer.__module__ and os.path.abspath(sys.modules[SDFRenderer.__module__].__file__).startswith(REFERENCE_ROOT)
+    return SDFRenderer, SDFRenderer_warp, Decoder, decoder_utils
+
+
+def build_reference_decoder(Ws, bs, weight_norm=False):
+    """Reference ``Decoder`` (core/graph/deep_sdf_decoder.py:18) holding the fixture weights.
+
+    weight_norm=False: plain nn.Linear layers (norm_layers=()) so the effective weights are
+    bit-identical to the arrays handed to the packer/oracle.
+    weight_norm=True:  DeepSDF's published configuration (weight_norm on lin0..7):
+    weight_v = W, weight_g = ||W||_row, effective W = g*v/||v||.
+    """
+    _, _, Decoder, _ = reference_modules()
+    if weight_norm:
+        dec = Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)),
+                      latent_in=[4], xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=True)
+    else:
+        dec = Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=(),
+                      latent_in=[4], xyz_in_all=False, use_tanh=False, latent_dropout=False, weight_norm=False)
+    sd = {}
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        Wt, bt = torch.from_numpy(W.copy()), torch.from_numpy(b.copy())
+        if weight_norm and l < 8:
+            sd['lin%d.weight_v' % l] = Wt
+            sd['lin%d.weight_g' % l] = Wt.norm(dim=1, keepdim=True)
+        else:
+            sd['lin%d.weight' % l] = Wt
+        sd['lin%d.bias' % l] = bt
+    dec.load_state_dict(sd)
+    dec.eval()
+    return dec
