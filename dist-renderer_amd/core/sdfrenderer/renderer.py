@@ -1,0 +1,177 @@
+"""SDFRenderer: the reference's differentiable sphere tracer API on top of the MI355X kernels.
+
+Same constructor and method signatures as core/sdfrenderer/renderer.py:12-999 of the reference (cited per
+method), but nothing is marched in PyTorch: `render` / `render_depth` / `render_normal` are single calls into
+libdistr.so (distr.functions), which run the whole march loop, sample selection and backward on the GPU without
+host synchronisation.
+"""
+import numpy as np
+import torch
+
+from distr import binding, functions
+
+
+class SDFRenderer(object):
+    # reference: renderer.py:13
+    def __init__(self, decoder, intrinsic, img_hw=None, transform_matrix=None, march_step=50, buffer_size=5,
+                 ray_marching_ratio=1.5, use_depth2normal=False, max_sample_dist=0.2, radius=1.0, threshold=5e-5,
+                 scale_list=[4, 2, 1], march_step_list=[3, 3, -1], use_gpu=True, is_eval=True):
+        if not use_gpu:
+            raise ValueError('SDFRenderer(use_gpu=False): this build has no CPU path (MI355X kernels only).')
+        if torch.cuda.device_count() == 0:
+            raise ValueError('No GPU device found.')
+        self.decoder = decoder
+        dev = next(decoder.parameters()).device
+        if dev.type != 'cuda':
+            raise ValueError('decoder parameters must live on the GPU')
+        self.device = dev.index if dev.index is not None else torch.cuda.current_device()
+        if is_eval:
+            decoder.eval()
+        self.march_step = march_step
+        self.buffer_size = buffer_size
+        self.max_sample_dist = max_sample_dist
+        self.ray_marching_ratio = ray_marching_ratio
+        self.use_depth2normal = use_depth2normal
+        self.radius = radius
+        self.threshold = threshold
+        self.scale_list = list(scale_list)
+        self.march_step_list = list(march_step_list)
+        if list(self.scale_list) != [4, 2, 1] or len(self.march_step_list) != 3:
+            raise NotImplementedError('only the 3-level pyramid scale_list=[4,2,1] is implemented')
+        if isinstance(intrinsic, torch.Tensor):
+            intrinsic = intrinsic.detach().cpu().numpy()
+        self.intrinsic = intrinsic
+        if img_hw is None:
+            img_hw = (int(intrinsic[1, 2] * 2), int(intrinsic[0, 2] * 2))   # renderer.py:31-33
+        self.img_hw = (int(img_hw[0]), int(img_hw[1]))
+        if transform_matrix is None:
+            transform_matrix = np.array([[1., 0., 0.], [0., 0., -1.], [0., 1., 0.]])   # renderer.py:45
+        self._M_np = np.asarray(transform_matrix, dtype=np.float64)
+        if self._M_np.shape != (3, 3):
+            raise NotImplementedError('3x4 sim3 transform matrices are not supported (the reference path ends in an '
+                                      'un-imported pdb.set_trace(), renderer.py:116)')
+
+        tdev = torch.device('cuda', self.device)
+        h, w = self.img_hw
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+        self.homo_2d = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(h * w)], 0).to(tdev)    # (3, H*W)
+        self.K = torch.from_numpy(np.asarray(intrinsic)).float().to(tdev)
+        self.K_inv = torch.from_numpy(np.linalg.inv(np.asarray(intrinsic, dtype=np.float64))).float().to(tdev)
+        self.homo_calib = torch.matmul(self.K_inv, self.homo_2d)                                     # (3, H*W)
+        self.imgmap_init = torch.zeros(h, w, device=tdev)
+        self.transform_matrix = torch.from_numpy(self._M_np).float().to(tdev)
+        self.calib_map = self.normalize_vectors(self.homo_calib)[2, :]
+        self._engine = functions.get_engine(decoder, self.device)
+        self.last_stats = None
+
+    # ---- small accessors (renderer.py:61-68)
+    def get_intrinsic(self):
+        return self.intrinsic
+
+    def get_threshold(self):
+        return self.threshold
+
+    def get_img_hw(self):
+        return self.img_hw
+
+    # ---- geometry helpers kept for subclasses / callers (renderer.py:84-120, 171-223); plain torch, tiny
+    def transform_points(self, points):
+        return torch.matmul(self.transform_matrix, points)
+
+    def inv_transform_points(self, points):
+        return torch.matmul(self.transform_matrix.t(), points)
+
+    def normalize_vectors(self, x):
+        return x / (torch.norm(x, p=2, dim=0, keepdim=True) + 1e-12)
+
+    def get_camera_location(self, R, T):
+        return -torch.matmul(R.t(), T)
+
+    def get_camera_rays(self, R, homo=None):
+        homo = self.homo_calib if homo is None else homo
+        return self.normalize_vectors(torch.matmul(R.t(), homo))
+
+    def generate_point_samples(self, cam_pos, cam_rays, Zdepth, inv_transform=True, has_zdepth_grad=False):
+        if not has_zdepth_grad:
+            Zdepth = Zdepth.detach()
+        if Zdepth.shape[0] == 0:
+            raise ValueError('No valid depth.')
+        points = cam_rays * Zdepth[None, :] + cam_pos[:, None]
+        if inv_transform:
+            points = self.inv_transform_points(points)
+        return points
+
+    # ---- C-struct for one call
+    def _cfg(self, clamp_dist, ray_marching_type, use_transform, want_normal, normalize_normal=True,
+             no_grad_depth=False, no_grad_mask=False, no_grad_camera=False):
+        msl = list(self.march_step_list)
+        return binding.make_cfg(self.img_hw, self.intrinsic, march_step=self.march_step, buffer_size=self.buffer_size,
+                                ratio=self.ray_marching_ratio, threshold=self.threshold, radius=self.radius,
+                                clamp_dist=clamp_dist, marcher=ray_marching_type, coarse_steps=(msl[0], msl[1]),
+                                transform_matrix=self._M_np, use_transform=use_transform,
+                                use_depth2normal=self.use_depth2normal, normalize_normal=normalize_normal,
+                                want_normal=want_normal, grad_depth=not no_grad_depth, grad_mask=not no_grad_mask,
+                                grad_camera=not no_grad_camera)
+
+    @staticmethod
+    def _check_marcher(ray_marching_type):
+        if ray_marching_type == 'trivial_non_parallel':
+            ray_marching_type = 'trivial'      # per-ray debug loop of renderer.py:422: same values as 'trivial'
+        if ray_marching_type not in binding.MARCHERS:
+            raise ValueError('Error! Invalid type of ray marching: {}.'.format(ray_marching_type))
+        return ray_marching_type
+
+    # reference: renderer.py:836
+    def render_depth(self, latent, R, T, clamp_dist=0.1, sample_index_type='min_abs', profile=False, no_grad=False,
+                     no_grad_depth=False, no_grad_mask=False, no_grad_camera=False, ray_marching_type='recursive',
+                     use_transform=True):
+        if sample_index_type != 'min_abs':
+            raise NotImplementedError("only sample_index_type='min_abs' (the one every caller uses) is implemented")
+        if no_grad:
+            no_grad_depth, no_grad_mask, no_grad_camera = True, True, True
+        cfg = self._cfg(clamp_dist, self._check_marcher(ray_marching_type), use_transform, want_normal=False,
+                        no_grad_depth=no_grad_depth, no_grad_mask=no_grad_mask, no_grad_camera=no_grad_camera)
+        zdepth, mask, min_sdf, _, _ = functions.render_call(self._engine, cfg, latent, R, T)
+        self._last = (cfg, zdepth)
+        if no_grad_depth:
+            zdepth = zdepth.detach()
+        if no_grad_mask and no_grad_camera:
+            min_sdf = min_sdf.detach()
+        return zdepth, mask.bool(), min_sdf          # (H*W), (H*W), (H*W)
+
+    # reference: renderer.py:880
+    def render_normal(self, latent, R, T, Zdepth, valid_mask, clamp_dist=0.1, MAX_POINTS=100000, no_grad=False,
+                      normalize=True, use_transform=True):
+        cfg = self._cfg(clamp_dist, 'recursive', use_transform, want_normal=True, normalize_normal=normalize)
+        cfg.use_depth2normal = 0
+        return functions.render_normal_call(self._engine, cfg, latent, R, T, Zdepth, valid_mask)   # (3, H*W)
+
+    # reference: renderer.py:943
+    def render(self, latent, R, T, clamp_dist=0.1, sample_index_type='min_abs', profile=False, no_grad=False,
+               no_grad_depth=False, no_grad_normal=False, no_grad_mask=False, no_grad_camera=False,
+               normalize_normal=True, use_transform=True, ray_marching_type='pyramid_recursive',
+               num_forward_sampling=0):
+        if sample_index_type != 'min_abs':
+            raise NotImplementedError("only sample_index_type='min_abs' is implemented")
+        if num_forward_sampling != 0:
+            raise NotImplementedError('forward_sampling (renderer.py:912; device-mismatch bug upstream) is not implemented')
+        if no_grad:
+            no_grad_depth, no_grad_normal, no_grad_mask, no_grad_camera = True, True, True, True
+        h, w = self.img_hw
+        cfg = self._cfg(clamp_dist, self._check_marcher(ray_marching_type), use_transform, want_normal=True,
+                        normalize_normal=normalize_normal, no_grad_depth=no_grad_depth, no_grad_mask=no_grad_mask,
+                        no_grad_camera=no_grad_camera)
+        if profile:
+            self._engine.ctx.profile_enable(True)
+        zdepth, mask, min_sdf, depth, normal = functions.render_call(self._engine, cfg, latent, R, T)
+        if profile:
+            n, ms = self._engine.ctx.profile_read()
+            self._engine.ctx.profile_enable(False)
+            print('march kernel: {0} launches\t: {1:.4f} ms'.format(n, ms))
+        if no_grad_depth:
+            depth = depth.detach()
+        if no_grad_normal and not self.use_depth2normal:
+            normal = normal.detach()
+        if no_grad_mask and no_grad_camera:
+            min_sdf = min_sdf.detach()
+        return depth, normal, mask.reshape(h, w), min_sdf.reshape(h, w)

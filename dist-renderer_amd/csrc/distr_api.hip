@@ -1,0 +1,533 @@
+// distr_api.hip -- host side of libdistr.so: C ABI (include/distr.h), weight-fragment packer, workspace carving,
+// kernel launch sequences. Built with: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared.
+// No device allocation / synchronisation happens inside forward/backward (caller-owned workspaces, caller's stream).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "distr_kernels.hpp"
+
+using namespace distr;
+
+struct distr_ctx {
+  int device = 0;
+  std::string err;
+  float* dec_buf = nullptr;  // one device allocation holding every packed array
+  size_t dec_floats = 0;
+  DecoderDev D{};
+  bool has_decoder = false;
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(distr_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(ctx, DISTR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define LAUNCH_CHECK(name)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess) return fail(ctx, DISTR_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// A-fragment packing for v_mfma_f32_32x32x2_f32 (see distr_mlp.hpp::dense):
+//   dst float4 index ((g*4 + w)*NOB + ob)*64 + lane = { W[o][8g+2s+h] : s=0..3 }, o = w*32*NOB + 32*ob + (lane&31), h = lane>>5
+void pack_fragments(const float* W, int K, int O, float* dst) {
+  const int NOB = O / 128, NG = K / 8;
+  for (int g = 0; g < NG; ++g)
+    for (int w = 0; w < 4; ++w)
+      for (int ob = 0; ob < NOB; ++ob)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int o = w * 32 * NOB + 32 * ob + (lane & 31), h = lane >> 5;
+          float* d = dst + ((((size_t)g * 4 + w) * NOB + ob) * 64 + lane) * 4;
+          for (int s = 0; s < 4; ++s) d[s] = W[(size_t)o * K + 8 * g + 2 * s + h];
+        }
+}
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
+  if (!c) return fail(ctx, DISTR_ERR_INVALID_ARG, "cfg is null");
+  if (c->H < 1 || c->W < 1 || (int64_t)c->H * c->W >= (1 << 28)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", c->H, c->W);
+  if (c->buffer_size < 1 || c->buffer_size > MAX_BS) return fail(ctx, DISTR_ERR_UNSUPPORTED, "buffer_size %d not in [1,%d]", c->buffer_size, MAX_BS);
+  if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
+  int fine = c->march_step;
+  if (c->marcher == DISTR_MARCH_PYRAMID_RECURSIVE) {
+    if (c->coarse_steps[0] < 1 || c->coarse_steps[1] < 1) return fail(ctx, DISTR_ERR_UNSUPPORTED, "pyramid needs >=1 step per coarse level");
+    fine -= c->coarse_steps[0] + c->coarse_steps[1];
+  }
+  if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
+  if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
+  return DISTR_OK;
+}
+
+// Lays the forward workspace out; with base==nullptr only sizes are computed.
+size_t make_view(const distr_render_cfg& c, void* base, View& V) {
+  Carver cv(base);
+  memset(&V, 0, sizeof(V));
+  V.cfg = c;
+  V.P = c.H * c.W;
+  V.pyramid = (c.marcher == DISTR_MARCH_PYRAMID_RECURSIVE) ? 1 : 0;
+  V.nlev = V.pyramid ? 3 : 1;
+  V.fine_steps = c.march_step - (V.pyramid ? c.coarse_steps[0] + c.coarse_steps[1] : 0);
+  V.C = cv.take<Consts>(1);
+  V.lv[0].h = c.H; V.lv[0].w = c.W; V.lv[0].scale = 1.f; V.lv[0].off = 0.f;
+  for (int l = 1; l < V.nlev; ++l) {
+    V.lv[l].h = (V.lv[l - 1].h + 1) / 2;
+    V.lv[l].w = (V.lv[l - 1].w + 1) / 2;
+    V.lv[l].scale = V.lv[l - 1].scale * 2.f;
+    V.lv[l].off = (V.lv[l].scale - 1.f) / 2.f;
+  }
+  for (int l = 0; l < V.nlev; ++l) {
+    LevelView& L = V.lv[l];
+    L.n = L.h * L.w;
+    L.steps = (l == 0) ? 0 : c.coarse_steps[V.nlev - 1 - l];
+    L.valid = cv.take<uint8_t>(L.n);
+    L.list = cv.take<int32_t>(L.n);
+    if (l > 0) {
+      L.cinit = cv.take<float>(L.n);
+      L.cm = cv.take<float>(L.n);
+      L.rs = cv.take<float>((size_t)L.steps * L.n);
+      L.rzb = cv.take<float>((size_t)L.steps * L.n);
+      L.rza = cv.take<float>((size_t)L.steps * L.n);
+    }
+  }
+  const size_t P = V.P, bs = c.buffer_size;
+  V.live[0] = cv.take<int32_t>(P);
+  V.live[1] = cv.take<int32_t>(P);
+  V.m = cv.take<float>(P); V.init_now = cv.take<float>(P); V.maxbound = cv.take<float>(P);
+  V.minabs = cv.take<float>(P); V.first_sdf = cv.take<float>(P);
+  V.tk_s = cv.take<float>(bs * P); V.tk_zb = cv.take<float>(bs * P); V.tk_za = cv.take<float>(bs * P);
+  V.tk_src = cv.take<int32_t>(bs * P);
+  V.zdepth_s = cv.take<float>(P); V.depth_pre = cv.take<float>(P); V.nrm_t = cv.take<float>(3 * P);
+  V.mask_s = cv.take<uint8_t>(P);
+  V.nlist = cv.take<int32_t>(P); V.n_sdf = cv.take<float>(P); V.n_g = cv.take<float>(3 * P);
+  return (cv.off + 255) & ~(size_t)255;
+}
+
+size_t bwd_bytes(const distr_render_cfg& c) {
+  const size_t smax = (size_t)c.H * c.W * c.buffer_size + 1;
+  const size_t tiles = (smax + TILE - 1) / TILE;
+  return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + 256;
+}
+
+inline dim3 grid1(int64_t n, int per = 256) { return dim3((unsigned)((n + per - 1) / per)); }
+
+struct MarchTimer {  // optional hipEvent bracket around the march kernel launches
+  distr_ctx* ctx; hipStream_t s; bool on;
+  MarchTimer(distr_ctx* c, hipStream_t st) : ctx(c), s(st), on(c->profiling) {}
+  void begin() {
+    if (!on) return;
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      ctx->ev_pool.emplace_back(a, b);
+    }
+    (void)hipEventRecord(ctx->ev_pool[ctx->ev_used].first, s);
+  }
+  void end() {
+    if (!on) return;
+    (void)hipEventRecord(ctx->ev_pool[ctx->ev_used].second, s);
+    ctx->ev_used++;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* distr_version(void) { return "distr 0.1 (gfx950, f32 MFMA)"; }
+
+int distr_create(distr_ctx** out, int hip_device) {
+  if (!out) return DISTR_ERR_INVALID_ARG;
+  *out = nullptr;
+  distr_ctx* ctx = new distr_ctx();
+  ctx->device = hip_device;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || hip_device < 0 || hip_device >= n) {
+    // keep the context so the caller can read the message
+    ctx->err = std::string("no usable HIP device ") + std::to_string(hip_device) + " (" + (e == hipSuccess ? "count=" + std::to_string(n) : hipGetErrorString(e)) + ")";
+    *out = ctx;
+    return DISTR_ERR_HIP;
+  }
+  *out = ctx;
+  return DISTR_OK;
+}
+
+void distr_destroy(distr_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->dec_buf) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf); }
+  for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  delete ctx;
+}
+
+const char* distr_last_error(const distr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
+  if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
+    return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
+                "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
+  static const int OUT[9] = {512, 512, 512, 253, 512, 512, 512, 512, 1};
+  static const int IN[9] = {259, 512, 512, 512, 512, 512, 512, 512, 512};
+  size_t need = 0;
+  for (int l = 0; l < 9; ++l) need += (size_t)OUT[l] * IN[l] + OUT[l];
+  if (n_floats != need) return fail(ctx, DISTR_ERR_INVALID_ARG, "weight buffer has %zu floats, expected %zu", n_floats, need);
+  const float* W[9]; const float* b[9];
+  const float* p = w;
+  for (int l = 0; l < 9; ++l) { W[l] = p; p += (size_t)OUT[l] * IN[l]; b[l] = p; p += OUT[l]; }
+
+  // padded dense matrices [O][K] of the eight MFMA layers
+  const int Kp[8] = {8, 512, 512, 512, 256, 512, 512, 512};
+  const int Op[8] = {512, 512, 512, 256, 512, 512, 512, 512};
+  std::vector<std::vector<float>> Wp(8);
+  for (int l = 0; l < 8; ++l) Wp[l].assign((size_t)Op[l] * Kp[l], 0.f);
+  for (int o = 0; o < 512; ++o) for (int k = 0; k < 3; ++k) Wp[0][(size_t)o * 8 + k] = W[0][(size_t)o * 259 + 256 + k];
+  for (int l : {1, 2, 5, 6, 7}) memcpy(Wp[l].data(), W[l], sizeof(float) * 512 * 512);
+  for (int o = 0; o < 253; ++o) memcpy(&Wp[3][(size_t)o * 512], &W[3][(size_t)o * 512], sizeof(float) * 512);
+  for (int o = 0; o < 512; ++o) {
+    for (int k = 0; k < 253; ++k) Wp[4][(size_t)o * 256 + k] = W[4][(size_t)o * 512 + k];
+    for (int k = 0; k < 3; ++k) Wp[4][(size_t)o * 256 + 253 + k] = W[4][(size_t)o * 512 + 509 + k];
+  }
+
+  std::vector<float> host;
+  auto reserve = [&](size_t n) { size_t off = (host.size() + 63) & ~(size_t)63; host.resize(off + n, 0.f); return off; };
+  size_t offWf[8], offWb[8] = {0}, offB[8] = {0};
+  for (int l = 0; l < 8; ++l) {
+    offWf[l] = reserve(Wp[l].size());
+    pack_fragments(Wp[l].data(), Kp[l], Op[l], host.data() + offWf[l]);
+  }
+  for (int l = 1; l < 8; ++l) {
+    std::vector<float> Wt((size_t)Kp[l] * Op[l]);
+    for (int o = 0; o < Op[l]; ++o) for (int k = 0; k < Kp[l]; ++k) Wt[(size_t)k * Op[l] + o] = Wp[l][(size_t)o * Kp[l] + k];
+    offWb[l] = reserve(Wt.size());
+    pack_fragments(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], host.data() + offWb[l]);
+  }
+  for (int l : {1, 2, 3, 5, 6, 7}) {
+    offB[l] = reserve(Op[l]);
+    memcpy(host.data() + offB[l], b[l], sizeof(float) * OUT[l]);
+  }
+  const size_t o_W0lat_t = reserve((size_t)LAT * HID), o_W4lat_t = reserve((size_t)LAT * HID);
+  const size_t o_W0lat = reserve((size_t)HID * LAT), o_W4lat = reserve((size_t)HID * LAT);
+  for (int o = 0; o < HID; ++o) for (int k = 0; k < LAT; ++k) {
+    const float v0 = W[0][(size_t)o * 259 + k], v4 = W[4][(size_t)o * 512 + 253 + k];
+    host[o_W0lat_t + (size_t)k * HID + o] = v0; host[o_W0lat + (size_t)o * LAT + k] = v0;
+    host[o_W4lat_t + (size_t)k * HID + o] = v4; host[o_W4lat + (size_t)o * LAT + k] = v4;
+  }
+  const size_t o_b0 = reserve(HID), o_b4 = reserve(HID), o_w8 = reserve(HID), o_W0x = reserve(3 * HID);
+  memcpy(host.data() + o_b0, b[0], sizeof(float) * HID);
+  memcpy(host.data() + o_b4, b[4], sizeof(float) * HID);
+  memcpy(host.data() + o_w8, W[8], sizeof(float) * HID);
+  for (int o = 0; o < HID; ++o) for (int k = 0; k < 3; ++k) host[o_W0x + (size_t)k * HID + o] = W[0][(size_t)o * 259 + 256 + k];
+
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->dec_buf) { HIP_TRY(hipFree(ctx->dec_buf)); ctx->dec_buf = nullptr; }
+  HIP_TRY(hipMalloc((void**)&ctx->dec_buf, host.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(ctx->dec_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  ctx->dec_floats = host.size();
+  DecoderDev& D = ctx->D;
+  const float* d = ctx->dec_buf;
+  for (int l = 0; l < 8; ++l) { D.Wf[l] = d + offWf[l]; D.Wb[l] = l ? d + offWb[l] : nullptr; D.bias[l] = (l == 0 || l == 4) ? nullptr : d + offB[l]; }
+  D.W0lat_t = d + o_W0lat_t; D.W4lat_t = d + o_W4lat_t; D.W0lat = d + o_W0lat; D.W4lat = d + o_W4lat;
+  D.b0 = d + o_b0; D.b4 = d + o_b4; D.w8 = d + o_w8; D.W0x = d + o_W0x;
+  D.b8 = b[8][0];
+  ctx->has_decoder = true;
+  return DISTR_OK;
+}
+
+int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* fwd, size_t* bwd) {
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  View V;
+  if (fwd) *fwd = make_view(*cfg, nullptr, V);
+  if (bwd) *bwd = bwd_bytes(*cfg);
+  return DISTR_OK;
+}
+
+int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
+                         float* zdepth, uint8_t* mask, float* min_sdf, float* depth, float* normal, void* ws, size_t ws_bytes,
+                         void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  if (!latent || !R || !T || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  View V;
+  const size_t need = make_view(*cfg, ws, V);
+  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderDev& D = ctx->D;
+  const int P = V.P;
+
+  hipLaunchKernelGGL(k_prep, dim3(4), dim3(256), 0, s, V.C, D, latent, R, T);
+  LAUNCH_CHECK("k_prep");
+  for (int l = 0; l < V.nlev; ++l) {
+    hipLaunchKernelGGL(k_setup_level, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
+    LAUNCH_CHECK("k_setup_level");
+  }
+  MarchTimer timer(ctx, s);
+  MarchArgs A;
+  memset(&A, 0, sizeof(A));
+  A.V = V;
+  bool origin_done = false;
+  for (int l = V.nlev - 1; l >= 1; --l) {
+    hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
+    LAUNCH_CHECK("k_coarse_init");
+    for (int st = 0; st < V.lv[l].steps; ++st) {
+      A.lvl = l; A.step = st; A.origin_tile = origin_done ? 0 : 1;
+      origin_done = true;
+      const unsigned tiles = (unsigned)((V.lv[l].n + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
+      timer.begin();
+      hipLaunchKernelGGL(k_march<MODE_COARSE>, dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      timer.end();
+      LAUNCH_CHECK("k_march<coarse>");
+    }
+  }
+  hipLaunchKernelGGL(k_fine_init, grid1(P), dim3(256), 0, s, V);
+  LAUNCH_CHECK("k_fine_init");
+  for (int st = 0; st < V.fine_steps; ++st) {
+    A.lvl = 0; A.step = st; A.origin_tile = origin_done ? 0 : 1;
+    origin_done = true;
+    const unsigned tiles = (unsigned)((P + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
+    timer.begin();
+    hipLaunchKernelGGL(k_march<MODE_FINE>, dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    timer.end();
+    LAUNCH_CHECK("k_march<fine>");
+  }
+  hipLaunchKernelGGL(k_finalize, grid1(P), dim3(256), 0, s, V, zdepth, mask, min_sdf, depth);
+  LAUNCH_CHECK("k_finalize");
+  if (cfg->want_normal) {
+    if (cfg->use_depth2normal) {
+      hipLaunchKernelGGL(k_depth2normal, grid1(P), dim3(256), 0, s, V, depth, normal);
+      LAUNCH_CHECK("k_depth2normal");
+    } else {
+      if (normal) HIP_TRY(hipMemsetAsync(normal, 0, (size_t)P * 3 * sizeof(float), s));
+      BwdArgs B;
+      memset(&B, 0, sizeof(B));
+      B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = V.zdepth_s;
+      B.out_sdf = V.n_sdf; B.out_g = V.n_g;
+      hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+      LAUNCH_CHECK("k_bwd<pointgrad>");
+      hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
+                         (const float*)V.n_sdf, (const float*)V.n_g, normal, (float*)nullptr, V.nrm_t);
+      LAUNCH_CHECK("k_normal_finish");
+    }
+  }
+  return DISTR_OK;
+}
+
+__global__ void k_bwd_begin(Consts* C) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < PSTRIDE) C->red[t] = 0.f;
+  if (t < 12) C->cam_acc[t] = 0.f;
+  if (t == 0) { C->cnt_samples = 0; C->pad_coef = 0.f; }
+}
+
+int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, size_t ws_bytes, const float* g_zdepth,
+                          const float* g_min_sdf, const float* g_depth, const float* g_normal, float* g_latent, float* g_R,
+                          float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  if (!ws || !ws_bwd) return fail(ctx, DISTR_ERR_INVALID_ARG, "null workspace");
+  View V;
+  const size_t need = make_view(*cfg, const_cast<void*>(ws), V);
+  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
+  if (ws_bwd_bytes < bwd_bytes(*cfg)) return fail(ctx, DISTR_ERR_WORKSPACE, "backward workspace too small: %zu < %zu", ws_bwd_bytes, bwd_bytes(*cfg));
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderDev& D = ctx->D;
+  const int P = V.P;
+  const size_t smax = (size_t)P * cfg->buffer_size + 1;
+  Carver cv(ws_bwd);
+  Sample* samples = cv.take<Sample>(smax);
+  const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
+  float* partial = cv.take<float>((size_t)tiles * PSTRIDE);
+
+  hipLaunchKernelGGL(k_bwd_begin, dim3((PSTRIDE + 255) / 256), dim3(256), 0, s, V.C);
+  LAUNCH_CHECK("k_bwd_begin");
+  hipLaunchKernelGGL(k_bwd_prep, grid1(P), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples);
+  LAUNCH_CHECK("k_bwd_prep");
+  hipLaunchKernelGGL(k_bwd_pad, dim3(1), dim3(64), 0, s, V, samples);
+  LAUNCH_CHECK("k_bwd_pad");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
+  hipLaunchKernelGGL(k_bwd<BWD_FULL>, dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  LAUNCH_CHECK("k_bwd<full>");
+  const int chunk = 64;
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, (tiles + chunk - 1) / chunk), dim3(256), 0, s, V,
+                     (const float*)partial, chunk);
+  LAUNCH_CHECK("k_bwd_reduce");
+  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, g_latent, g_R, g_T);
+  LAUNCH_CHECK("k_bwd_final");
+  return DISTR_OK;
+}
+
+int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
+                        const float* zdepth, const uint8_t* mask, float* normal3xP, void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  if (!latent || !R || !T || !zdepth || !mask || !normal3xP || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  View V;
+  const size_t need = make_view(*cfg, ws, V);
+  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderDev& D = ctx->D;
+  const int P = V.P;
+  hipLaunchKernelGGL(k_prep, dim3(4), dim3(256), 0, s, V.C, D, latent, R, T);
+  LAUNCH_CHECK("k_prep");
+  HIP_TRY(hipMemsetAsync(normal3xP, 0, (size_t)P * 3 * sizeof(float), s));
+  hipLaunchKernelGGL(k_mask_list, grid1(P), dim3(256), 0, s, P, mask, V.nlist, &V.C->cnt_normal);
+  LAUNCH_CHECK("k_mask_list");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = zdepth; B.out_sdf = V.n_sdf; B.out_g = V.n_g;
+  hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+  LAUNCH_CHECK("k_bwd<pointgrad>");
+  hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
+                     (const float*)V.n_sdf, (const float*)V.n_g, (float*)nullptr, normal3xP, (float*)nullptr);
+  LAUNCH_CHECK("k_normal_finish");
+  return DISTR_OK;
+}
+
+size_t distr_mlp_workspace_bytes(int64_t n) { (void)n; return 2 * HID * sizeof(float) + 256; }
+
+int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float clamp, float* sdf, void* ws,
+                   size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n < 0 || (n > 0 && (!xyz || !sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  if (n == 0) return DISTR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
+  LAUNCH_CHECK("k_latent_consts");
+  MarchArgs A;
+  memset(&A, 0, sizeof(A));
+  A.xyz = xyz; A.sdf_out = sdf; A.c0c4 = c0c4; A.n = n; A.clamp = clamp;
+  MarchTimer timer(ctx, s);
+  timer.begin();
+  hipLaunchKernelGGL(k_march<MODE_EVAL>, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  timer.end();
+  LAUNCH_CHECK("k_march<eval>");
+  return DISTR_OK;
+}
+
+int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float* sdf, float* grad, void* ws,
+                   size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n < 0 || (n > 0 && (!xyz || !sdf || !grad)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  if (n == 0) return DISTR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
+  LAUNCH_CHECK("k_latent_consts");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.n = n; B.xyz = xyz; B.c0c4 = c0c4; B.out_sdf = sdf; B.out_g = grad;
+  hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
+  LAUNCH_CHECK("k_bwd<pointgrad>");
+  return DISTR_OK;
+}
+
+int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, int layer, float* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n <= 0 || !xyz || !out || !latent || !ws || layer < 0 || layer > 7) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
+  LAUNCH_CHECK("k_latent_consts");
+  hipLaunchKernelGGL(k_debug_layer, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
+  LAUNCH_CHECK("k_debug_layer");
+  return DISTR_OK;
+}
+
+int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, distr_render_stats* out, void* stream) {
+  if (!ctx || !ws || !out) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  View V;
+  make_view(*cfg, const_cast<void*>(ws), V);
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local std::vector<char> hostbuf;
+  hostbuf.resize(sizeof(Consts));
+  HIP_TRY(hipMemcpyAsync(hostbuf.data(), V.C, sizeof(Consts), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const Consts* C = (const Consts*)hostbuf.data();
+  memset(out, 0, sizeof(*out));
+  out->num_in_sphere = C->cnt_level[0];
+  int64_t ev = 0, launches = 0;
+  for (int l = 1; l < V.nlev; ++l) { ev += (int64_t)V.lv[l].steps * C->cnt_level[l]; launches += V.lv[l].steps; }
+  if (cfg->marcher == DISTR_MARCH_TRIVIAL) ev += (int64_t)V.fine_steps * C->cnt_level[0];
+  else for (int t = 0; t < V.fine_steps; ++t) ev += C->cnt_live[t];
+  launches += V.fine_steps;
+  out->num_point_evals = ev;
+  out->num_march_launches = launches;
+  out->num_valid = C->cnt_valid;
+  out->num_grad_samples = C->cnt_samples;
+  return DISTR_OK;
+}
+
+int distr_profile_enable(distr_ctx* ctx, int enable) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  ctx->profiling = enable != 0;
+  ctx->ev_used = 0;
+  return DISTR_OK;
+}
+
+int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < ctx->ev_used; ++i) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+    tot += ms;
+  }
+  if (launches) *launches = (int64_t)ctx->ev_used;
+  if (total_ms) *total_ms = tot;
+  ctx->ev_used = 0;
+  return DISTR_OK;
+}
+
+}  // extern "C"

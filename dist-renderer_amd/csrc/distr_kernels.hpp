@@ -1,0 +1,877 @@
+// distr_kernels.hpp -- device-side data layout + all HIP kernels of the DIST hot path (gfx950).
+//
+// Reference functions restated here (paths under the reference tree):
+//   ray setup / unit-sphere init        core/sdfrenderer/renderer.py:171-282
+//   trivial / recursive / pyramid march core/sdfrenderer/renderer.py:472-583, 713-805
+//   min-|sdf| sample selection          core/sdfrenderer/renderer.py:304-420   (done ONLINE: O(bs) state per ray
+//                                        instead of the reference's (steps x N x 5) history tensors)
+//   render_depth / render outputs       core/sdfrenderer/renderer.py:836-878, 943-999
+//   depth2normal                        core/utils/render_utils.py:9-43
+//   autograd backward                   (PyTorch tape in the reference; SURVEY.md Appendix A.6 contract)
+#pragma once
+#include "distr_mlp.hpp"
+#include "../../include/distr.h"
+
+namespace distr {
+
+constexpr int MAX_BS = DISTR_MAX_BUFFER_SIZE;
+constexpr int MAX_STEPS = 2048;
+constexpr int PSTRIDE = 1040;  // floats per backward tile partial: sd0[512] sd4[512] gR[9] gc[3] pad[4]
+
+struct Consts {
+  float c0[HID];          // b0 + W0[:, :256] * latent
+  float c4[HID];          // b4 + W4[:, 253:509] * latent
+  float latent[LAT];
+  float R[9], T[3], c[3];
+  float cdist;
+  int32_t inside;         // camera inside the unit sphere (renderer.py:266-268)
+  float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
+  uint32_t maxinit_bits[3];
+  int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
+  int32_t cnt_valid;
+  int32_t cnt_normal;
+  int32_t cnt_samples;
+  float pad_coef;
+  float cam_acc[12];      // backward: gR[9] + g_campos[3] from non-MLP terms
+  float red[PSTRIDE];     // backward: reduced tile partials
+  int32_t cnt_live[MAX_STEPS + 2];  // live rays entering fine step t
+};
+
+struct LevelView {
+  int32_t h, w, n, steps;
+  float scale, off;       // pixel centre = scale*i + off  (renderer.py:616-617)
+  uint8_t* valid;
+  int32_t* list;
+  float* cinit;           // start depth of this level
+  float* cm;              // marching depth
+  float* rs;              // [steps][n] sdf rows
+  float* rzb;             // [steps][n] depth before the step
+  float* rza;             // [steps][n] depth after the step
+};
+
+struct View {
+  distr_render_cfg cfg;
+  Consts* C;
+  LevelView lv[3];
+  int32_t nlev, P, fine_steps, pyramid;
+  int32_t* live[2];
+  float *m, *init_now, *maxbound, *minabs, *first_sdf;
+  float *tk_s, *tk_zb, *tk_za;   // [bs][P] selected rows: sdf, depth before, depth after (pyramid) / marching depth after
+  int32_t* tk_src;               // [bs][P] (level<<28 | ray) or -1 for a padded row
+  float *zdepth_s, *depth_pre, *nrm_t;
+  uint8_t* mask_s;
+  int32_t* nlist;
+  float *n_sdf, *n_g;
+};
+
+struct Sample { int32_t src; float zb; float coef; int32_t flags; };
+
+// ------------------------------------------------------------------------------------------ geometry
+struct RayGeo { float d[3], r[3], hx, hy, hz, rn, calib; };
+struct Sph { float dist, chord, init_raw, ptq; float v[3]; bool in; };
+
+__device__ __forceinline__ RayGeo make_ray(const float* Ki, const float* R, float px, float py) {
+  RayGeo g;
+  g.hx = Ki[0] * px + Ki[1] * py + Ki[2];
+  g.hy = Ki[3] * px + Ki[4] * py + Ki[5];
+  g.hz = Ki[6] * px + Ki[7] * py + Ki[8];
+  const float hn = sqrtf(g.hx * g.hx + g.hy * g.hy + g.hz * g.hz);
+  g.calib = g.hz / (hn + 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.r[i] = R[0 * 3 + i] * g.hx + R[1 * 3 + i] * g.hy + R[2 * 3 + i] * g.hz;
+  g.rn = sqrtf(g.r[0] * g.r[0] + g.r[1] * g.r[1] + g.r[2] * g.r[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g.d[i] = g.r[i] / (g.rn + 1e-12f);
+  return g;
+}
+
+__device__ __forceinline__ Sph intersect(float radius, const float* c, float cdist, const float* d) {
+  Sph s;
+  s.ptq = c[0] * d[0] + c[1] * d[1] + c[2] * d[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s.v[i] = c[i] - s.ptq * d[i];
+  s.dist = sqrtf(s.v[0] * s.v[0] + s.v[1] * s.v[1] + s.v[2] * s.v[2]);
+  s.in = s.dist <= radius;
+  const float value = radius * radius - s.dist * s.dist;
+  s.chord = value >= 0.f ? 2.0f * sqrtf(value) : 0.f;
+  s.init_raw = sqrtf(cdist * cdist - s.dist * s.dist) - s.chord / 2.0f;
+  return s;
+}
+
+__device__ __forceinline__ void make_point(const float* M, const float* c, const float* d, float zd, float* p) {
+  float q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = d[i] * zd + c[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = M[0 * 3 + i] * q[0] + M[1 * 3 + i] * q[1] + M[2 * 3 + i] * q[2];
+}
+
+__device__ __forceinline__ void level_center(const LevelView& L, int i, float& px, float& py) {
+  px = L.scale * (float)(i % L.w) + L.off;
+  py = L.scale * (float)(i / L.w) + L.off;
+}
+
+struct CamRegs { float R[9], c[3], cdist; int inside; };
+__device__ __forceinline__ CamRegs load_cam(const Consts* C) {
+  CamRegs k;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k.R[i] = C->R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) k.c[i] = C->c[i];
+  k.cdist = C->cdist;
+  k.inside = C->inside;
+  return k;
+}
+
+// wave-level stream compaction: appends `id` of flagged lanes to list, one atomic per wavefront
+__device__ __forceinline__ void wave_append(bool flag, int32_t id, int32_t* list, int32_t* counter) {
+  const unsigned long long ball = __ballot(flag);
+  if (ball == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int n = __popcll(ball);
+  int base = 0;
+  if (lane == 0) base = atomicAdd(counter, n);
+  base = __shfl(base, 0);
+  if (flag) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = id;
+}
+
+// ------------------------------------------------------------------------------------------ k_prep
+__global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const float* __restrict__ latent,
+                                              const float* __restrict__ R, const float* __restrict__ T) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;  // 1024 threads
+  {
+    const int o = gid & 511;
+    const float* Wt = (gid < 512) ? D.W0lat_t : D.W4lat_t;
+    float acc = (gid < 512) ? D.b0[o] : D.b4[o];
+#pragma unroll 8
+    for (int k = 0; k < LAT; ++k) acc = __builtin_fmaf(Wt[k * HID + o], latent[k], acc);
+    if (gid < 512) C->c0[o] = acc; else C->c4[o] = acc;
+  }
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    C->latent[t] = latent[t];
+    for (int i = t; i < MAX_STEPS + 2; i += 256) C->cnt_live[i] = 0;
+    for (int i = t; i < PSTRIDE; i += 256) C->red[i] = 0.f;
+    if (t < 12) C->cam_acc[t] = 0.f;
+    if (t < 3) { C->maxinit_bits[t] = 0u; C->cnt_level[t] = 0; }
+    if (t == 0) {
+      float c[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) C->R[i] = R[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) C->T[i] = T[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { c[i] = -(R[0 * 3 + i] * T[0] + R[1 * 3 + i] * T[1] + R[2 * 3 + i] * T[2]); C->c[i] = c[i]; }
+      const float cd = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      C->cdist = cd;
+      C->inside = cd < 1.0f ? 1 : 0;  // patched with cfg.radius by k_setup_level (radius is a cfg field)
+      C->f_origin = 0.f;
+      C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
+    }
+  }
+}
+
+// latent constants only (decode_sdf / decode_sdf_gradient entry points)
+__global__ void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, DecoderDev D, const float* __restrict__ latent) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int o = gid & 511;
+  const float* Wt = (gid < 512) ? D.W0lat_t : D.W4lat_t;
+  float acc = (gid < 512) ? D.b0[o] : D.b4[o];
+#pragma unroll 8
+  for (int k = 0; k < LAT; ++k) acc = __builtin_fmaf(Wt[k * HID + o], latent[k], acc);
+  c0c4[gid] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ ray setup
+// get_intersections_with_unit_spheres (renderer.py:254-273) for one pyramid level; coarse masks are the OR of the
+// 2x2 children (maxpool_valid_mask_with_index / torch_scatter.scatter_max, renderer.py:668-680).
+__global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
+  const LevelView& L = V.lv[lvl];
+  Consts* C = V.C;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const CamRegs cam = load_cam(C);
+  const bool inside = cam.cdist < V.cfg.radius;
+  if (i == 0 && lvl == 0) C->inside = inside ? 1 : 0;
+  bool valid = false;
+  if (i < L.n) {
+    float px, py;
+    level_center(L, i, px, py);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, px, py);
+    const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+    if (lvl == 0) {
+      valid = s.in;
+    } else {
+      const LevelView& F = V.lv[lvl - 1];
+      const int y = i / L.w, x = i % L.w;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int fy = 2 * y + dy, fx = 2 * x + dx;
+          if (fy < F.h && fx < F.w) valid = valid || (F.valid[fy * F.w + fx] != 0);
+        }
+    }
+    L.valid[i] = valid ? 1 : 0;
+    if (s.in && !inside) atomicMax(&C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
+  }
+  wave_append(valid, i, L.list, &C->cnt_level[lvl]);
+}
+
+// start depth of a coarse level: unit-sphere entry (coarsest) or the parent's last marched depth (renderer.py:766-769)
+__global__ void __launch_bounds__(256) k_coarse_init(View V, int lvl) {
+  const LevelView& L = V.lv[lvl];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L.n) return;
+  float init;
+  if (lvl == V.nlev - 1) {
+    const CamRegs cam = load_cam(V.C);
+    float px, py;
+    level_center(L, i, px, py);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, px, py);
+    const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+    const bool inside = cam.cdist < V.cfg.radius;
+    init = inside ? 0.f : (s.in ? s.init_raw : __uint_as_float(V.C->maxinit_bits[lvl]));
+  } else {
+    const LevelView& Pp = V.lv[lvl + 1];
+    const int par = ((i / L.w) / 2) * Pp.w + ((i % L.w) / 2);
+    init = Pp.rza[(size_t)(Pp.steps - 1) * Pp.n + par];
+  }
+  L.cinit[i] = init;
+  L.cm[i] = 0.f;
+}
+
+// selected-row buffer: bs entries sorted by |sdf| ascending, earlier row wins ties (renderer.py:314-318 topk)
+__device__ __forceinline__ void topk_insert(const View& V, int px, float s, float zb, float za, int32_t src) {
+  const int bs = V.cfg.buffer_size;
+  const size_t P = (size_t)V.P;
+  const float key = fabsf(s);
+  int pos = bs;
+  for (int k = bs - 1; k >= 0; --k) {
+    const float sk = V.tk_s[k * P + px];
+    if (key < fabsf(sk)) pos = k; else break;
+  }
+  if (pos >= bs) return;
+  for (int k = bs - 1; k > pos; --k) {
+    V.tk_s[k * P + px] = V.tk_s[(k - 1) * P + px];
+    V.tk_zb[k * P + px] = V.tk_zb[(k - 1) * P + px];
+    V.tk_za[k * P + px] = V.tk_za[(k - 1) * P + px];
+    V.tk_src[k * P + px] = V.tk_src[(k - 1) * P + px];
+  }
+  V.tk_s[pos * P + px] = s;
+  V.tk_zb[pos * P + px] = zb;
+  V.tk_za[pos * P + px] = za;
+  V.tk_src[pos * P + px] = src;
+}
+
+// per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
+__global__ void __launch_bounds__(256) k_fine_init(View V) {
+  const LevelView& L0 = V.lv[0];
+  Consts* C = V.C;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  bool live = false;
+  if (px < V.P && L0.valid[px]) {
+    const CamRegs cam = load_cam(C);
+    float cx, cy;
+    level_center(L0, px, cx, cy);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+    const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+    const bool inside = cam.cdist < V.cfg.radius;
+    const float init_orig = inside ? 0.f : s.init_raw;
+    const float maxbound = init_orig + s.chord;
+    float init_now = init_orig;
+    const size_t P = (size_t)V.P;
+    const int y = px / L0.w, x = px % L0.w;
+    if (V.pyramid) {
+      const LevelView& L1 = V.lv[1];
+      const int par1 = (y / 2) * L1.w + (x / 2);
+      init_now = L1.rza[(size_t)(L1.steps - 1) * L1.n + par1];
+    }
+    for (int k = 0; k < V.cfg.buffer_size; ++k) {
+      V.tk_s[k * P + px] = 1.0f;
+      V.tk_zb[k * P + px] = 0.f;
+      V.tk_za[k * P + px] = V.pyramid ? init_now : 0.f;
+      V.tk_src[k * P + px] = -1;
+    }
+    if (V.pyramid) {
+      for (int lvl = V.nlev - 1; lvl >= 1; --lvl) {
+        const LevelView& Lc = V.lv[lvl];
+        const int par = (y >> lvl) * Lc.w + (x >> lvl);
+        for (int st = 0; st < Lc.steps; ++st) {
+          const size_t o = (size_t)st * Lc.n + par;
+          topk_insert(V, px, Lc.rs[o], Lc.rzb[o], Lc.rza[o], (lvl << 28) | par);
+        }
+      }
+    }
+    V.m[px] = 0.f;
+    V.init_now[px] = init_now;
+    V.maxbound[px] = maxbound;
+    V.minabs[px] = INFINITY;
+    V.first_sdf[px] = 1.0f;
+    live = (V.cfg.marcher == DISTR_MARCH_TRIVIAL) ? true : ((0.f + init_now) < maxbound);
+  }
+  if (V.cfg.marcher != DISTR_MARCH_TRIVIAL) wave_append(live, px, V.live[0], &C->cnt_live[0]);
+}
+
+// ------------------------------------------------------------------------------------------ the march kernel
+// One launch = one marching step over a compacted list of rays: gather ray state -> sample point -> fused 9-layer
+// decoder (distr_mlp.hpp) -> aggressive step update, online min-|sdf| selection, convergence/escape masking and
+// ballot compaction of the rays that stay live (renderer.py:481-494, 528-567). Launched with the worst-case grid;
+// workgroups beyond the device-side count exit immediately, so the host never synchronises inside the loop.
+enum { MODE_EVAL = 0, MODE_COARSE = 1, MODE_FINE = 2 };
+
+struct MarchArgs {
+  View V;
+  int32_t lvl, step;
+  int32_t origin_tile;       // the last workgroup evaluates f(origin) instead of a tile
+  const float* xyz;          // MODE_EVAL
+  float* sdf_out;
+  const float* c0c4;         // MODE_EVAL: latent constants
+  int64_t n;
+  float clamp;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_march(MarchArgs A, DecoderDev D) {
+  __shared__ Smem S;
+  const View& V = A.V;
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  bool origin = false;
+  if (MODE != MODE_EVAL && A.origin_tile && tile == (int)gridDim.x - 1) origin = true;
+
+  int64_t count;
+  const int32_t* list = nullptr;
+  if (MODE == MODE_EVAL) {
+    count = A.n;
+  } else if (MODE == MODE_COARSE) {
+    count = V.C->cnt_level[A.lvl];
+    list = V.lv[A.lvl].list;
+  } else {
+    if (V.cfg.marcher == DISTR_MARCH_TRIVIAL) { count = V.C->cnt_level[0]; list = V.lv[0].list; }
+    else { count = V.C->cnt_live[A.step]; list = V.live[A.step & 1]; }
+  }
+  const int64_t base = (int64_t)tile * TILE;
+  if (!origin && base >= count) return;
+
+  int32_t id = -1;
+  float zd = 0.f;
+  bool valid = false;
+  if (tid < TILE) {
+    float p[3] = {0.f, 0.f, 0.f};
+    if (!origin) {
+      const int64_t r = base + tid;
+      valid = r < count;
+      if (valid) {
+        if (MODE == MODE_EVAL) {
+          id = (int32_t)r;
+          p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
+        } else {
+          id = list[r];
+          const LevelView& L = V.lv[MODE == MODE_COARSE ? A.lvl : 0];
+          const CamRegs cam = load_cam(V.C);
+          float cx, cy;
+          level_center(L, id, cx, cy);
+          const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+          zd = (MODE == MODE_COARSE) ? (L.cinit[id] + L.cm[id]) : (V.init_now[id] + V.m[id]);
+          make_point(V.cfg.M, cam.c, g.d, zd, p);
+        }
+      }
+    }
+    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+  }
+  __syncthreads();
+
+  uint32_t masks[8][4];
+  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
+  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
+  const float pre = mlp_forward<false>(D, c0, c4, S, masks);
+
+  if (tid >= TILE) return;  // epilogue: wave 0, lane = ray of the tile
+  const float s = tanh_spec(pre);
+  if (origin) { if (tid == 0) V.C->f_origin = s; return; }
+
+  if (MODE == MODE_EVAL) {
+    if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
+    return;
+  }
+  const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+  if (MODE == MODE_COARSE) {
+    if (valid) {
+      const LevelView& L = V.lv[A.lvl];
+      const float mn = L.cm[id] + clampf(s, -cd, cd) * ratio;
+      L.cm[id] = mn;
+      const size_t o = (size_t)A.step * L.n + id;
+      L.rs[o] = s;
+      L.rzb[o] = zd;
+      L.rza[o] = mn + L.cinit[id];
+    }
+    return;
+  }
+  // MODE_FINE
+  bool stay = false;
+  if (valid) {
+    const float init_now = V.init_now[id];
+    const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
+    V.m[id] = mn;
+    const float za = mn + init_now;
+    topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
+    const float a = fabsf(s);
+    if (a < V.minabs[id]) V.minabs[id] = a;
+    if (A.step == 0) V.first_sdf[id] = s;
+    stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+  }
+  if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
+    wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
+}
+
+// test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
+__global__ void __launch_bounds__(256, 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer, float* out,
+                                                        DecoderDev D) {
+  __shared__ Smem S;
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  if (tid < TILE) {
+    const int64_t r = base + tid;
+    const bool v = r < n;
+    S.xyz[tid] = v ? xyz[r * 3] : 0.f; S.xyz[TILE + tid] = v ? xyz[r * 3 + 1] : 0.f; S.xyz[2 * TILE + tid] = v ? xyz[r * 3 + 2] : 0.f;
+  }
+  __syncthreads();
+  uint32_t masks[8][4];
+  mlp_forward<false, true>(D, c0c4, c0c4 + HID, S, masks, layer);
+  __syncthreads();
+  for (int i = tid; i < HID * TILE; i += 256) {
+    const int f = i / TILE, ray = i % TILE;
+    if (base + ray < n) out[(base + ray) * HID + f] = S.X[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ finalize
+// render_depth's output assembly (renderer.py:859-878) + depth = Zdepth*calib (renderer.py:967-969)
+__global__ void __launch_bounds__(256) k_finalize(View V, float* zdepth, uint8_t* mask, float* min_sdf, float* depth) {
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  Consts* C = V.C;
+  bool vout = false;
+  if (px < V.P) {
+    const LevelView& L0 = V.lv[0];
+    const CamRegs cam = load_cam(C);
+    float cx, cy;
+    level_center(L0, px, cx, cy);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+    const Sph sp = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+    float Z = 1e11f, q;
+    if (!L0.valid[px]) {
+      q = sp.dist + V.cfg.threshold - V.cfg.radius;
+    } else {
+      const size_t P = (size_t)V.P;
+      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+      const bool inside = cam.cdist < V.cfg.radius;
+      const float init_orig = inside ? 0.f : sp.init_raw;
+      const bool pad0 = V.tk_src[px] < 0;
+      const float s0 = V.tk_s[px];
+      const float za0 = V.tk_za[px];
+      const float m_row = V.pyramid ? (za0 - init_orig) : za0;
+      float z = m_row + (1.0f - ratio) * clampf(s0, -cd, cd);
+      if (V.cfg.grad_depth) {
+        for (int k = 0; k < V.cfg.buffer_size; ++k) {
+          const float sv = (V.tk_src[k * P + px] < 0) ? C->f_origin : V.tk_s[k * P + px];
+          const float sc = clampf(sv, -cd, cd);
+          z = z - sc * ratio;
+          z = z + sc * ratio;
+        }
+      }
+      Z = init_orig + z;
+      q = pad0 ? C->f_origin : s0;
+      bool v = (V.m[px] + V.init_now[px] < V.maxbound[px]) && (V.minabs[px] <= V.cfg.threshold);
+      if (!V.pyramid) v = v && (V.first_sdf[px] > V.cfg.threshold);
+      vout = v;
+    }
+    V.zdepth_s[px] = Z;
+    V.mask_s[px] = vout ? 1 : 0;
+    const float dp = vout ? Z * g.calib : 1e11f;
+    V.depth_pre[px] = dp;
+    if (zdepth) zdepth[px] = Z;
+    if (mask) mask[px] = vout ? 1 : 0;
+    if (min_sdf) min_sdf[px] = q;
+    if (depth && !V.cfg.use_depth2normal) depth[px] = dp;
+  }
+  // valid-pixel list (autograd normals) + count
+  const bool want_list = V.cfg.want_normal && !V.cfg.use_depth2normal;
+  if (want_list) wave_append(vout, px, V.nlist, &C->cnt_normal);
+  const unsigned long long ball = __ballot(vout);
+  if ((threadIdx.x & 63) == 0 && ball) atomicAdd(&C->cnt_valid, __popcll(ball));
+}
+
+__device__ __forceinline__ float bg_depth(const float* dp, int i) {
+  const float d = dp[i];
+  return ((d > 1e5f) || (d == 0.f)) ? 0.f : d;
+}
+
+// depth2normal (core/utils/render_utils.py:9-43) incl. its in-place zeroing of the background depth
+__global__ void __launch_bounds__(256) k_depth2normal(View V, float* depth, float* normal) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= V.P) return;
+  const int Ww = V.cfg.W, Hh = V.cfg.H;
+  const int y = i / Ww, x = i % Ww;
+  const float* dp = V.depth_pre;
+  const float d0 = bg_depth(dp, i);
+  if (depth) depth[i] = d0;
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  if (d0 != 0.f) {
+    const bool ix = (x >= 1 && x <= Ww - 2), iy = (y >= 1 && y <= Hh - 2);
+    const float l = ix ? bg_depth(dp, i - 1) : 0.f, r = ix ? bg_depth(dp, i + 1) : 0.f;
+    const float u = iy ? bg_depth(dp, i - Ww) : 0.f, d = iy ? bg_depth(dp, i + Ww) : 0.f;
+    const float dzdx = (r - l) * V.cfg.fx / 2.0f, dzdy = (d - u) * V.cfg.fy / 2.0f;
+    const float len = sqrtf(dzdx * dzdx + dzdy * dzdy + 1.0f);
+    n0 = dzdx / (len + 1e-12f); n1 = dzdy / (len + 1e-12f); n2 = -1.0f / (len + 1e-12f);
+  }
+  if (normal) { normal[i * 3] = n0; normal[i * 3 + 1] = n1; normal[i * 3 + 2] = n2; }
+}
+
+// ------------------------------------------------------------------------------------------ backward MLP kernel
+// Recomputes the decoder forward for a tile of 64 gradient-carrying samples, back-propagates coef * d f through it
+// (dX chain with transposed weight fragments), and emits per tile: sum_n delta0, sum_n delta4 (for the shared-latent
+// gradient, multiplied once by W_lat^T afterwards) and the camera-gradient partials; or, in POINTGRAD mode, the
+// per-point sdf and d f/d xyz (decode_sdf_gradient, core/utils/decoder_utils.py:76-92).
+enum { BWD_FULL = 0, BWD_POINTGRAD = 1 };
+
+struct BwdArgs {
+  View V;
+  const Sample* samples;     // FULL
+  const int32_t* count_ptr;  // device-side count (FULL / normal pass); null -> n
+  int64_t n;
+  const float* xyz;          // POINTGRAD from explicit points (distr_mlp_grad); else from V.nlist + zdepth
+  const float* zdepth;       // POINTGRAD from pixel list: depth along the level-0 ray
+  const int32_t* pix_list;
+  const float* c0c4;         // POINTGRAD explicit: latent constants; null -> V.C
+  float* partial;            // FULL: [tiles][PSTRIDE]
+  float* out_sdf;            // POINTGRAD: [n]
+  float* out_g;              // POINTGRAD: [n][3]
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_bwd(BwdArgs A, DecoderDev D) {
+  __shared__ Smem S;
+  const View& V = A.V;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int64_t count = A.count_ptr ? (int64_t)(*A.count_ptr) : A.n;
+  const int64_t base = (int64_t)tile * TILE;
+  if (base >= count) return;
+
+  Sample sm; sm.src = -1; sm.zb = 0.f; sm.coef = 0.f; sm.flags = 0;
+  bool valid = false;
+  int64_t r = 0;
+  if (tid < TILE) {
+    float p[3] = {0.f, 0.f, 0.f};
+    r = base + tid;
+    valid = r < count;
+    if (valid) {
+      if (MODE == BWD_POINTGRAD && A.xyz) {
+        p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
+        sm.coef = 1.0f;
+      } else {
+        if (MODE == BWD_POINTGRAD) { sm.src = A.pix_list[r]; sm.zb = A.zdepth[sm.src]; sm.coef = 1.0f; }
+        else sm = A.samples[r];
+        if (sm.src >= 0) {
+          const int lvl = sm.src >> 28, ray = sm.src & 0x0fffffff;
+          const CamRegs cam = load_cam(V.C);
+          float cx, cy;
+          level_center(V.lv[lvl], ray, cx, cy);
+          const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+          make_point(V.cfg.M, cam.c, g.d, sm.zb, p);
+        }
+      }
+    }
+    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+  }
+  __syncthreads();
+
+  uint32_t masks[8][4];
+  const float* c0 = A.c0c4 ? A.c0c4 : V.C->c0;
+  const float* c4 = A.c0c4 ? A.c0c4 + HID : V.C->c4;
+  const float pre = mlp_forward<true>(D, c0, c4, S, masks);
+  float y = 0.f;
+  if (tid < TILE) {
+    y = tanh_spec(pre);
+    S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
+  }
+  __syncthreads();
+  float* part = (MODE == BWD_FULL) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
+  mlp_backward(D, S, masks, part, part ? part + HID : nullptr);
+
+  if (tid >= TILE) return;
+  const float gp0 = S.aux[TILE + tid], gp1 = S.aux[2 * TILE + tid], gp2 = S.aux[3 * TILE + tid];
+  if (MODE == BWD_POINTGRAD) {
+    if (valid) {
+      A.out_sdf[r] = y;
+      A.out_g[r * 3] = gp0; A.out_g[r * 3 + 1] = gp1; A.out_g[r * 3 + 2] = gp2;
+    }
+    return;
+  }
+  // sample point -> camera: p = M^T (cam_pos + ray * zb), zb detached (renderer.py:202-223)
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  if (valid && sm.src >= 0 && (sm.flags & 1)) {
+    const int lvl = sm.src >> 28, ray = sm.src & 0x0fffffff;
+    const CamRegs cam = load_cam(V.C);
+    float cx, cy;
+    level_center(V.lv[lvl], ray, cx, cy);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+    const float* M = V.cfg.M;
+    float gq[3], gd[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gq[j] = M[j * 3] * gp0 + M[j * 3 + 1] * gp1 + M[j * 3 + 2] * gp2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { acc[9 + j] = gq[j]; gd[j] = sm.zb * gq[j]; }
+    const float e = g.rn + 1e-12f;
+    const float dot = gd[0] * g.r[0] + gd[1] * g.r[1] + gd[2] * g.r[2];
+    const float hh[3] = {g.hx, g.hy, g.hz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float gr = gd[i] / e - (g.rn > 0.f ? dot * g.r[i] / (g.rn * e * e) : 0.f);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j * 3 + i] = hh[j] * gr;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) part[2 * HID + i] = acc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ normals (autograd path)
+// render_normal (renderer.py:880-910) epilogue: n = normalize(3 * grad f) (torch-1.1 grad_outputs quirk,
+// decoder_utils.py:84), t = M n; render(): out = flipx(R t) (renderer.py:977-980)
+__global__ void __launch_bounds__(256) k_normal_finish(View V, const int32_t* count_ptr, const int32_t* pix_list,
+                                                       const float* n_sdf, const float* n_g, float* normal_hw3,
+                                                       float* normal_3xP, float* nrm_t) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= *count_ptr) return;
+  const int px = pix_list[r];
+  const bool inclamp = fabsf(n_sdf[r]) <= V.cfg.clamp_dist;
+  float g[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) g[j] = inclamp ? 3.0f * n_g[r * 3 + j] : 0.f;
+  if (V.cfg.normalize_normal) {
+    const float len = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[j] = g[j] / (len + 1e-12f);
+  }
+  const float* M = V.cfg.M;
+  float t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = M[i * 3] * g[0] + M[i * 3 + 1] * g[1] + M[i * 3 + 2] * g[2];
+  if (nrm_t) { nrm_t[px * 3] = t[0]; nrm_t[px * 3 + 1] = t[1]; nrm_t[px * 3 + 2] = t[2]; }
+  if (normal_3xP) {
+    const size_t P = (size_t)V.P;
+    normal_3xP[px] = t[0]; normal_3xP[P + px] = t[1]; normal_3xP[2 * P + px] = t[2];
+  }
+  if (normal_hw3) {
+    const float* R = V.C->R;
+    float o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = R[i * 3] * t[0] + R[i * 3 + 1] * t[1] + R[i * 3 + 2] * t[2];
+    normal_hw3[px * 3] = -o[0]; normal_hw3[px * 3 + 1] = o[1]; normal_hw3[px * 3 + 2] = o[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mask_list(int P, const uint8_t* mask, int32_t* list, int32_t* counter) {
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  wave_append(px < P && mask[px] != 0, px, list, counter);
+}
+
+__global__ void k_zero_i32(int32_t* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------ backward: image side
+__device__ __forceinline__ void d2n_gv(const View& V, const float* g_normal, int i, float& gv0, float& gv1) {
+  // gradient wrt (dzdx, dzdy) of pixel i of depth2normal's normalised vector
+  const int Ww = V.cfg.W, Hh = V.cfg.H;
+  const int y = i / Ww, x = i % Ww;
+  const float* dp = V.depth_pre;
+  const bool ix = (x >= 1 && x <= Ww - 2), iy = (y >= 1 && y <= Hh - 2);
+  const float l = ix ? bg_depth(dp, i - 1) : 0.f, r = ix ? bg_depth(dp, i + 1) : 0.f;
+  const float u = iy ? bg_depth(dp, i - Ww) : 0.f, d = iy ? bg_depth(dp, i + Ww) : 0.f;
+  const float v0 = (r - l) * V.cfg.fx / 2.0f, v1 = (d - u) * V.cfg.fy / 2.0f;
+  const float len = sqrtf(v0 * v0 + v1 * v1 + 1.0f), e = len + 1e-12f;
+  const float g0 = g_normal[i * 3], g1 = g_normal[i * 3 + 1], g2 = g_normal[i * 3 + 2];
+  const float dot = g0 * v0 + g1 * v1 - g2;
+  gv0 = g0 / e - dot * v0 / (len * e * e);
+  gv1 = g1 / e - dot * v1 / (len * e * e);
+}
+
+__device__ __forceinline__ void ray_backward_acc(const RayGeo& g, const float* gd, float* acc /*gR[9]*/) {
+  const float e = g.rn + 1e-12f;
+  const float dot = gd[0] * g.r[0] + gd[1] * g.r[1] + gd[2] * g.r[2];
+  const float hh[3] = {g.hx, g.hy, g.hz};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float gr = gd[i] / e - (g.rn > 0.f ? dot * g.r[i] / (g.rn * e * e) : 0.f);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j * 3 + i] += hh[j] * gr;
+  }
+}
+
+// Turns the upstream image gradients into (i) per-sample coefficients on the selected rows (ii) camera-gradient
+// terms that do not pass through the decoder (rays missing the sphere, renderer.py:863; the explicit R*n product,
+// renderer.py:978). SURVEY.md Appendix A.6 steps 1-3, 5.
+__global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth, const float* g_min_sdf,
+                                                  const float* g_depth, const float* g_normal, Sample* samples) {
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  Consts* C = V.C;
+  const LevelView& L0 = V.lv[0];
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+  float pad_acc = 0.f;
+  const int bs = V.cfg.buffer_size;
+  const bool act = px < V.P;
+  const bool in = act && L0.valid[px];
+  float gz = 0.f, gq = 0.f;
+  if (act) {
+    gq = g_min_sdf ? g_min_sdf[px] : 0.f;
+    const CamRegs cam = load_cam(C);
+    float cx, cy;
+    level_center(L0, px, cx, cy);
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+    if (!in) {
+      if (gq != 0.f) {
+        const Sph sp = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+        if (sp.dist > 0.f) {
+          float gv[3], gd[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) gv[j] = gq * sp.v[j] / sp.dist;
+          const float gvd = gv[0] * g.d[0] + gv[1] * g.d[1] + gv[2] * g.d[2];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { acc[9 + j] += gv[j] - g.d[j] * gvd; gd[j] = -cam.c[j] * gvd - sp.ptq * gv[j]; }
+          ray_backward_acc(g, gd, acc);
+        }
+      }
+    } else {
+      const bool m = V.mask_s[px] != 0;
+      if (V.cfg.grad_depth) {
+        if (g_zdepth) gz += g_zdepth[px];
+        if (m) {
+          float gd_eff = g_depth ? g_depth[px] : 0.f;
+          if (V.cfg.want_normal && V.cfg.use_depth2normal) {
+            if (bg_depth(V.depth_pre, px) == 0.f) {
+              gd_eff = 0.f;
+            } else if (g_normal) {
+              const int Ww = V.cfg.W, Hh = V.cfg.H;
+              const int y = px / Ww, x = px % Ww;
+              float a0, a1, add = 0.f;
+              if (x - 1 >= 1 && x - 1 <= Ww - 2 && bg_depth(V.depth_pre, px - 1) != 0.f) { d2n_gv(V, g_normal, px - 1, a0, a1); add += a0 * V.cfg.fx / 2.0f; }
+              if (x + 1 >= 1 && x + 1 <= Ww - 2 && bg_depth(V.depth_pre, px + 1) != 0.f) { d2n_gv(V, g_normal, px + 1, a0, a1); add -= a0 * V.cfg.fx / 2.0f; }
+              if (y - 1 >= 1 && y - 1 <= Hh - 2 && bg_depth(V.depth_pre, px - Ww) != 0.f) { d2n_gv(V, g_normal, px - Ww, a0, a1); add += a1 * V.cfg.fy / 2.0f; }
+              if (y + 1 >= 1 && y + 1 <= Hh - 2 && bg_depth(V.depth_pre, px + Ww) != 0.f) { d2n_gv(V, g_normal, px + Ww, a0, a1); add -= a1 * V.cfg.fy / 2.0f; }
+              gd_eff += add;
+            }
+          }
+          gz += gd_eff * g.calib;
+        }
+      }
+      if (m && V.cfg.want_normal && !V.cfg.use_depth2normal && g_normal) {
+        const float go[3] = {-g_normal[px * 3], g_normal[px * 3 + 1], g_normal[px * 3 + 2]};
+        const float* t = V.nrm_t + (size_t)px * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) acc[a * 3 + b] += go[a] * t[b];
+      }
+    }
+  }
+  const size_t P = (size_t)V.P;
+  for (int k = 0; k < bs; ++k) {
+    Sample s; s.src = -1; s.zb = 0.f; s.coef = 0.f; s.flags = 0;
+    bool emit = false;
+    if (in) {
+      s.src = V.tk_src[k * P + px];
+      const float sv = s.src < 0 ? C->f_origin : V.tk_s[k * P + px];
+      float c = 0.f;
+      if (V.cfg.grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
+      if (k == 0 && V.cfg.grad_mask) c += gq;
+      if (c != 0.f) {
+        if (s.src < 0) {
+          pad_acc += c;
+        } else {
+          s.zb = V.tk_zb[k * P + px];
+          s.coef = c;
+          const bool fine_row = (s.src >> 28) == 0;
+          s.flags = (fine_row && !V.cfg.grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
+          emit = true;
+        }
+      }
+    }
+    const unsigned long long ball = __ballot(emit);
+    if (ball) {
+      const int lane = threadIdx.x & 63;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&C->cnt_samples, __popcll(ball));
+      base = __shfl(base, 0);
+      if (emit) samples[base + __popcll(ball & ((1ull << lane) - 1ull))] = s;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float v = wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&C->cam_acc[i], v);
+  }
+  const float pv = wave_sum(pad_acc);
+  if ((threadIdx.x & 63) == 0 && pv != 0.f) atomicAdd(&C->pad_coef, pv);
+}
+
+// all padded rows sample the origin (points = 0, renderer.py:539): one combined sample, no camera dependence
+__global__ void k_bwd_pad(View V, Sample* samples) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && V.C->pad_coef != 0.f) {
+    Sample s; s.src = -1; s.zb = 0.f; s.coef = V.C->pad_coef; s.flags = 0;
+    samples[V.C->cnt_samples] = s;
+    V.C->cnt_samples = V.C->cnt_samples + 1;
+  }
+}
+
+// column sums of the tile partials (deterministic order), chunked over tiles
+__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, int chunk) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int ntiles = (V.C->cnt_samples + TILE - 1) / TILE;
+  const int t0 = blockIdx.y * chunk, t1 = min(ntiles, t0 + chunk);
+  if (col >= 2 * HID + 12 || t0 >= t1) return;
+  float s = 0.f;
+  for (int t = t0; t < t1; ++t) s += partial[(size_t)t * PSTRIDE + col];
+  atomicAdd(&V.C->red[col], s);
+}
+
+// g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)
+__global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, float* g_latent, float* g_R, float* g_T) {
+  const int k = threadIdx.x;
+  Consts* C = V.C;
+  const float* sd0 = C->red;
+  const float* sd4 = C->red + HID;
+  float a = 0.f;
+  for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * sd0[o] + D.W4lat[o * LAT + k] * sd4[o];
+  if (g_latent) g_latent[k] = a;
+  if (k < 12) {
+    float gc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gc[i] = C->red[2 * HID + 9 + i] + C->cam_acc[9 + i];
+    if (k < 9) {
+      const int j = k / 3, i = k % 3;
+      if (g_R) g_R[k] = C->red[2 * HID + k] + C->cam_acc[k] - C->T[j] * gc[i];
+    } else {
+      const int j = k - 9;
+      if (g_T) g_T[j] = -(C->R[j * 3] * gc[0] + C->R[j * 3 + 1] * gc[1] + C->R[j * 3 + 2] * gc[2]);
+    }
+  }
+}
+
+}  // namespace distr

@@ -1,0 +1,406 @@
+// distr_mlp.hpp -- the fused DeepSDF 8x512 decoder tile for gfx950 (CDNA4), forward and backward.
+//
+// Replaces Decoder.inference (core/graph/deep_sdf_decoder.py:80-111) + decode_sdf's latent expand/cat
+// (core/utils/decoder_utils.py:53-74) + the autograd replay through them.
+//
+// One workgroup = 4 wavefronts (256 threads, one wave per SIMD) evaluates TILE=64 points through all nine
+// layers without touching HBM in between:
+//   * activations live in LDS, feature-major X[feature][ray] (512 x 64 f32 = 128 KiB), updated in place;
+//   * each dense layer is computed transposed, Y^T = W * X^T, with v_mfma_f32_32x32x2_f32: the weight
+//     matrix is the MFMA "A" operand (one f32 per lane, lane (i,h) holds W[o=i][k=h]) and the activations
+//     are the "B" operand (lane (j,h) holds X[k=h][ray=j]) read from LDS with conflict-free ds_read_b32;
+//   * wave w owns output rows [w*O/4, (w+1)*O/4) for all 64 rays: NOB x 2 accumulator tiles of 32x32
+//     (128 accumulator registers for O=512), so every weight fragment is used for 2 MFMAs and every
+//     activation fragment for NOB MFMAs; weights are streamed from L2 exactly once per workgroup per
+//     layer as host-pre-packed, fully coalesced float4 fragments (1 KiB per wave-load), prefetched one
+//     8-feature group (32 MFMAs = 2048 cycles) ahead;
+//   * the k-loop visits features in natural order, and an f32 MFMA is bit-for-bit a k-ordered fmaf chain,
+//     so the result equals the oracle's (and a scalar CPU) fmaf chain started from the bias;
+//   * the latent columns of lin0 / lin4 are folded into per-render constant vectors c0 / c4 (k_prep).
+// Backward re-uses the same dense loop with transposed weight fragments; ReLU masks of the recomputed
+// forward are kept as bitmasks in registers (32 VGPRs) because forward outputs and backward deltas of a
+// layer sit in the same lane/register positions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace distr {
+
+constexpr int TILE = 64;
+constexpr int HID = 512;
+constexpr int LAT = 256;
+constexpr int NTHREADS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DecoderDev {
+  const float* Wf[8];   // forward A-fragments of lin0..lin7 (lin0: K padded to 8; lin3: O padded to 256; lin4: K=256)
+  const float* Wb[8];   // backward (transposed) A-fragments, index = layer whose weights are used (1..7)
+  const float* bias[8]; // biases of lin1,2,3(padded),5,6,7 ([0],[4]: unused -- c0/c4 are per render)
+  const float* W0lat_t; // [256][512]  lin0 latent columns, k-major
+  const float* W4lat_t; // [256][512]
+  const float* W0lat;   // [512][256]
+  const float* W4lat;   // [512][256]
+  const float* b0;      // [512]
+  const float* b4;      // [512]
+  const float* w8;      // [512]
+  const float* W0x;     // [3][512]   lin0 xyz columns
+  float b8;
+};
+
+struct Smem {
+  float X[HID * TILE];   // activations / deltas [feature][ray]
+  float xyz[4 * TILE];   // rows 0..2: sample points of the tile
+  float part[12 * TILE]; // lin8 partial chains [4][64]; backward: xyz-gradient partials [3][4][64]
+  float aux[4 * TILE];   // backward: row 0 = d8, rows 1..3 = d/dxyz through lin4's xyz columns
+};
+
+// ---------------------------------------------------------------------------------------- scalar math
+// tanh in explicit IEEE operations so that host (oracle) and device agree bit for bit.
+__device__ __forceinline__ float exp_spec(float x) {
+  const float LOG2E = 1.44269504088896341f;
+  const float C1 = 0.693359375f;
+  const float C2 = -2.12194440e-4f;
+  float n = floorf(__builtin_fmaf(LOG2E, x, 0.5f));
+  float r = __builtin_fmaf(n, -C1, x);
+  r = __builtin_fmaf(n, -C2, r);
+  float z = r * r;
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  p = __builtin_fmaf(p, z, r);
+  p = p + 1.0f;
+  int32_t bits = ((int32_t)n + 127) << 23;
+  return p * __int_as_float(bits);
+}
+
+__device__ __forceinline__ float tanh_spec(float x) {
+  float a = fabsf(x);
+  if (a < 0.625f) {
+    float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    p = p * z;
+    return __builtin_fmaf(p, x, x);
+  }
+  if (a > 10.0f) return x > 0 ? 1.0f : -1.0f;
+  float e = exp_spec(a + a);
+  float r = 1.0f - 2.0f / (e + 1.0f);
+  return x > 0 ? r : -r;
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------- dense layer
+// D rows of one 32x32 accumulator register r on lane (j,h): row = (r&3) + 8*(r>>2) + 4*h, col = j.
+template <int NOB>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[NOB][2], const float* __restrict__ init, int row0, int h) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(init + row0 + 32 * ob + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[ob][0][4 * q + j] = b[j];
+        acc[ob][1][4 * q + j] = b[j];
+      }
+    }
+  }
+}
+
+template <int NOB>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NOB][2]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[ob][0][r] = 0.f; acc[ob][1][r] = 0.f; }
+}
+
+// acc[ob][rb] += W[rows of this wave][0..K) * X[0..K)[rays]   (K multiple of 8, natural k order)
+// Wp: packed fragments, float4 index ((g*4 + wave)*NOB + ob)*64 + lane  holds
+//     { W[o][8g+2s+h] : s=0..3 },  o = wave*32*NOB + 32*ob + (lane&31), h = lane>>5.
+template <int K, int NOB>
+__device__ __forceinline__ void dense(const float* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][2], int wave,
+                                      int lane) {
+  constexpr int NG = K / 8;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)wave * NOB * 64 + lane;
+  const float* xb = X + (lane >> 5) * TILE + (lane & 31);
+  f32x4 a[NOB];
+  float b[8];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) a[ob] = wp[ob * 64];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { b[2 * s] = xb[2 * s * TILE]; b[2 * s + 1] = xb[2 * s * TILE + 32]; }
+#pragma unroll 2
+  for (int g = 0; g < NG; ++g) {
+    // register double buffer: fetch group g+1 (weights from L2, activations from LDS) before the 32 MFMAs of
+    // group g; the scheduling barrier keeps the loads at the top so they get a full group (2048 cycles) of cover
+    f32x4 an[NOB];
+    float bn[8];
+    const int gn = (g + 1 < NG) ? g + 1 : g;
+    const f32x4* wn = wp + (size_t)gn * (4 * NOB * 64);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) an[ob] = wn[ob * 64];
+    const float* xg = xb + (size_t)gn * 8 * TILE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { bn[2 * s] = xg[2 * s * TILE]; bn[2 * s + 1] = xg[2 * s * TILE + 32]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[2 * s], acc[ob][0], 0, 0, 0);
+        acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[2 * s + 1], acc[ob][1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) a[ob] = an[ob];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = bn[i];
+  }
+}
+
+// Write a layer's accumulators back to X (in place). RELU: max(x,0); mask out: bit (rb*16+r) of mask[ob] = x>0.
+// GATE: multiply by the given mask bits instead (backward: delta = mask ? acc : 0).
+// (sign/zero tests are done with integer bit arithmetic: a float compare per element would make hipcc keep 128
+// wave-wide lane masks in SGPR pairs and spill them)
+__device__ __forceinline__ uint32_t pos_bit(float v) {  // 1 if v > 0 (v finite), else 0
+  const uint32_t u = __float_as_uint(v);
+  return ((~u) >> 31) & ((u | (0u - u)) >> 31);
+}
+__device__ __forceinline__ float gate(float v, uint32_t bit) {  // bit ? v : +0
+  return __uint_as_float(__float_as_uint(v) & (0u - bit));
+}
+
+template <int NOB, bool RELU, bool GATE, bool KEEP = true>
+__device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][2], int row0, int lane, uint32_t (&mask)[4]) {
+  const int h = lane >> 5, j = lane & 31;
+  __builtin_amdgcn_sched_barrier(0);  // keep the mask packing here: do not let raw accumulators stay live (spill)
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    uint32_t m = GATE ? mask[ob] : 0u;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[ob][rb][r];
+        if (GATE) {
+          v = gate(v, (m >> (rb * 16 + r)) & 1u);
+        } else if (KEEP) {
+          const uint32_t pb = pos_bit(v);
+          if (RELU) v = gate(v, pb);
+          m |= pb << (rb * 16 + r);
+        } else if (RELU) {
+          v = __int_as_float(max(__float_as_int(v), 0));  // relu on the bit pattern (v_max_i32)
+        }
+        X[row * TILE + 32 * rb + j] = v;
+      }
+    }
+    if (!GATE && KEEP) {
+      // opaque to the optimiser: otherwise LLVM sees through the bit packing ((m>>n)&1 == pos_bit(acc_n)) and keeps all
+      // 128 x 8 forward accumulators alive (in scratch) until the backward pass instead of the 4 mask registers
+      asm volatile("" : "+v"(m));
+      mask[ob] = m;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------------------- forward tile
+// Preconditions: S.xyz rows 0..2 hold the 64 points (x row, y row, z row), visible to all threads (barrier done).
+// Returns (every thread, for ray = tid & 63) the pre-tanh output. masks[l] = ReLU bitmasks of layer l.
+// DEBUG_STOP: (test builds only) return right after layer `stop`'s activations are in X.
+template <bool KEEP, bool DEBUG_STOP = false>
+__device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* __restrict__ c0,
+                                             const float* __restrict__ c4, Smem& S, uint32_t (&masks)[8][4],
+                                             int stop = 8) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int h = lane >> 5;
+  float* X = S.X;
+  // layer-0 input rows: xyz + zero padding to K=8
+  X[tid] = (tid < 3 * TILE) ? S.xyz[tid] : 0.f;
+  X[tid + 256] = 0.f;
+  __syncthreads();
+  {
+    f32x16 acc[4][2];
+    acc_init<4>(acc, c0, wave * 128, h);
+    dense<8, 4>(D.Wf[0], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[0]);
+    __syncthreads();
+  }
+  if (DEBUG_STOP && stop == 0) return 0.f;
+#pragma unroll
+  for (int l = 1; l <= 2; ++l) {
+    f32x16 acc[4][2];
+    acc_init<4>(acc, D.bias[l], wave * 128, h);
+    dense<512, 4>(D.Wf[l], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+    __syncthreads();
+    if (DEBUG_STOP && stop == l) return 0.f;
+  }
+  {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
+    f32x16 acc[2][2];
+    acc_init<2>(acc, D.bias[3], wave * 64, h);
+    dense<512, 2>(D.Wf[3], X, acc, wave, lane);
+    __syncthreads();
+    masks[3][2] = 0; masks[3][3] = 0;
+    writeback<2, true, false, KEEP>(X, acc, wave * 64, lane, masks[3]);
+    __syncthreads();
+    if (tid < 3 * TILE) X[(253 + (tid >> 6)) * TILE + (tid & 63)] = S.xyz[tid];
+    __syncthreads();
+  }
+  if (DEBUG_STOP && stop == 3) return 0.f;
+  {  // lin4: [x3(253) | xyz(3)] -> 512, latent part folded into c4
+    f32x16 acc[4][2];
+    acc_init<4>(acc, c4, wave * 128, h);
+    dense<256, 4>(D.Wf[4], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
+    __syncthreads();
+  }
+  if (DEBUG_STOP && stop == 4) return 0.f;
+#pragma unroll
+  for (int l = 5; l <= 7; ++l) {
+    f32x16 acc[4][2];
+    acc_init<4>(acc, D.bias[l], wave * 128, h);
+    dense<512, 4>(D.Wf[l], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+    __syncthreads();
+    if (DEBUG_STOP && stop == l) return 0.f;
+  }
+  // lin8: four 128-long chains per ray (one per wave), combined in fixed order
+  {
+    float p = 0.f;
+    const float* w8 = D.w8 + wave * 128;
+    const float* xr = X + (size_t)wave * 128 * TILE + lane;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * TILE], p);
+    S.part[wave * TILE + lane] = p;
+  }
+  __syncthreads();
+  const float pre = ((S.part[lane] + S.part[TILE + lane]) + (S.part[2 * TILE + lane] + S.part[3 * TILE + lane])) + D.b8;
+  return pre;
+}
+
+// ---------------------------------------------------------------------------------------- backward tile
+// Preconditions: mlp_forward just ran on this tile (X = h7, masks filled); S.aux row 0 = d8[ray] = coef*(1-y^2),
+// visible to all threads. On return: S.aux rows 1..3 (wave 0 view after the final barrier) hold
+// d(coef*f)/d xyz per ray; sd0/sd4 (if non-null) receive the row sums over the 64 rays of delta0 / delta4.
+__device__ __forceinline__ void row_sums(const float* X, float* __restrict__ dst, int tid) {
+  const int lane = tid & 63;
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = tid + rr * 256;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < TILE; ++i) s += X[row * TILE + ((i + lane) & 63)];
+    dst[row] = s;
+  }
+}
+
+__device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem& S, uint32_t (&masks)[8][4],
+                                             float* __restrict__ sd0, float* __restrict__ sd4) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  float* X = S.X;
+  // delta7[k][ray] = relu'(h7) * w8[k] * d8[ray]
+  {
+    const float d8a = S.aux[j], d8b = S.aux[32 + j];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const uint32_t m = masks[7][ob];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 128 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float w = D.w8[row];
+        X[row * TILE + j] = gate(w * d8a, (m >> r) & 1u);
+        X[row * TILE + 32 + j] = gate(w * d8b, (m >> (16 + r)) & 1u);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 7; l >= 5; --l) {  // delta_l (512) -> delta_{l-1} (512)
+    f32x16 acc[4][2];
+    acc_zero<4>(acc);
+    dense<512, 4>(D.Wb[l], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd4) row_sums(X, sd4, tid);  // X = delta4
+  {  // lin4^T: delta4 (512) -> [delta3 (253) | d xyz (3)]
+    f32x16 acc[2][2];
+    acc_zero<2>(acc);
+    dense<512, 2>(D.Wb[4], X, acc, wave, lane);
+    __syncthreads();
+    writeback<2, false, true>(X, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
+    if (wave == 3 && h == 1) {
+#pragma unroll
+      for (int r = 13; r < 16; ++r) {
+        S.aux[(1 + r - 13) * TILE + j] = acc[1][0][r];
+        S.aux[(1 + r - 13) * TILE + 32 + j] = acc[1][1][r];
+      }
+    }
+    __syncthreads();
+  }
+  {  // lin3^T: delta3 (256 rows, 253 real) -> delta2 (512)
+    f32x16 acc[4][2];
+    acc_zero<4>(acc);
+    dense<256, 4>(D.Wb[3], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, false, true>(X, acc, wave * 128, lane, masks[2]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 2; l >= 1; --l) {
+    f32x16 acc[4][2];
+    acc_zero<4>(acc);
+    dense<512, 4>(D.Wb[l], X, acc, wave, lane);
+    __syncthreads();
+    writeback<4, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd0) row_sums(X, sd0, tid);  // X = delta0
+  // d xyz through lin0's xyz columns: 3 x four 128-long chains per ray
+  {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    const float* wx = D.W0x + wave * 128;
+    const float* xr = X + (size_t)wave * 128 * TILE + lane;
+#pragma unroll 4
+    for (int k = 0; k < 128; ++k) {
+      const float d = xr[k * TILE];
+      p0 = __builtin_fmaf(wx[k], d, p0);
+      p1 = __builtin_fmaf(wx[HID + k], d, p1);
+      p2 = __builtin_fmaf(wx[2 * HID + k], d, p2);
+    }
+    S.part[(0 * 4 + wave) * TILE + lane] = p0;
+    S.part[(1 * 4 + wave) * TILE + lane] = p1;
+    S.part[(2 * 4 + wave) * TILE + lane] = p2;
+  }
+  __syncthreads();
+  if (tid < 3 * TILE) {
+    const int c = tid >> 6, r = tid & 63;
+    const float* p = S.part + c * 4 * TILE + r;
+    S.aux[(1 + c) * TILE + r] = S.aux[(1 + c) * TILE + r] + ((p[0] + p[TILE]) + (p[2 * TILE] + p[3 * TILE]));
+  }
+  __syncthreads();
+}
+
+}  // namespace distr

@@ -1,0 +1,199 @@
+"""ctypes binding of libdistr.so (C ABI: include/distr.h) + per-device context cache.
+
+PyTorch is used only for device memory (tensors own every buffer handed to the library) and for
+the current HIP stream. There is NO CPU / PyTorch fallback: if the shared library is missing, or no
+MI355X is visible, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, '..', 'csrc')
+LIB_PATH = os.path.abspath(os.path.join(CSRC, 'libdistr.so'))
+
+MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
+EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
+           'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
+           'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
+           'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer']
+
+
+class DistrError(RuntimeError):
+    pass
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [('latent_size', C.c_int32), ('hidden', C.c_int32), ('num_linear', C.c_int32), ('latent_in', C.c_int32)]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [
+        ('H', C.c_int32), ('W', C.c_int32),
+        ('K_inv', C.c_float * 9),
+        ('fx', C.c_float), ('fy', C.c_float),
+        ('M', C.c_float * 9),
+        ('march_step', C.c_int32), ('buffer_size', C.c_int32),
+        ('ratio', C.c_float), ('threshold', C.c_float), ('radius', C.c_float), ('clamp_dist', C.c_float),
+        ('marcher', C.c_int32),
+        ('coarse_steps', C.c_int32 * 2),
+        ('use_depth2normal', C.c_int32), ('normalize_normal', C.c_int32), ('want_normal', C.c_int32),
+        ('grad_depth', C.c_int32), ('grad_mask', C.c_int32), ('grad_camera', C.c_int32),
+    ]
+
+    def clone(self):
+        c = RenderCfg()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(RenderCfg))
+        return c
+
+
+class RenderStats(C.Structure):
+    _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
+                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64)]
+
+
+def build_library(force=False, verbose=False):
+    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
+    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp')]
+    srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
+           '-o', LIB_PATH, os.path.join(CSRC, 'distr_api.hip')]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib():
+    """Loads libdistr.so (must have been built: __graft_entry__.build() / distr.binding.build_library())."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DistrError('libdistr.so not found at %s -- build it with `python __graft_entry__.py build` '
+                                 '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+            L = C.CDLL(LIB_PATH)
+            vp, fp, u8p = C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
+            L.distr_version.restype = C.c_char_p
+            L.distr_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+            L.distr_destroy.argtypes = [vp]
+            L.distr_destroy.restype = None
+            L.distr_last_error.argtypes = [vp]
+            L.distr_last_error.restype = C.c_char_p
+            L.distr_set_decoder.argtypes = [vp, C.POINTER(DecoderDesc), C.POINTER(C.c_float), C.c_size_t]
+            L.distr_workspace_bytes.argtypes = [vp, C.POINTER(RenderCfg), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+            L.distr_render_forward.argtypes = [vp, C.POINTER(RenderCfg), fp, fp, fp, fp, u8p, fp, fp, fp, vp, C.c_size_t, vp]
+            L.distr_render_backward.argtypes = [vp, C.POINTER(RenderCfg), vp, C.c_size_t, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
+            L.distr_render_normal.argtypes = [vp, C.POINTER(RenderCfg), fp, fp, fp, fp, u8p, fp, vp, C.c_size_t, vp]
+            L.distr_mlp_workspace_bytes.argtypes = [C.c_int64]
+            L.distr_mlp_workspace_bytes.restype = C.c_size_t
+            L.distr_mlp_eval.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
+            L.distr_mlp_grad.argtypes = [vp, fp, fp, C.c_int64, fp, fp, vp, C.c_size_t, vp]
+            L.distr_debug_mlp_layer.argtypes = [vp, fp, fp, C.c_int64, C.c_int, fp, vp, C.c_size_t, vp]
+            L.distr_get_render_stats.argtypes = [vp, C.POINTER(RenderCfg), vp, C.POINTER(RenderStats), vp]
+            L.distr_profile_enable.argtypes = [vp, C.c_int]
+            L.distr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), vp]
+            _lib = L
+    return _lib
+
+
+def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
+             marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
+             use_depth2normal=False, normalize_normal=True, want_normal=True,
+             grad_depth=True, grad_mask=True, grad_camera=True):
+    """Host-side part of SDFRenderer.__init__ (core/sdfrenderer/renderer.py:13-59) as a C struct."""
+    cfg = RenderCfg()
+    cfg.H, cfg.W = int(img_hw[0]), int(img_hw[1])
+    K = np.asarray(intrinsic, dtype=np.float64)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    cfg.K_inv = (C.c_float * 9)(*Kinv.reshape(-1))
+    cfg.fx, cfg.fy = float(np.float32(K[0, 0])), float(np.float32(K[1, 1]))
+    if transform_matrix is None:
+        transform_matrix = np.array([[1., 0., 0.], [0., 0., -1.], [0., 1., 0.]])
+    Mm = np.asarray(transform_matrix, dtype=np.float32)
+    if Mm.shape != (3, 3):
+        raise NotImplementedError('only 3x3 transform matrices are supported (the reference\'s 3x4 sim3 inverse path '
+                                  'hits an un-imported pdb.set_trace(), renderer.py:116)')
+    if not use_transform:
+        Mm = np.eye(3, dtype=np.float32)
+    cfg.M = (C.c_float * 9)(*Mm.reshape(-1))
+    cfg.march_step, cfg.buffer_size = int(march_step), int(buffer_size)
+    cfg.ratio, cfg.threshold, cfg.radius, cfg.clamp_dist = float(ratio), float(threshold), float(radius), float(clamp_dist)
+    if marcher not in MARCHERS:
+        raise ValueError('Error! Invalid type of ray marching: {}.'.format(marcher))
+    cfg.marcher = MARCHERS[marcher]
+    cfg.coarse_steps = (C.c_int32 * 2)(int(coarse_steps[0]), int(coarse_steps[1]))
+    cfg.use_depth2normal, cfg.normalize_normal, cfg.want_normal = int(use_depth2normal), int(normalize_normal), int(want_normal)
+    cfg.grad_depth, cfg.grad_mask, cfg.grad_camera = int(grad_depth), int(grad_mask), int(grad_camera)
+    return cfg
+
+
+class Context(object):
+    """One distr_ctx (device-bound handle holding the packed decoder)."""
+
+    def __init__(self, device_index=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise DistrError('no HIP device visible: the MI355X kernels cannot run (no CPU fallback exists)')
+        self.device_index = int(device_index)
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.distr_create(C.byref(h), self.device_index)
+        self.h = h
+        if rc != 0:
+            msg = self.L.distr_last_error(h).decode() if h else 'distr_create failed'
+            raise DistrError(msg)
+        self._decoder_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.L.distr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise DistrError('libdistr error %d: %s' % (rc, self.L.distr_last_error(self.h).decode()))
+
+    def set_decoder(self, flat_weights):
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        desc = DecoderDesc(256, 512, 9, 4)
+        self.check(self.L.distr_set_decoder(self.h, C.byref(desc), w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
+
+    def workspace_bytes(self, cfg):
+        f, b = C.c_size_t(), C.c_size_t()
+        self.check(self.L.distr_workspace_bytes(self.h, C.byref(cfg), C.byref(f), C.byref(b)))
+        return f.value, b.value
+
+    def stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+
+    def profile_enable(self, on=True):
+        self.check(self.L.distr_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms = C.c_int64(), C.c_double()
+        self.check(self.L.distr_profile_read(self.h, C.byref(n), C.byref(ms), self.stream()))
+        return n.value, ms.value
+
+    def render_stats(self, cfg, ws):
+        st = RenderStats()
+        self.check(self.L.distr_get_render_stats(self.h, C.byref(cfg), C.c_void_p(ws.data_ptr()), C.byref(st), self.stream()))
+        return {k: getattr(st, k) for k, _ in RenderStats._fields_}
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

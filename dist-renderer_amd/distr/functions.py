@@ -1,0 +1,171 @@
+"""torch.autograd glue around the C ABI: forward -> distr_render_forward, backward -> distr_render_backward.
+
+Replaces the autograd tape the reference records through ~50 decode_sdf calls per render
+(core/sdfrenderer/renderer.py:382-420, 836-878): the forward keeps O(buffer_size) selected rows per ray
+in the workspace tensor, the backward kernel recomputes the decoder at exactly those points.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import binding, decoder_pack
+
+
+class DecoderEngine(object):
+    """Packed decoder on one device (distr_ctx). One per (decoder module, device)."""
+
+    def __init__(self, decoder, device_index):
+        self.ctx = binding.Context(device_index)
+        self.device = torch.device('cuda', device_index)
+        self.refresh(decoder)
+
+    def refresh(self, decoder):
+        """(Re)uploads the weights; call after changing decoder parameters (they are frozen in every reference driver:
+        run_single_shape.py:88 optimises the latent only)."""
+        self.ctx.set_decoder(decoder_pack.pack_module(decoder))
+
+
+_engines = weakref.WeakKeyDictionary()
+
+
+def get_engine(decoder, device_index):
+    per_dec = _engines.setdefault(decoder, {})
+    if device_index not in per_dec:
+        per_dec[device_index] = DecoderEngine(decoder, device_index)
+    return per_dec[device_index]
+
+
+def engine_from_weights(Ws, bs, device_index=0):
+    """Engine straight from numpy weights (tests / bench; no nn.Module needed)."""
+    eng = DecoderEngine.__new__(DecoderEngine)
+    eng.ctx = binding.Context(device_index)
+    eng.device = torch.device('cuda', device_index)
+    eng.ctx.set_decoder(decoder_pack.flatten(Ws, bs))
+    return eng
+
+
+def _f32c(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class RenderFunction(torch.autograd.Function):
+    """(latent, R, T) -> (zdepth[P], mask[P] uint8, min_sdf[P], depth[H,W], normal[H,W,3])"""
+
+    @staticmethod
+    def forward(ctx, latent, R, T, engine, cfg):
+        dev = engine.device
+        H, W = cfg.H, cfg.W
+        P = H * W
+        lat, Rc, Tc = _f32c(latent, dev).reshape(-1), _f32c(R, dev).reshape(-1), _f32c(T, dev).reshape(-1)
+        if lat.numel() != 256 or Rc.numel() != 9 or Tc.numel() != 3:
+            raise ValueError('expected latent (1,256), R (3,3), T (3)')
+        fwd_bytes, bwd_bytes = engine.ctx.workspace_bytes(cfg)
+        ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+        zdepth = torch.empty(P, dtype=torch.float32, device=dev)
+        mask = torch.empty(P, dtype=torch.uint8, device=dev)
+        min_sdf = torch.empty(P, dtype=torch.float32, device=dev)
+        if cfg.want_normal:
+            depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+            normal = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        else:
+            depth = torch.empty(0, dtype=torch.float32, device=dev)
+            normal = torch.empty(0, dtype=torch.float32, device=dev)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_render_forward(
+            engine.ctx.h, C.byref(cfg), p(lat), p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
+            p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None,
+            p(ws), ws.numel(), engine.ctx.stream()))
+        ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes = engine, cfg, ws, bwd_bytes
+        ctx.shapes = (latent.shape, R.shape, T.shape)
+        ctx.mark_non_differentiable(mask)
+        return zdepth, mask, min_sdf, depth, normal
+
+    @staticmethod
+    def backward(ctx, g_zdepth, g_mask, g_min_sdf, g_depth, g_normal):
+        engine, cfg, ws = ctx.engine, ctx.cfg, ctx.ws
+        dev = engine.device
+
+        def prep(g, n):
+            if g is None or g.numel() != n:
+                return None
+            return g.to(dtype=torch.float32).contiguous()
+        P = cfg.H * cfg.W
+        gz, gq = prep(g_zdepth, P), prep(g_min_sdf, P)
+        gd, gn = (prep(g_depth, P), prep(g_normal, 3 * P)) if cfg.want_normal else (None, None)
+        g_lat = torch.empty(256, dtype=torch.float32, device=dev)
+        g_R = torch.empty(9, dtype=torch.float32, device=dev)
+        g_T = torch.empty(3, dtype=torch.float32, device=dev)
+        ws_b = torch.empty(ctx.bwd_bytes, dtype=torch.uint8, device=dev)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_render_backward(
+            engine.ctx.h, C.byref(cfg), p(ws), ws.numel(), p(gz), p(gq), p(gd), p(gn), p(g_lat), p(g_R), p(g_T),
+            p(ws_b), ws_b.numel(), engine.ctx.stream()))
+        ctx.last_ws = ws
+        ls, rs, ts = ctx.shapes
+        return g_lat.reshape(ls), g_R.reshape(rs), g_T.reshape(ts), None, None
+
+
+def render_call(engine, cfg, latent, R, T):
+    return RenderFunction.apply(latent, R, T, engine, cfg)
+
+
+def render_normal_call(engine, cfg, latent, R, T, zdepth, mask):
+    """SDFRenderer.render_normal forward (renderer.py:880-910) -> (3, P). Gradient-free: for ReLU decoders the
+    normalised SDF gradient is piecewise constant in (latent, point), its autograd contribution is identically ~0
+    (SURVEY.md A.6-1)."""
+    dev = engine.device
+    P = cfg.H * cfg.W
+    lat, Rc, Tc = _f32c(latent, dev).reshape(-1), _f32c(R, dev).reshape(-1), _f32c(T, dev).reshape(-1)
+    z = _f32c(zdepth, dev).reshape(-1)
+    m = mask.detach().to(device=dev).reshape(-1).to(torch.uint8).contiguous()
+    fwd_bytes, _ = engine.ctx.workspace_bytes(cfg)
+    ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(3, P, dtype=torch.float32, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_render_normal(engine.ctx.h, C.byref(cfg), p(lat), p(Rc), p(Tc), p(z), p(m), p(out),
+                                                      p(ws), ws.numel(), engine.ctx.stream()))
+    return out
+
+
+def mlp_eval(engine, latent, points, clamp_dist=None):
+    """decode_sdf forward (core/utils/decoder_utils.py:53-74): points (n,3) -> (n,1)."""
+    dev = engine.device
+    lat = _f32c(latent, dev).reshape(-1)
+    x = _f32c(points, dev).reshape(-1, 3)
+    n = x.shape[0]
+    out = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_mlp_eval(engine.ctx.h, p(lat), p(x), n, -1.0 if clamp_dist is None else float(clamp_dist),
+                                                p(out), p(ws), ws.numel(), engine.ctx.stream()))
+    return out
+
+
+def mlp_grad(engine, latent, points):
+    """(sdf (n,), d sdf/d xyz (n,3)) of the unclamped decoder."""
+    dev = engine.device
+    lat = _f32c(latent, dev).reshape(-1)
+    x = _f32c(points, dev).reshape(-1, 3)
+    n = x.shape[0]
+    sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    g = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_mlp_grad(engine.ctx.h, p(lat), p(x), n, p(sdf), p(g), p(ws), ws.numel(), engine.ctx.stream()))
+    return sdf, g
+
+
+def debug_mlp_layer(engine, latent, points, layer):
+    """Test aid: post-activation of hidden layer `layer` -> (n,512)."""
+    dev = engine.device
+    lat = _f32c(latent, dev).reshape(-1)
+    x = _f32c(points, dev).reshape(-1, 3)
+    n = x.shape[0]
+    out = torch.empty(n, 512, dtype=torch.float32, device=dev)
+    ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_debug_mlp_layer(engine.ctx.h, p(lat), p(x), n, int(layer), p(out), p(ws), ws.numel(),
+                                                       engine.ctx.stream()))
+    return out

@@ -1,0 +1,61 @@
+"""View-parallel multi-GPU helpers: one process per GPU, views sharded over ranks, ONE small RCCL all-reduce of the
+packed [latent-gradient | scalars] buffer per optimiser step.
+
+The reference has no distributed code at all; the natural data-parallel axis is the sum over view pairs that
+optimize_multi.py:62-81 accumulates before a single backward(). Rays never need to be exchanged: every rank holds
+the (1.8 M parameter) decoder and renders its own views, so the only collective is the gradient sum -- ~1 KiB,
+latency-bound on xGMI, which is why everything is packed into a single call.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world_size, local_rank). backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_views(num_views, rank, world_size):
+    """Round-robin view assignment: rank r renders views r, r+world, ... (C4: 8 views on 8 GPUs = 1 view each)."""
+    return list(range(rank, num_views, world_size))
+
+
+def allreduce_packed(tensors, group=None):
+    """Sums every tensor of `tensors` over all ranks with ONE all-reduce of a packed flat f32 buffer (in place)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.detach().copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+        off += n
+    return tensors
+
+
+def allreduce_max_scalar(value, device=None, group=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def barrier(group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)

@@ -1,0 +1,152 @@
+/*
+ * distr.h -- C ABI of libdistr.so: MI355X-native differentiable sphere tracing of DeepSDF decoders.
+ *
+ * Drop-in boundary for the hot path of B1ueber2y/DIST-Renderer (all citations: paths under the
+ * reference tree, file:line). The reference has no native interface -- its hot path is Python that
+ * issues hundreds of ATen launches per march step -- so each entry point below replaces a Python
+ * method; the Python mirror in dist-renderer_amd/core/ calls these through ctypes with
+ * tensor.data_ptr() and the current HIP stream (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C, no C++ / torch types; every pointer named *_dev is DEVICE memory owned by the caller;
+ *   - the library never allocates or frees device memory inside forward/backward and never
+ *     synchronises the device: all work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - all functions return 0 (DISTR_OK) or a negative error code; distr_last_error() gives text;
+ *   - a context is bound to one HIP device; it is not thread-safe, distinct contexts are independent;
+ *   - everything is float32 except masks (uint8) -- the same types the reference computes in.
+ */
+#ifndef DISTR_H_
+#define DISTR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISTR_OK 0
+#define DISTR_ERR_INVALID_ARG (-1)
+#define DISTR_ERR_UNSUPPORTED (-2)
+#define DISTR_ERR_HIP (-3)
+#define DISTR_ERR_WORKSPACE (-4)
+#define DISTR_ERR_NO_DECODER (-5)
+
+#define DISTR_MARCH_TRIVIAL 0           /* SDFRenderer.ray_marching_trivial            renderer.py:472 */
+#define DISTR_MARCH_RECURSIVE 1         /* SDFRenderer.ray_marching_recursive          renderer.py:512 */
+#define DISTR_MARCH_PYRAMID_RECURSIVE 2 /* SDFRenderer.ray_marching_pyramid_recursive  renderer.py:713 */
+
+#define DISTR_MAX_BUFFER_SIZE 8
+
+typedef struct distr_ctx distr_ctx;
+
+/* Architecture of the decoder: replaces Decoder.__init__ (core/graph/deep_sdf_decoder.py:19-73) +
+ * specs.json handling of load_decoder (core/utils/decoder_utils.py:7-27). The kernels are specialised
+ * for DeepSDF "8x512": latent 256, hidden 512, latent_in=[4], ReLU, final tanh, no LayerNorm. */
+typedef struct distr_decoder_desc {
+  int32_t latent_size;  /* 256 */
+  int32_t hidden;       /* 512 */
+  int32_t num_linear;   /* 9  (lin0..lin8) */
+  int32_t latent_in;    /* 4  */
+} distr_decoder_desc;
+
+/* Per-renderer + per-call options: SDFRenderer.__init__ (renderer.py:13-59) and the keyword arguments
+ * of render / render_depth (renderer.py:836, 943). */
+typedef struct distr_render_cfg {
+  int32_t H, W;               /* img_hw                                                     renderer.py:31-35 */
+  float K_inv[9];             /* float32(inv(K)), row-major                                 renderer.py:161-164 */
+  float fx, fy;               /* K[0,0], K[1,1] (depth2normal)                              renderer.py:973-974 */
+  float M[9];                 /* transform_matrix (3x3), identity when use_transform=False  renderer.py:45, 84-120 */
+  int32_t march_step;         /* renderer.py:18  */
+  int32_t buffer_size;        /* renderer.py:19  (<= DISTR_MAX_BUFFER_SIZE) */
+  float ratio;                /* ray_marching_ratio renderer.py:21 */
+  float threshold;            /* renderer.py:24  */
+  float radius;               /* renderer.py:23  */
+  float clamp_dist;           /* clamp_dist kwarg of render()                               renderer.py:943 */
+  int32_t marcher;            /* DISTR_MARCH_*   ray_marching_type                          renderer.py:807-834 */
+  int32_t coarse_steps[2];    /* march_step_list[0:2] for scale_list=[4,2,1]                renderer.py:25-26, 724-725 */
+  int32_t use_depth2normal;   /* renderer.py:22, 972-975 */
+  int32_t normalize_normal;   /* normalize_normal kwarg                                     renderer.py:898-901 */
+  int32_t want_normal;        /* 0: render_depth() only (no depth/normal image outputs) */
+  int32_t grad_depth;         /* !no_grad_depth                                             renderer.py:410-411, 876-877 */
+  int32_t grad_mask;          /* !no_grad_mask                                              renderer.py:388-389 */
+  int32_t grad_camera;        /* !no_grad_camera                                            renderer.py:536-542 */
+} distr_render_cfg;
+
+/* Counters of one forward call (read back with distr_get_render_stats). */
+typedef struct distr_render_stats {
+  int64_t num_in_sphere;      /* rays hitting the unit sphere (N of renderer.py:473)   */
+  int64_t num_march_launches; /* launches of the fused march/MLP kernel                */
+  int64_t num_point_evals;    /* decoder evaluations executed by the march kernel      */
+  int64_t num_valid;          /* final valid pixels                                    */
+  int64_t num_grad_samples;   /* (backward) gradient-carrying samples of the last backward on this workspace */
+} distr_render_stats;
+
+int distr_create(distr_ctx** out, int hip_device);
+void distr_destroy(distr_ctx* ctx);
+const char* distr_last_error(const distr_ctx* ctx);
+const char* distr_version(void);
+
+/* Upload + pack decoder weights. `weights_host` = for l in 0..8: W_l row-major (out,in) then b_l (effective
+ * weights, weight-norm already folded); replaces load_decoder()'s load_state_dict (decoder_utils.py:33-50). */
+int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* weights_host, size_t n_floats);
+
+/* Bytes the caller must provide as `ws_dev` to forward (it doubles as the saved-for-backward buffer and must
+ * stay untouched until backward has run) and as `ws_bwd_dev` to backward. */
+int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* forward_bytes, size_t* backward_bytes);
+
+/* SDFRenderer.render_depth (renderer.py:836-878) and, when cfg->want_normal, the rest of
+ * SDFRenderer.render (renderer.py:943-999).
+ *   latent_dev[256], R_dev[9] row-major, T_dev[3]
+ *   zdepth_dev[H*W]   Zdepth   (1e11 where the ray misses the unit sphere)
+ *   mask_dev[H*W]     final valid mask (uint8 0/1)
+ *   min_sdf_dev[H*W]  min_sdf_sample / min_abs_query
+ *   depth_dev[H*W]    (want_normal) depth = Zdepth*calib on valid px, else 1e11 -- 0 when use_depth2normal
+ *                     (the reference's depth2normal zeroes the background in place, render_utils.py:24-25)
+ *   normal_dev[H*W*3] (want_normal) (h,w,3) normal map
+ * Output pointers may be NULL when not wanted. */
+int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent_dev, const float* R_dev,
+                         const float* T_dev, float* zdepth_dev, uint8_t* mask_dev, float* min_sdf_dev,
+                         float* depth_dev, float* normal_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* What loss.backward() does through the reference's autograd tape (optimize_single.py:83): upstream gradients of
+ * the forward outputs (any may be NULL) -> gradients of latent (256), R (9), T (3). `ws_dev` is the forward
+ * workspace of the SAME cfg/inputs. */
+int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws_dev, size_t ws_bytes,
+                          const float* g_zdepth_dev, const float* g_min_sdf_dev, const float* g_depth_dev,
+                          const float* g_normal_dev, float* g_latent_dev, float* g_R_dev, float* g_T_dev,
+                          void* ws_bwd_dev, size_t ws_bwd_bytes, void* stream);
+
+/* SDFRenderer.render_normal (renderer.py:880-910) for caller-provided Zdepth/mask: writes (3, H*W) like the
+ * reference (untransformed by R; render() applies R and the x-flip itself). */
+int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent_dev, const float* R_dev,
+                        const float* T_dev, const float* zdepth_dev, const uint8_t* mask_dev, float* normal3xP_dev,
+                        void* ws_dev, size_t ws_bytes, void* stream);
+
+/* decode_sdf (core/utils/decoder_utils.py:53-74): n points xyz_dev[n][3] -> sdf_dev[n]; clamp_dist < 0 = no clamp.
+ * decode_sdf_gradient (decoder_utils.py:76-92) without the 3x of the torch-1.1 grad_outputs quirk:
+ * grad_dev[n][3] = d f / d xyz (callers apply clamp mask / scaling). ws >= distr_mlp_workspace_bytes(n). */
+size_t distr_mlp_workspace_bytes(int64_t n);
+int distr_mlp_eval(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float clamp_dist,
+                   float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
+int distr_mlp_grad(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float* sdf_dev,
+                   float* grad_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Test aid: post-activation of hidden layer `layer` (0..7) for n points -> out_dev[n][512]. */
+int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, int layer,
+                          float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Debug / measurement. distr_get_render_stats copies the counters of the forward (and last backward) that used
+ * `ws_dev` device->host and synchronises `stream`.
+ * Profiling: when enabled, every launch of the fused march/MLP kernel is bracketed by hipEvents on the launch
+ * stream; distr_profile_read synchronises `stream` and returns the number of bracketed launches and their summed
+ * kernel milliseconds since the last read (reset on read). */
+int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws_dev, distr_render_stats* out,
+                       void* stream);
+int distr_profile_enable(distr_ctx* ctx, int enable);
+int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISTR_H_ */

@@ -1,0 +1,263 @@
+"""GPU parity tests: the HIP kernels (called through the C ABI of libdistr.so) against the CPU oracle on the same
+seeded inputs, against the committed reference goldens, and -- at BASELINE.json's full sizes -- through
+size-independent properties. Run on the MI355X box: python -m pytest tests -m gpu.
+
+Tolerances: north_star asks for depth / normal / silhouette within 1e-4 of the reference. HIP vs oracle is held
+to 1e-6 wherever both sides are the same IEEE op sequence (decoder, march); the reduction order of the backward
+differs, so gradients are compared at 1e-4 relative.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine(fixture_decoder):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from distr import binding, functions
+    assert os.path.exists(binding.LIB_PATH), 'libdistr.so missing: run __graft_entry__.build()'
+    Ws, bs, _ = fixture_decoder
+    return functions.engine_from_weights(Ws, bs, 0)
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def _points(n, seed=3):
+    rs = np.random.RandomState(seed)
+    p = (rs.rand(n, 3) * 1.8 - 0.9).astype(np.float32)
+    p[:4] = 0.0
+    return p
+
+
+def test_decoder_layers_bitwise(engine, cpu_oracle, fixture_decoder):
+    """Every hidden layer of the fused MFMA decoder == the oracle's k-ordered fmaf chains, bit for bit."""
+    import torch
+    from distr import functions
+    _, _, latent = fixture_decoder
+    pts = _points(64 * 3 + 17)
+    for layer in range(8):
+        got = functions.debug_mlp_layer(engine, torch.from_numpy(latent), torch.from_numpy(pts), layer).cpu().numpy()
+        ref = cpu_oracle.layer_activations(latent, pts, layer)
+        width = 256 if layer == 3 else 512
+        diff = np.abs(got[:, :width] - ref[:, :width])
+        assert diff.max() == 0.0, 'layer %d: max diff %g at %s' % (layer, diff.max(), np.unravel_index(diff.argmax(), diff.shape))
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 4096 + 37])
+def test_decode_sdf_matches_oracle(engine, cpu_oracle, fixture_decoder, n):
+    import torch
+    from distr import functions
+    _, _, latent = fixture_decoder
+    pts = _points(n)
+    got = functions.mlp_eval(engine, torch.from_numpy(latent), torch.from_numpy(pts)).cpu().numpy().reshape(-1)
+    ref = cpu_oracle.decode_sdf(latent, pts)
+    assert np.abs(got - ref).max() <= 1e-7, np.abs(got - ref).max()
+    got_c = functions.mlp_eval(engine, torch.from_numpy(latent), torch.from_numpy(pts), 0.1).cpu().numpy().reshape(-1)
+    assert np.abs(got_c - np.clip(ref, -0.1, 0.1)).max() <= 1e-7
+
+
+def test_decode_sdf_matches_reference_golden(engine):
+    import torch
+    from distr import functions
+    g = np.load(os.path.join(GOLDEN, 'g2_decode_sdf.npz'))
+    got = functions.mlp_eval(engine, torch.from_numpy(g['latent']), torch.from_numpy(g['points'])).cpu().numpy().reshape(-1)
+    assert np.abs(got - g['sdf']).max() <= 2e-6
+    sdf, grad = functions.mlp_grad(engine, torch.from_numpy(g['latent']), torch.from_numpy(g['points']))
+    sdf, grad = sdf.cpu().numpy(), grad.cpu().numpy()
+    inclamp = np.abs(g['sdf']) <= 0.1 - 1e-5
+    assert np.abs(3.0 * grad[inclamp] - g['gradient_x3_clamped'][inclamp]).max() <= 5e-5
+
+
+def test_decode_sdf_gradient_matches_oracle(engine, cpu_oracle, fixture_decoder):
+    import torch
+    from distr import functions
+    _, _, latent = fixture_decoder
+    pts = _points(300)
+    sdf, grad = functions.mlp_grad(engine, torch.from_numpy(latent), torch.from_numpy(pts))
+    s_ref, g_ref = cpu_oracle.decode_sdf_and_gradient(latent, pts)
+    assert np.abs(sdf.cpu().numpy() - s_ref).max() <= 1e-7
+    assert np.abs(grad.cpu().numpy() - g_ref).max() <= 1e-5 * max(1.0, np.abs(g_ref).max())
+
+
+CASES = [(m, d) for m in ('trivial', 'recursive', 'pyramid_recursive') for d in (False, True)]
+
+
+@pytest.mark.parametrize('marcher,d2n', CASES)
+def test_render_c1_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, marcher, d2n):
+    """C1 (64x64, 20 steps, bs=3, rotated camera): forward outputs and latent/camera gradients vs the oracle."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(30, 20, 1.6, 10)
+    kw = dict(march_step=20, buffer_size=3, marcher=marcher, use_depth2normal=d2n)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=1e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0, res
+
+
+@pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))))
+def test_render_matches_reference_goldens(engine, name):
+    """HIP path directly against outputs of the reference itself (tests/golden, made by oracle/gen_golden.py)."""
+    from distr import fixture, decoder_pack, functions
+    g = dict(np.load(os.path.join(GOLDEN, name)))
+    H, W = int(g['H']), int(g['W'])
+    eng = engine
+    if bool(g['weight_norm']):
+        Ws, bs, _ = fixture.make_decoder_weights(int(g['fixture_seed']))
+        Wse, bse = decoder_pack.effective_weights(decoder_pack.fixture_state_dict(Ws, bs, weight_norm=True))
+        eng = functions.engine_from_weights(Wse, bse, 0)
+    a = helpers.hip_render(eng, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']),
+                           march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']),
+                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']))
+    b = dict(mask=g['mask'], depth=g['depth'], zdepth=g['zdepth'], min_sdf=g['min_abs_query'], normal=g['normal'],
+             g_latent=g['g_latent'], g_R=g['g_R'], g_T=g['g_T'])
+    fx = float(g['K'][0, 0])
+    helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=2e-3,
+                    normal_p99=max(1e-4, 1e-5 * fx) if bool(g['use_depth2normal']) else 1e-4)
+
+
+def test_render_depth_and_warp_gradient_path(engine, cpu_oracle, orc, fixture_decoder):
+    """render_depth() callers (render_warp) send their gradient through Zdepth of every in-sphere pixel."""
+    import torch
+    from distr import binding, fixture, functions
+    _, _, latent = fixture_decoder
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-20, 10, 1.6, 0)
+    kw = dict(march_step=30, buffer_size=1, marcher='recursive', want_normal=False)
+    dev = engine.device
+    cfg = binding.make_cfg((H, W), K, **kw)
+    lat = torch.from_numpy(latent).to(dev).requires_grad_(True)
+    Rt = torch.from_numpy(R).to(dev).requires_grad_(True)
+    Tt = torch.from_numpy(T).to(dev).requires_grad_(True)
+    z, m, q, _, _ = functions.render_call(engine, cfg, lat, Rt, Tt)
+    gz = torch.from_numpy(np.random.RandomState(1).rand(H * W).astype(np.float32)).to(dev)
+    (z * gz)[m.bool()].sum().backward()
+    ocfg = orc.make_cfg(H, W, K, **kw)
+    out = cpu_oracle.render(ocfg, latent, R, T)
+    assert np.array_equal(out['mask'], m.cpu().numpy())
+    gl, gR, gT, _ = out['state'].backward(g_zdepth=gz.cpu().numpy() * out['mask'])
+    assert np.abs(z.detach().cpu().numpy() - out['zdepth'])[out['mask'].astype(bool)].max() <= 1e-6
+    for mine, ref in ((lat.grad, gl), (Rt.grad, gR), (Tt.grad, gT)):
+        assert np.abs(mine.cpu().numpy().reshape(-1) - ref.reshape(-1)).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_camera_inside_sphere_and_empty_view(engine, cpu_oracle, orc, fixture_decoder):
+    """Edge cases of get_intersections_with_unit_spheres (renderer.py:266-268): camera inside the unit sphere
+    (init depth 0 everywhere) and a camera looking away (no ray hits the sphere: empty lists everywhere)."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 32
+    K = fixture.make_intrinsic(H, W)
+    R, _ = fixture.make_camera(15, 5, 1.6, 0)
+    for T in (np.array([0, 0, 0.8], np.float32), np.array([0, 0, -3.0], np.float32)):
+        for marcher in ('recursive', 'pyramid_recursive'):
+            kw = dict(march_step=12, buffer_size=3, marcher=marcher, use_depth2normal=False)
+            a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+            b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+            helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=1e-4, normal_p99=1e-5, max_flip_frac=0.0)
+
+
+def test_c3_full_size_properties(engine, fixture_decoder):
+    """C3 = 512x512, 50 steps, depth2normal (the benchmark workload): properties that need no CPU reference."""
+    import torch
+    from distr import binding, fixture, functions
+    _, _, latent = fixture_decoder
+    H = W = 512
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(0, 0, 1.6, 0)
+    kw = dict(march_step=50, buffer_size=3, use_depth2normal=True)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='pyramid_recursive', **kw)
+    b = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='pyramid_recursive', **kw)
+    # idempotence: same inputs -> same bits (forward is deterministic; compaction order does not enter the values)
+    for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal'):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.abs(a['g_latent'] - b['g_latent']).max() <= 1e-4 * np.abs(a['g_latent']).max()   # atomics: order only
+    m = a['mask'].reshape(H, W).astype(bool)
+    assert 0.15 * H * W < m.sum() < 0.40 * H * W
+    # silhouette is inside the unit-sphere footprint, depth is within the sphere's extent, normals are unit length
+    assert np.all(a['zdepth'][a['mask'].astype(bool)] < 1e5)
+    d = a['depth'][m]
+    assert d.min() > 0.6 and d.max() < 2.6
+    nl = np.linalg.norm(a['normal'][m], axis=-1)
+    assert np.abs(nl - 1).max() < 1e-5
+    assert np.all(a['depth'][~m] == 0.0) and np.all(a['normal'][~m] == 0.0)      # depth2normal background convention
+    # converged pixels carry |sdf| <= threshold
+    assert np.all(np.abs(a['min_sdf'][a['mask'].astype(bool)]) <= 5e-5)
+    # the dense ('trivial') and compacted ('recursive') marchers agree on the surface they find
+    t = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='trivial', **kw)
+    r = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='recursive', **kw)
+    both = t['mask'].astype(bool) & r['mask'].astype(bool)
+    assert (t['mask'] != r['mask']).mean() < 0.01
+    assert np.abs(t['zdepth'] - r['zdepth'])[both].max() < 5e-4
+    # backward is linear in the upstream gradient
+    dev = engine.device
+    cfg = binding.make_cfg((H, W), K, marcher='pyramid_recursive', **kw)
+    lat = torch.from_numpy(latent).to(dev).requires_grad_(True)
+    Rt, Tt = torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev)
+    z, mk, q, dep, nrm = functions.render_call(engine, cfg, lat, Rt, Tt)
+    g1 = torch.rand(H, W, device=dev)
+    g2 = torch.rand(H * W, device=dev)
+    ga, = torch.autograd.grad((dep * g1)[mk.reshape(H, W).bool()].sum(), lat, retain_graph=True)
+    gb, = torch.autograd.grad((q * g2).sum(), lat, retain_graph=True)
+    gab, = torch.autograd.grad((dep * g1)[mk.reshape(H, W).bool()].sum() + (q * g2).sum(), lat)
+    assert (ga + gb - gab).abs().max() <= 2e-4 * gab.abs().max()
+
+
+def test_dropin_api_with_module(fixture_decoder):
+    """`from core.sdfrenderer import SDFRenderer, SDFRenderer_warp` with the reference's constructor/call signatures
+    (run_single_shape.py:110-117, run_multi_pmodata.py:92-100) on a weight-normed Decoder module."""
+    import torch
+    from core.sdfrenderer import SDFRenderer, SDFRenderer_warp
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.utils.decoder_utils import decode_sdf, decode_sdf_gradient
+    from distr import decoder_pack, fixture
+    Ws, bs, latent = fixture_decoder
+    dec = Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
+                  weight_norm=True, xyz_in_all=False, use_tanh=False, latent_dropout=False)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in decoder_pack.fixture_state_dict(Ws, bs, True).items()})
+    dec = torch.nn.DataParallel(dec.cuda()).module        # drivers unwrap DataParallel (decoder_utils.py:29-30)
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(25, 15, 1.6, 0)
+    r = SDFRenderer(dec, K, march_step=30, buffer_size=3, threshold=5e-5, ray_marching_ratio=1.5, use_depth2normal=True)
+    assert r.get_img_hw() == (H, W) and r.get_threshold() == 5e-5
+    lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+    Rt, Tt = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda()
+    depth, normal, mask, q = r.render(lat, Rt, Tt)
+    assert depth.shape == (H, W) and normal.shape == (H, W, 3) and mask.shape == (H, W) and q.shape == (H, W)
+    assert mask.dtype == torch.uint8 and depth.dtype == torch.float32
+    (depth[mask.bool()].sum() + q.sum() + normal.sum()).backward()
+    assert lat.grad is not None and torch.isfinite(lat.grad).all() and lat.grad.abs().max() > 0
+    # PyTorch evaluation of the same module agrees with the fused kernel
+    pts = torch.from_numpy(_points(500)).cuda()
+    with torch.no_grad():
+        ref = dec.inference(torch.cat([lat.detach().expand(500, -1), pts], 1))
+        got = decode_sdf(dec, lat.detach(), pts, clamp_dist=None, no_grad=True)
+    assert (ref - got).abs().max() < 5e-6
+    g = decode_sdf_gradient(dec, lat.detach(), pts, clamp_dist=0.1, no_grad=True)
+    assert g.shape == (500, 3)
+    # multi-view warp loss (run_multi_pmodata.py:92: march_step=100, buffer_size=1, default 'recursive' marcher)
+    rw = SDFRenderer_warp(dec, K, march_step=40, buffer_size=1)
+    R2, T2 = fixture.make_camera(35, 15, 1.6, 0)
+    img1, img2 = torch.rand(H, W, 3).cuda(), torch.rand(H, W, 3).cuda()
+    lat2 = torch.from_numpy(latent).cuda().requires_grad_(True)
+    out = rw.render_warp(lat2, Rt, Tt, torch.from_numpy(R2).cuda(), torch.from_numpy(T2).cuda(), img1, img2)
+    assert len(out) == 9
+    out[0].backward()
+    assert lat2.grad is not None and torch.isfinite(lat2.grad).all()
