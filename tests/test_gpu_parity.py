@@ -204,7 +204,8 @@ def test_c3_full_size_properties(engine, fixture_decoder):
     r = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='recursive', **kw)
     both = t['mask'].astype(bool) & r['mask'].astype(bool)
     assert (t['mask'] != r['mask']).mean() < 0.01
-    assert np.abs(t['zdepth'] - r['zdepth'])[both].max() < 5e-4
+    # (the dense marcher keeps over-stepping around the surface after |sdf| < threshold: agreement is O(step), not O(eps))
+    assert np.abs(t['zdepth'] - r['zdepth'])[both].max() < 5e-3
     # backward is linear in the upstream gradient
     dev = engine.device
     cfg = binding.make_cfg((H, W), K, marcher='pyramid_recursive', **kw)
