@@ -3,8 +3,10 @@
 // No device allocation / synchronisation happens inside forward/backward (caller-owned workspaces, caller's stream).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,6 +23,8 @@ struct distr_ctx {
   DecoderDev D{};
   bool has_decoder = false;
   bool profiling = false;
+  int tile_rb = 0;           // 0: hybrid (64-ray tiles, 32-ray tiles once few rays are live); 1 / 2: force 32 / 64-ray tiles
+  int hybrid_threshold = 8192;  // live-ray count below which a march step runs on 32-ray tiles
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
 };
@@ -137,7 +141,7 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V) {
 
 size_t bwd_bytes(const distr_render_cfg& c) {
   const size_t smax = (size_t)c.H * c.W * c.buffer_size + 1;
-  const size_t tiles = (smax + TILE - 1) / TILE;
+  const size_t tiles = (smax + 31) / 32;
   return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + 256;
 }
 
@@ -173,6 +177,9 @@ int distr_create(distr_ctx** out, int hip_device) {
   *out = nullptr;
   distr_ctx* ctx = new distr_ctx();
   ctx->device = hip_device;
+  if (const char* e = getenv("DISTR_TILE_RB")) ctx->tile_rb = atoi(e);
+  if (ctx->tile_rb < 0 || ctx->tile_rb > 2) ctx->tile_rb = 0;
+  if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || hip_device < 0 || hip_device >= n) {
@@ -289,6 +296,8 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   hipStream_t s = (hipStream_t)stream;
   const DecoderDev& D = ctx->D;
   const int P = V.P;
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;   // tile used for dense launches
+  const int TILE = 32 * rb_dense;
 
   hipLaunchKernelGGL(k_prep, dim3(4), dim3(256), 0, s, V.C, D, latent, R, T);
   LAUNCH_CHECK("k_prep");
@@ -300,6 +309,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   MarchArgs A;
   memset(&A, 0, sizeof(A));
   A.V = V;
+  A.count_lo = 0; A.count_hi = 0x7fffffff;
   bool origin_done = false;
   for (int l = V.nlev - 1; l >= 1; --l) {
     hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
@@ -309,7 +319,8 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       origin_done = true;
       const unsigned tiles = (unsigned)((V.lv[l].n + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
       timer.begin();
-      hipLaunchKernelGGL(k_march<MODE_COARSE>, dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      else hipLaunchKernelGGL((k_march<MODE_COARSE, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       timer.end();
       LAUNCH_CHECK("k_march<coarse>");
     }
@@ -320,8 +331,17 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     A.lvl = 0; A.step = st; A.origin_tile = origin_done ? 0 : 1;
     origin_done = true;
     const unsigned tiles = (unsigned)((P + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
+    const bool hybrid = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
     timer.begin();
-    hipLaunchKernelGGL(k_march<MODE_FINE>, dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    A.count_lo = hybrid ? ctx->hybrid_threshold : 0; A.count_hi = 0x7fffffff;
+    if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    else hipLaunchKernelGGL((k_march<MODE_FINE, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    if (hybrid) {  // the same step on 32-ray tiles (two workgroups per CU) when fewer than `hybrid_threshold` rays are live
+      MarchArgs A1 = A;
+      A1.count_lo = 0; A1.count_hi = ctx->hybrid_threshold; A1.origin_tile = 0;
+      const unsigned t1 = (unsigned)((std::min(P, ctx->hybrid_threshold) + 31) / 32);
+      hipLaunchKernelGGL((k_march<MODE_FINE, 1>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
+    }
     timer.end();
     LAUNCH_CHECK("k_march<fine>");
   }
@@ -337,7 +357,8 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       memset(&B, 0, sizeof(B));
       B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = V.zdepth_s;
       B.out_sdf = V.n_sdf; B.out_g = V.n_g;
-      hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+      if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+      else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
       LAUNCH_CHECK("k_bwd<pointgrad>");
       hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
                          (const float*)V.n_sdf, (const float*)V.n_g, normal, (float*)nullptr, V.nrm_t);
@@ -370,6 +391,8 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   const DecoderDev& D = ctx->D;
   const int P = V.P;
   const size_t smax = (size_t)P * cfg->buffer_size + 1;
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
   Carver cv(ws_bwd);
   Sample* samples = cv.take<Sample>(smax);
   const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
@@ -384,11 +407,12 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
-  hipLaunchKernelGGL(k_bwd<BWD_FULL>, dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_FULL, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  else hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
   LAUNCH_CHECK("k_bwd<full>");
   const int chunk = 64;
   hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, (tiles + chunk - 1) / chunk), dim3(256), 0, s, V,
-                     (const float*)partial, chunk);
+                     (const float*)partial, chunk, TILE);
   LAUNCH_CHECK("k_bwd_reduce");
   hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, g_latent, g_R, g_T);
   LAUNCH_CHECK("k_bwd_final");
@@ -416,7 +440,10 @@ int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = zdepth; B.out_sdf = V.n_sdf; B.out_g = V.n_g;
-  hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
+  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
   LAUNCH_CHECK("k_bwd<pointgrad>");
   hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
                      (const float*)V.n_sdf, (const float*)V.n_g, (float*)nullptr, normal3xP, (float*)nullptr);
@@ -441,8 +468,11 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   memset(&A, 0, sizeof(A));
   A.xyz = xyz; A.sdf_out = sdf; A.c0c4 = c0c4; A.n = n; A.clamp = clamp;
   MarchTimer timer(ctx, s);
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
   timer.begin();
-  hipLaunchKernelGGL(k_march<MODE_EVAL>, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  else hipLaunchKernelGGL((k_march<MODE_EVAL, 2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
   timer.end();
   LAUNCH_CHECK("k_march<eval>");
   return DISTR_OK;
@@ -462,7 +492,10 @@ int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.n = n; B.xyz = xyz; B.c0c4 = c0c4; B.out_sdf = sdf; B.out_g = grad;
-  hipLaunchKernelGGL(k_bwd<BWD_POINTGRAD>, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
+  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
+  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
   LAUNCH_CHECK("k_bwd<pointgrad>");
   return DISTR_OK;
 }
@@ -477,7 +510,10 @@ int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz,
   float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
   LAUNCH_CHECK("k_latent_consts");
-  hipLaunchKernelGGL(k_debug_layer, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
+  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
+  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
   LAUNCH_CHECK("k_debug_layer");
   return DISTR_OK;
 }

@@ -328,11 +328,13 @@ struct MarchArgs {
   const float* c0c4;         // MODE_EVAL: latent constants
   int64_t n;
   float clamp;
+  int32_t count_lo, count_hi;  // MODE_FINE: this launch only runs if count_lo <= live count < count_hi (tile-size hybrid)
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_march(MarchArgs A, DecoderDev D) {
-  __shared__ Smem S;
+template <int MODE, int RB>
+__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
+  constexpr int TILE = 32 * RB;
+  __shared__ Smem<RB> S;
   const View& V = A.V;
   const int tid = threadIdx.x;
   int tile = blockIdx.x;
@@ -351,7 +353,10 @@ __global__ void __launch_bounds__(256, 1) k_march(MarchArgs A, DecoderDev D) {
     else { count = V.C->cnt_live[A.step]; list = V.live[A.step & 1]; }
   }
   const int64_t base = (int64_t)tile * TILE;
-  if (!origin && base >= count) return;
+  if (!origin) {
+    if (base >= count) return;
+    if (MODE == MODE_FINE && (count < A.count_lo || count >= A.count_hi)) return;   // the other tile size handles this step
+  }
 
   int32_t id = -1;
   float zd = 0.f;
@@ -384,9 +389,9 @@ __global__ void __launch_bounds__(256, 1) k_march(MarchArgs A, DecoderDev D) {
   uint32_t masks[8][4];
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward<false>(D, c0, c4, S, masks);
+  const float pre = mlp_forward<RB, false>(D, c0, c4, S, masks);
 
-  if (tid >= TILE) return;  // epilogue: wave 0, lane = ray of the tile
+  if (tid >= 64) return;  // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
   const float s = tanh_spec(pre);
   if (origin) { if (tid == 0) V.C->f_origin = s; return; }
 
@@ -425,9 +430,11 @@ __global__ void __launch_bounds__(256, 1) k_march(MarchArgs A, DecoderDev D) {
 }
 
 // test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
-__global__ void __launch_bounds__(256, 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer, float* out,
-                                                        DecoderDev D) {
-  __shared__ Smem S;
+template <int RB>
+__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer,
+                                                                        float* out, DecoderDev D) {
+  constexpr int TILE = 32 * RB;
+  __shared__ Smem<RB> S;
   const int tid = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * TILE;
   if (tid < TILE) {
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(256, 1) k_debug_layer(const float* xyz, int64_
   }
   __syncthreads();
   uint32_t masks[8][4];
-  mlp_forward<false, true>(D, c0c4, c0c4 + HID, S, masks, layer);
+  mlp_forward<RB, false, true>(D, c0c4, c0c4 + HID, S, masks, layer);
   __syncthreads();
   for (int i = tid; i < HID * TILE; i += 256) {
     const int f = i / TILE, ray = i % TILE;
@@ -554,9 +561,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_bwd(BwdArgs A, DecoderDev D) {
-  __shared__ Smem S;
+template <int MODE, int RB>
+__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, DecoderDev D) {
+  constexpr int TILE = 32 * RB;
+  __shared__ Smem<RB> S;
   const View& V = A.V;
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -595,7 +603,7 @@ __global__ void __launch_bounds__(256, 1) k_bwd(BwdArgs A, DecoderDev D) {
   uint32_t masks[8][4];
   const float* c0 = A.c0c4 ? A.c0c4 : V.C->c0;
   const float* c4 = A.c0c4 ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward<true>(D, c0, c4, S, masks);
+  const float pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
   float y = 0.f;
   if (tid < TILE) {
     y = tanh_spec(pre);
@@ -603,10 +611,11 @@ __global__ void __launch_bounds__(256, 1) k_bwd(BwdArgs A, DecoderDev D) {
   }
   __syncthreads();
   float* part = (MODE == BWD_FULL) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
-  mlp_backward(D, S, masks, part, part ? part + HID : nullptr);
+  mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
 
-  if (tid >= TILE) return;
-  const float gp0 = S.aux[TILE + tid], gp1 = S.aux[2 * TILE + tid], gp2 = S.aux[3 * TILE + tid];
+  if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
+  const int rl = tid & (TILE - 1);
+  const float gp0 = S.aux[TILE + rl], gp1 = S.aux[2 * TILE + rl], gp2 = S.aux[3 * TILE + rl];
   if (MODE == BWD_POINTGRAD) {
     if (valid) {
       A.out_sdf[r] = y;
@@ -841,9 +850,9 @@ __global__ void k_bwd_pad(View V, Sample* samples) {
 }
 
 // column sums of the tile partials (deterministic order), chunked over tiles
-__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, int chunk) {
+__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, int chunk, int tile) {
   const int col = blockIdx.x * 256 + threadIdx.x;
-  const int ntiles = (V.C->cnt_samples + TILE - 1) / TILE;
+  const int ntiles = (V.C->cnt_samples + tile - 1) / tile;
   const int t0 = blockIdx.y * chunk, t1 = min(ntiles, t0 + chunk);
   if (col >= 2 * HID + 12 || t0 >= t1) return;
   float s = 0.f;

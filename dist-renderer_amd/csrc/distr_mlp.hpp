@@ -26,7 +26,6 @@
 
 namespace distr {
 
-constexpr int TILE = 64;
 constexpr int HID = 512;
 constexpr int LAT = 256;
 constexpr int NTHREADS = 256;
@@ -49,10 +48,14 @@ struct DecoderDev {
   float b8;
 };
 
+// A tile = RB blocks of 32 rays. RB=2: 64 rays, 133 KiB LDS, one workgroup per CU. RB=1: 32 rays, 67 KiB LDS, two
+// workgroups per CU (each hides the other's prologue / epilogue / barrier stalls; half the tile latency).
+template <int RB>
 struct Smem {
+  static constexpr int TILE = 32 * RB;
   float X[HID * TILE];   // activations / deltas [feature][ray]
   float xyz[4 * TILE];   // rows 0..2: sample points of the tile
-  float part[12 * TILE]; // lin8 partial chains [4][64]; backward: xyz-gradient partials [3][4][64]
+  float part[12 * TILE]; // lin8 partial chains [4][TILE]; backward: xyz-gradient partials [3][4][TILE]
   float aux[4 * TILE];   // backward: row 0 = d8, rows 1..3 = d/dxyz through lin4's xyz columns
 };
 
@@ -100,8 +103,8 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v 
 
 // ---------------------------------------------------------------------------------------- dense layer
 // D rows of one 32x32 accumulator register r on lane (j,h): row = (r&3) + 8*(r>>2) + 4*h, col = j.
-template <int NOB>
-__device__ __forceinline__ void acc_init(f32x16 (&acc)[NOB][2], const float* __restrict__ init, int row0, int h) {
+template <int NOB, int RB>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[NOB][RB], const float* __restrict__ init, int row0, int h) {
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
@@ -109,62 +112,73 @@ __device__ __forceinline__ void acc_init(f32x16 (&acc)[NOB][2], const float* __r
       const f32x4 b = *reinterpret_cast<const f32x4*>(init + row0 + 32 * ob + 8 * q + 4 * h);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[ob][0][4 * q + j] = b[j];
-        acc[ob][1][4 * q + j] = b[j];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[ob][rb][4 * q + j] = b[j];
       }
     }
   }
 }
 
-template <int NOB>
-__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NOB][2]) {
+template <int NOB, int RB>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NOB][RB]) {
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[ob][0][r] = 0.f; acc[ob][1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[ob][rb][r] = 0.f;
+    }
 }
 
 // acc[ob][rb] += W[rows of this wave][0..K) * X[0..K)[rays]   (K multiple of 8, natural k order)
 // Wp: packed fragments, float4 index ((g*4 + wave)*NOB + ob)*64 + lane  holds
 //     { W[o][8g+2s+h] : s=0..3 },  o = wave*32*NOB + 32*ob + (lane&31), h = lane>>5.
-template <int K, int NOB>
-__device__ __forceinline__ void dense(const float* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][2], int wave,
+template <int K, int NOB, int RB>
+__device__ __forceinline__ void dense(const float* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][RB], int wave,
                                       int lane) {
   constexpr int NG = K / 8;
+  constexpr int TILE = 32 * RB;
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)wave * NOB * 64 + lane;
   const float* xb = X + (lane >> 5) * TILE + (lane & 31);
   f32x4 a[NOB];
-  float b[8];
+  float b[4][RB];
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) a[ob] = wp[ob * 64];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) { b[2 * s] = xb[2 * s * TILE]; b[2 * s + 1] = xb[2 * s * TILE + 32]; }
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) b[s][rb] = xb[2 * s * TILE + 32 * rb];
 #pragma unroll 2
   for (int g = 0; g < NG; ++g) {
-    // register double buffer: fetch group g+1 (weights from L2, activations from LDS) before the 32 MFMAs of
-    // group g; the scheduling barrier keeps the loads at the top so they get a full group (2048 cycles) of cover
+    // register double buffer: fetch group g+1 (weights from L2, activations from LDS) before the MFMAs of group g;
+    // the scheduling barrier keeps the loads at the top so they get a full group of MFMA time as cover
     f32x4 an[NOB];
-    float bn[8];
+    float bn[4][RB];
     const int gn = (g + 1 < NG) ? g + 1 : g;
     const f32x4* wn = wp + (size_t)gn * (4 * NOB * 64);
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) an[ob] = wn[ob * 64];
     const float* xg = xb + (size_t)gn * 8 * TILE;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { bn[2 * s] = xg[2 * s * TILE]; bn[2 * s + 1] = xg[2 * s * TILE + 32]; }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) bn[s][rb] = xg[2 * s * TILE + 32 * rb];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob) {
-        acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[2 * s], acc[ob][0], 0, 0, 0);
-        acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[2 * s + 1], acc[ob][1], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[s][rb], acc[ob][rb], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) a[ob] = an[ob];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = bn[i];
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) b[s][rb] = bn[s][rb];
   }
 }
 
@@ -180,15 +194,16 @@ __device__ __forceinline__ float gate(float v, uint32_t bit) {  // bit ? v : +0
   return __uint_as_float(__float_as_uint(v) & (0u - bit));
 }
 
-template <int NOB, bool RELU, bool GATE, bool KEEP = true>
-__device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][2], int row0, int lane, uint32_t (&mask)[4]) {
+template <int NOB, int RB, bool RELU, bool GATE, bool KEEP = true>
+__device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][RB], int row0, int lane, uint32_t (&mask)[4]) {
+  constexpr int TILE = 32 * RB;
   const int h = lane >> 5, j = lane & 31;
   __builtin_amdgcn_sched_barrier(0);  // keep the mask packing here: do not let raw accumulators stay live (spill)
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) {
     uint32_t m = GATE ? mask[ob] : 0u;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -216,69 +231,71 @@ __device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][2],
 }
 
 // ---------------------------------------------------------------------------------------- forward tile
-// Preconditions: S.xyz rows 0..2 hold the 64 points (x row, y row, z row), visible to all threads (barrier done).
-// Returns (every thread, for ray = tid & 63) the pre-tanh output. masks[l] = ReLU bitmasks of layer l.
-// DEBUG_STOP: (test builds only) return right after layer `stop`'s activations are in X.
-template <bool KEEP, bool DEBUG_STOP = false>
+// Preconditions: S.xyz rows 0..2 hold the TILE points (x row, y row, z row), visible to all threads (barrier done).
+// Returns (every thread, for ray = tid & (TILE-1)) the pre-tanh output. masks[l] = ReLU bitmasks of layer l
+// (bit rb*16+r of masks[l][ob]). DEBUG_STOP: (test builds only) return right after layer `stop` is in X.
+template <int RB, bool KEEP, bool DEBUG_STOP = false>
 __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* __restrict__ c0,
-                                             const float* __restrict__ c4, Smem& S, uint32_t (&masks)[8][4],
+                                             const float* __restrict__ c4, Smem<RB>& S, uint32_t (&masks)[8][4],
                                              int stop = 8) {
+  constexpr int TILE = 32 * RB;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int h = lane >> 5;
+  const int ray = tid & (TILE - 1);
   float* X = S.X;
   // layer-0 input rows: xyz + zero padding to K=8
-  X[tid] = (tid < 3 * TILE) ? S.xyz[tid] : 0.f;
-  X[tid + 256] = 0.f;
+#pragma unroll
+  for (int i = tid; i < 8 * TILE; i += NTHREADS) X[i] = (i < 3 * TILE) ? S.xyz[i] : 0.f;
   __syncthreads();
   {
-    f32x16 acc[4][2];
-    acc_init<4>(acc, c0, wave * 128, h);
-    dense<8, 4>(D.Wf[0], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_init<4, RB>(acc, c0, wave * 128, h);
+    dense<8, 4, RB>(D.Wf[0], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[0]);
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[0]);
     __syncthreads();
   }
   if (DEBUG_STOP && stop == 0) return 0.f;
 #pragma unroll
   for (int l = 1; l <= 2; ++l) {
-    f32x16 acc[4][2];
-    acc_init<4>(acc, D.bias[l], wave * 128, h);
-    dense<512, 4>(D.Wf[l], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
+    dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
     __syncthreads();
     if (DEBUG_STOP && stop == l) return 0.f;
   }
   {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
-    f32x16 acc[2][2];
-    acc_init<2>(acc, D.bias[3], wave * 64, h);
-    dense<512, 2>(D.Wf[3], X, acc, wave, lane);
+    f32x16 acc[2][RB];
+    acc_init<2, RB>(acc, D.bias[3], wave * 64, h);
+    dense<512, 2, RB>(D.Wf[3], X, acc, wave, lane);
     __syncthreads();
     masks[3][2] = 0; masks[3][3] = 0;
-    writeback<2, true, false, KEEP>(X, acc, wave * 64, lane, masks[3]);
+    writeback<2, RB, true, false, KEEP>(X, acc, wave * 64, lane, masks[3]);
     __syncthreads();
-    if (tid < 3 * TILE) X[(253 + (tid >> 6)) * TILE + (tid & 63)] = S.xyz[tid];
+    if (tid < 3 * TILE) X[253 * TILE + tid] = S.xyz[tid];
     __syncthreads();
   }
   if (DEBUG_STOP && stop == 3) return 0.f;
   {  // lin4: [x3(253) | xyz(3)] -> 512, latent part folded into c4
-    f32x16 acc[4][2];
-    acc_init<4>(acc, c4, wave * 128, h);
-    dense<256, 4>(D.Wf[4], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_init<4, RB>(acc, c4, wave * 128, h);
+    dense<256, 4, RB>(D.Wf[4], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
     __syncthreads();
   }
   if (DEBUG_STOP && stop == 4) return 0.f;
 #pragma unroll
   for (int l = 5; l <= 7; ++l) {
-    f32x16 acc[4][2];
-    acc_init<4>(acc, D.bias[l], wave * 128, h);
-    dense<512, 4>(D.Wf[l], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
+    dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
     __syncthreads();
     if (DEBUG_STOP && stop == l) return 0.f;
   }
@@ -286,42 +303,49 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
   {
     float p = 0.f;
     const float* w8 = D.w8 + wave * 128;
-    const float* xr = X + (size_t)wave * 128 * TILE + lane;
+    const float* xr = X + (size_t)wave * 128 * TILE + ray;
 #pragma unroll 8
     for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * TILE], p);
-    S.part[wave * TILE + lane] = p;
+    S.part[wave * TILE + ray] = p;   // (RB=1: both half-waves hold the same value)
   }
   __syncthreads();
-  const float pre = ((S.part[lane] + S.part[TILE + lane]) + (S.part[2 * TILE + lane] + S.part[3 * TILE + lane])) + D.b8;
+  const float pre = ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
   return pre;
 }
 
 // ---------------------------------------------------------------------------------------- backward tile
-// Preconditions: mlp_forward just ran on this tile (X = h7, masks filled); S.aux row 0 = d8[ray] = coef*(1-y^2),
-// visible to all threads. On return: S.aux rows 1..3 (wave 0 view after the final barrier) hold
-// d(coef*f)/d xyz per ray; sd0/sd4 (if non-null) receive the row sums over the 64 rays of delta0 / delta4.
+// Preconditions: mlp_forward<RB,true> just ran on this tile (X = h7, masks filled); S.aux row 0 = d8[ray] =
+// coef*(1-y^2), visible to all threads. On return: S.aux rows 1..3 hold d(coef*f)/d xyz per ray; sd0/sd4 (if non-null)
+// receive the row sums over the TILE rays of delta0 / delta4.
+template <int RB>
 __device__ __forceinline__ void row_sums(const float* X, float* __restrict__ dst, int tid) {
+  constexpr int TILE = 32 * RB;
   const int lane = tid & 63;
 #pragma unroll 1
   for (int rr = 0; rr < 2; ++rr) {
     const int row = tid + rr * 256;
     float s = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < TILE; ++i) s += X[row * TILE + ((i + lane) & 63)];
+    for (int i = 0; i < TILE; ++i) s += X[row * TILE + ((i + lane) & (TILE - 1))];   // rotated: conflict-free
     dst[row] = s;
   }
 }
 
-__device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem& S, uint32_t (&masks)[8][4],
+template <int RB>
+__device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, uint32_t (&masks)[8][4],
                                              float* __restrict__ sd0, float* __restrict__ sd4) {
+  constexpr int TILE = 32 * RB;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int h = lane >> 5, j = lane & 31;
+  const int ray = tid & (TILE - 1);
   float* X = S.X;
   // delta7[k][ray] = relu'(h7) * w8[k] * d8[ray]
   {
-    const float d8a = S.aux[j], d8b = S.aux[32 + j];
+    float d8[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) d8[rb] = S.aux[32 * rb + j];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
       const uint32_t m = masks[7][ob];
@@ -329,60 +353,59 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem& S, uint3
       for (int r = 0; r < 16; ++r) {
         const int row = wave * 128 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float w = D.w8[row];
-        X[row * TILE + j] = gate(w * d8a, (m >> r) & 1u);
-        X[row * TILE + 32 + j] = gate(w * d8b, (m >> (16 + r)) & 1u);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) X[row * TILE + 32 * rb + j] = gate(w * d8[rb], (m >> (16 * rb + r)) & 1u);
       }
     }
   }
   __syncthreads();
 #pragma unroll
   for (int l = 7; l >= 5; --l) {  // delta_l (512) -> delta_{l-1} (512)
-    f32x16 acc[4][2];
-    acc_zero<4>(acc);
-    dense<512, 4>(D.Wb[l], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_zero<4, RB>(acc);
+    dense<512, 4, RB>(D.Wb[l], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+    writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
     __syncthreads();
   }
-  if (sd4) row_sums(X, sd4, tid);  // X = delta4
+  if (sd4) row_sums<RB>(X, sd4, tid);  // X = delta4
   {  // lin4^T: delta4 (512) -> [delta3 (253) | d xyz (3)]
-    f32x16 acc[2][2];
-    acc_zero<2>(acc);
-    dense<512, 2>(D.Wb[4], X, acc, wave, lane);
+    f32x16 acc[2][RB];
+    acc_zero<2, RB>(acc);
+    dense<512, 2, RB>(D.Wb[4], X, acc, wave, lane);
     __syncthreads();
-    writeback<2, false, true>(X, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
+    writeback<2, RB, false, true>(X, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
     if (wave == 3 && h == 1) {
 #pragma unroll
-      for (int r = 13; r < 16; ++r) {
-        S.aux[(1 + r - 13) * TILE + j] = acc[1][0][r];
-        S.aux[(1 + r - 13) * TILE + 32 + j] = acc[1][1][r];
-      }
+      for (int r = 13; r < 16; ++r)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) S.aux[(1 + r - 13) * TILE + 32 * rb + j] = acc[1][rb][r];
     }
     __syncthreads();
   }
   {  // lin3^T: delta3 (256 rows, 253 real) -> delta2 (512)
-    f32x16 acc[4][2];
-    acc_zero<4>(acc);
-    dense<256, 4>(D.Wb[3], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_zero<4, RB>(acc);
+    dense<256, 4, RB>(D.Wb[3], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, false, true>(X, acc, wave * 128, lane, masks[2]);
+    writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[2]);
     __syncthreads();
   }
 #pragma unroll
   for (int l = 2; l >= 1; --l) {
-    f32x16 acc[4][2];
-    acc_zero<4>(acc);
-    dense<512, 4>(D.Wb[l], X, acc, wave, lane);
+    f32x16 acc[4][RB];
+    acc_zero<4, RB>(acc);
+    dense<512, 4, RB>(D.Wb[l], X, acc, wave, lane);
     __syncthreads();
-    writeback<4, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+    writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
     __syncthreads();
   }
-  if (sd0) row_sums(X, sd0, tid);  // X = delta0
+  if (sd0) row_sums<RB>(X, sd0, tid);  // X = delta0
   // d xyz through lin0's xyz columns: 3 x four 128-long chains per ray
   {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     const float* wx = D.W0x + wave * 128;
-    const float* xr = X + (size_t)wave * 128 * TILE + lane;
+    const float* xr = X + (size_t)wave * 128 * TILE + ray;
 #pragma unroll 4
     for (int k = 0; k < 128; ++k) {
       const float d = xr[k * TILE];
@@ -390,13 +413,13 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem& S, uint3
       p1 = __builtin_fmaf(wx[HID + k], d, p1);
       p2 = __builtin_fmaf(wx[2 * HID + k], d, p2);
     }
-    S.part[(0 * 4 + wave) * TILE + lane] = p0;
-    S.part[(1 * 4 + wave) * TILE + lane] = p1;
-    S.part[(2 * 4 + wave) * TILE + lane] = p2;
+    S.part[(0 * 4 + wave) * TILE + ray] = p0;
+    S.part[(1 * 4 + wave) * TILE + ray] = p1;
+    S.part[(2 * 4 + wave) * TILE + ray] = p2;
   }
   __syncthreads();
   if (tid < 3 * TILE) {
-    const int c = tid >> 6, r = tid & 63;
+    const int c = tid / TILE, r = tid % TILE;
     const float* p = S.part + c * 4 * TILE + r;
     S.aux[(1 + c) * TILE + r] = S.aux[(1 + c) * TILE + r] + ((p[0] + p[TILE]) + (p[2 * TILE] + p[3 * TILE]));
   }
