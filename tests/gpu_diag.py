@@ -124,6 +124,28 @@ def main():
         print('mlp_grad %d pts: %.3f ms -> %.1f TFLOP/s (fwd+bwd dX = 2x flops)' % (n, ms, 2 * 3146752 * n / ms / 1e9))
     thr()
 
+    @stage('cumulative per-layer time (262144 points, 64-ray tiles): layer l - layer l-1 = cost of layer l incl. overheads')
+    def layer_times():
+        n = 512 * 512
+        p = torch.rand(n, 3, device='cuda') * 1.6 - 0.8
+        prev = None
+        for layer in range(8):
+            for _ in range(2):
+                functions.debug_mlp_layer(eng, lat_t, p, layer)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                functions.debug_mlp_layer(eng, lat_t, p, layer)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            mac = {0: 8 * 512, 1: 512 * 512, 2: 512 * 512, 3: 512 * 256, 4: 256 * 512, 5: 512 * 512, 6: 512 * 512, 7: 512 * 512}[layer]
+            ideal = 2.0 * mac * n / 157.3e12 * 1e3
+            print('  up to layer %d: %.3f ms (delta %.3f ms, MFMA-ideal for this layer %.3f ms)' % (layer, ms, ms - (prev or 0), ideal))
+            prev = ms
+    layer_times()
+
     @stage('C3 fwd/bwd timing')
     def c3():
         H = W = 512
