@@ -512,9 +512,27 @@ int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz,
   LAUNCH_CHECK("k_latent_consts");
   const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
   const int TILE = 32 * rb_dense;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
-  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D);
+  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D, (long long*)nullptr);
+  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D, (long long*)nullptr);
   LAUNCH_CHECK("k_debug_layer");
+  return DISTR_OK;
+}
+
+int distr_debug_tile_timing(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float* sdf_out, long long* ts_out,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n <= 0 || !xyz || !sdf_out || !ts_out || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
+  LAUNCH_CHECK("k_latent_consts");
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
+  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, 8, sdf_out, ctx->D, ts_out);
+  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, 8, sdf_out, ctx->D, ts_out);
+  LAUNCH_CHECK("k_debug_layer<timing>");
   return DISTR_OK;
 }
 

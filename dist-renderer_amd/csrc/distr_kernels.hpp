@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
 // test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
 template <int RB>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer,
-                                                                        float* out, DecoderDev D) {
+                                                                        float* out, DecoderDev D, long long* ts_out) {
   constexpr int TILE = 32 * RB;
   __shared__ Smem<RB> S;
   const int tid = threadIdx.x;
@@ -444,7 +444,13 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const fl
   }
   __syncthreads();
   uint32_t masks[8][4];
-  mlp_forward<RB, false, true>(D, c0c4, c0c4 + HID, S, masks, layer);
+  long long* ts = ts_out ? ts_out + (size_t)blockIdx.x * 40 : nullptr;
+  const float pre = mlp_forward<RB, false, true>(D, c0c4, c0c4 + HID, S, masks, layer, ts);
+  if (ts_out) {   // timing mode: whole forward, no activation dump
+    if (tid == 0) { ts[36] = (long long)__builtin_readcyclecounter(); ts[37] = (long long)wall_clock64(); }
+    if (tid < TILE && base + tid < n) out[base + tid] = tanh_spec(pre);
+    return;
+  }
   __syncthreads();
   for (int i = tid; i < HID * TILE; i += 256) {
     const int f = i / TILE, ray = i % TILE;

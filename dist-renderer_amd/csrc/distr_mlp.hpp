@@ -237,8 +237,11 @@ __device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][RB]
 template <int RB, bool KEEP, bool DEBUG_STOP = false>
 __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* __restrict__ c0,
                                              const float* __restrict__ c4, Smem<RB>& S, uint32_t (&masks)[8][4],
-                                             int stop = 8) {
+                                             int stop = 8, long long* ts = nullptr) {
   constexpr int TILE = 32 * RB;
+  // test builds: shader-clock / wall-clock stamps of wave 0 at phase boundaries (ts[2i], ts[2i+1])
+#define DISTR_TS(i) do { if (DEBUG_STOP && ts && threadIdx.x == 0) { ts[2 * (i)] = (long long)__builtin_readcyclecounter(); ts[2 * (i) + 1] = (long long)wall_clock64(); } } while (0)
+  DISTR_TS(0);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -253,9 +256,11 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     f32x16 acc[4][RB];
     acc_init<4, RB>(acc, c0, wave * 128, h);
     dense<8, 4, RB>(D.Wf[0], X, acc, wave, lane);
+    DISTR_TS(1);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[0]);
     __syncthreads();
+    DISTR_TS(2);
   }
   if (DEBUG_STOP && stop == 0) return 0.f;
 #pragma unroll
@@ -263,30 +268,36 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     f32x16 acc[4][RB];
     acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
     dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
+    DISTR_TS(2 * l + 1);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
     __syncthreads();
+    DISTR_TS(2 * l + 2);
     if (DEBUG_STOP && stop == l) return 0.f;
   }
   {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
     f32x16 acc[2][RB];
     acc_init<2, RB>(acc, D.bias[3], wave * 64, h);
     dense<512, 2, RB>(D.Wf[3], X, acc, wave, lane);
+    DISTR_TS(7);
     __syncthreads();
     masks[3][2] = 0; masks[3][3] = 0;
     writeback<2, RB, true, false, KEEP>(X, acc, wave * 64, lane, masks[3]);
     __syncthreads();
     if (tid < 3 * TILE) X[253 * TILE + tid] = S.xyz[tid];
     __syncthreads();
+    DISTR_TS(8);
   }
   if (DEBUG_STOP && stop == 3) return 0.f;
   {  // lin4: [x3(253) | xyz(3)] -> 512, latent part folded into c4
     f32x16 acc[4][RB];
     acc_init<4, RB>(acc, c4, wave * 128, h);
     dense<256, 4, RB>(D.Wf[4], X, acc, wave, lane);
+    DISTR_TS(9);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
     __syncthreads();
+    DISTR_TS(10);
   }
   if (DEBUG_STOP && stop == 4) return 0.f;
 #pragma unroll
@@ -294,9 +305,11 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     f32x16 acc[4][RB];
     acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
     dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
+    DISTR_TS(2 * l + 1);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
     __syncthreads();
+    DISTR_TS(2 * l + 2);
     if (DEBUG_STOP && stop == l) return 0.f;
   }
   // lin8: four 128-long chains per ray (one per wave), combined in fixed order
@@ -310,6 +323,8 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
   }
   __syncthreads();
   const float pre = ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+  DISTR_TS(17);
+#undef DISTR_TS
   return pre;
 }
 

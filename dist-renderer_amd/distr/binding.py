@@ -19,7 +19,7 @@ MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
 EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
            'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
-           'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer']
+           'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing']
 
 
 class DistrError(RuntimeError):
@@ -100,6 +100,7 @@ def lib():
             L.distr_mlp_eval.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
             L.distr_mlp_grad.argtypes = [vp, fp, fp, C.c_int64, fp, fp, vp, C.c_size_t, vp]
             L.distr_debug_mlp_layer.argtypes = [vp, fp, fp, C.c_int64, C.c_int, fp, vp, C.c_size_t, vp]
+            L.distr_debug_tile_timing.argtypes = [vp, fp, fp, C.c_int64, fp, vp, vp, C.c_size_t, vp]
             L.distr_get_render_stats.argtypes = [vp, C.POINTER(RenderCfg), vp, C.POINTER(RenderStats), vp]
             L.distr_profile_enable.argtypes = [vp, C.c_int]
             L.distr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), vp]

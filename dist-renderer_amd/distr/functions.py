@@ -169,3 +169,19 @@ def debug_mlp_layer(engine, latent, points, layer):
     engine.ctx.check(engine.ctx.L.distr_debug_mlp_layer(engine.ctx.h, p(lat), p(x), n, int(layer), p(out), p(ws), ws.numel(),
                                                        engine.ctx.stream()))
     return out
+
+
+def debug_tile_timing(engine, latent, points, tile):
+    """Test aid: (sdf (n,), stamps (tiles, 20, 2) int64 [shader clock, 100 MHz wall clock]) of the decoder tile phases."""
+    dev = engine.device
+    lat = _f32c(latent, dev).reshape(-1)
+    x = _f32c(points, dev).reshape(-1, 3)
+    n = x.shape[0]
+    tiles = (n + tile - 1) // tile
+    sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    ts = torch.zeros(tiles, 20, 2, dtype=torch.int64, device=dev)
+    ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_debug_tile_timing(engine.ctx.h, p(lat), p(x), n, p(sdf), p(ts), p(ws), ws.numel(),
+                                                         engine.ctx.stream()))
+    return sdf, ts

@@ -136,6 +136,12 @@ int distr_mlp_grad(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev
 int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, int layer,
                           float* out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Test aid: in-kernel phase timing of the decoder tile. ts_dev[tile][40] (int64) receives (shader-clock, 100 MHz wall
+ * clock) stamp pairs of wave 0: [0] entry, [2l+1] after layer l's MFMA loop, [2l+2] after its write-back + barriers
+ * (l = 0..7), [17] after lin8, [18] kernel end; sdf_dev[n] receives the decoder output. */
+int distr_debug_tile_timing(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float* sdf_dev,
+                            long long* ts_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Debug / measurement. distr_get_render_stats copies the counters of the forward (and last backward) that used
  * `ws_dev` device->host and synchronises `stream`.
  * Profiling: when enabled, every launch of the fused march/MLP kernel is bracketed by hipEvents on the launch

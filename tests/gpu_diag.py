@@ -146,6 +146,29 @@ def main():
             prev = ms
     layer_times()
 
+    @stage('in-kernel phase timing of the decoder tile (wave 0 of each workgroup)')
+    def phases():
+        import os as _os
+        tile = 32 if _os.environ.get('DISTR_TILE_RB') == '1' else 64
+        for n, label in ((512 * 512, 'dense: 4096 tiles of 64'), (tile * 200, '200 tiles (chip mostly idle)')):
+            p = torch.rand(n, 3, device='cuda') * 1.6 - 0.8
+            functions.debug_tile_timing(eng, lat_t, p, tile)
+            sdf, ts = functions.debug_tile_timing(eng, lat_t, p, tile)
+            torch.cuda.synchronize()
+            ref = functions.mlp_eval(eng, lat_t, p).reshape(-1)
+            print('  [%s] sdf equal to mlp_eval: %s' % (label, bool((sdf == ref).all())))
+            t = ts.cpu().numpy().astype(np.float64)
+            cyc, wall = t[:, :, 0], t[:, :, 1]
+            tot_c, tot_w = cyc[:, 18] - cyc[:, 0], (wall[:, 18] - wall[:, 0]) * 10.0   # wall: 100 MHz -> ns
+            print('  [%s] tile total: %.0f cycles, %.1f us  -> shader clock %.3f GHz' % (label, np.median(tot_c), np.median(tot_w) / 1e3, np.median(tot_c / tot_w)))
+            names = ['L0 mfma', 'L0 wb', 'L1 mfma', 'L1 wb', 'L2 mfma', 'L2 wb', 'L3 mfma', 'L3 wb', 'L4 mfma', 'L4 wb', 'L5 mfma', 'L5 wb',
+                     'L6 mfma', 'L6 wb', 'L7 mfma', 'L7 wb', 'L8', 'tail']
+            d = np.diff(cyc[:, :19], axis=1)
+            print('   ' + ' | '.join('%s %.0f' % (nm, np.median(d[:, i])) for i, nm in enumerate(names)))
+            mf = sum(np.median(d[:, i]) for i in range(0, 16, 2)); wb = sum(np.median(d[:, i]) for i in range(1, 16, 2))
+            print('   sum mfma-loop phases %.0f (ideal 787456 at 64 cyc/MFMA for 64-ray tiles), write-back+barrier phases %.0f, L8+tail %.0f' % (mf, wb, np.median(d[:, 16]) + np.median(d[:, 17])))
+    phases()
+
     @stage('C3 fwd/bwd timing')
     def c3():
         H = W = 512
