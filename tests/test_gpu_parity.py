@@ -262,3 +262,37 @@ def test_dropin_api_with_module(fixture_decoder):
     assert len(out) == 9
     out[0].backward()
     assert lat2.grad is not None and torch.isfinite(lat2.grad).all()
+
+
+SWEEP = [
+    # (H, W, march_step, bs, ratio, marcher, d2n, camera(az,el,dist,roll), extra kwargs)
+    (33, 47, 14, 1, 1.5, 'recursive', False, (12, -8, 1.7, 5), {}),
+    (40, 40, 18, 5, 1.0, 'trivial', True, (-60, 30, 1.5, 0), {}),
+    (50, 70, 30, 8, 1.5, 'pyramid_recursive', False, (0, 0, 1.6, 0), {}),
+    (64, 48, 25, 3, 2.0, 'pyramid_recursive', True, (100, 45, 1.4, -20), dict(coarse_steps=(2, 4))),
+    (36, 36, 16, 3, 1.5, 'recursive', False, (20, 10, 1.6, 0), dict(use_transform=False)),
+    (36, 36, 16, 3, 1.5, 'pyramid_recursive', False, (20, 10, 1.6, 0), dict(grad_camera=False)),
+    (36, 36, 16, 3, 1.5, 'recursive', True, (20, 10, 1.6, 0), dict(grad_depth=False)),
+    (36, 36, 16, 3, 1.5, 'pyramid_recursive', True, (20, 10, 1.6, 0), dict(grad_mask=False)),
+    (36, 36, 16, 2, 1.5, 'recursive', False, (20, 10, 1.6, 0), dict(normalize_normal=False)),
+    (36, 36, 16, 3, 1.5, 'pyramid_recursive', False, (20, 10, 1.6, 0), dict(threshold=1e-3, clamp_dist=0.05, radius=0.9)),
+    (36, 36, 16, 3, 1.5, 'trivial', False, (20, 10, 1.6, 0),
+     dict(transform_matrix=np.array([[0., 1., 0.], [1., 0., 0.], [0., 0., -1.]]))),
+]
+
+
+@pytest.mark.parametrize('case', range(len(SWEEP)))
+def test_option_sweep_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, case):
+    """Less-travelled options (odd sizes, buffer_size 1..8, ratios, coarse step lists, no_grad_* flags, use_transform,
+    custom transform_matrix, radius/threshold/clamp) -- HIP vs oracle, same bars as C1."""
+    from distr import fixture
+    H, W, S, bs, ratio, marcher, d2n, cam, extra = SWEEP[case]
+    _, _, latent = fixture_decoder
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(*cam)
+    kw = dict(march_step=S, buffer_size=bs, ratio=ratio, marcher=marcher, use_depth2normal=d2n)
+    kw.update(extra)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=2e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0, res
