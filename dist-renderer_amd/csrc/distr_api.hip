@@ -25,6 +25,7 @@ struct distr_ctx {
   bool profiling = false;
   int tile_rb = 0;           // 0: hybrid (64-ray tiles, 32-ray tiles once few rays are live); 1 / 2: force 32 / 64-ray tiles
   int hybrid_threshold = 8192;  // live-ray count below which a march step runs on 32-ray tiles
+  bool save_masks = true;       // save ReLU masks in the forward so that the backward skips the decoder recompute
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
 };
@@ -82,12 +83,13 @@ struct Carver {
 
 int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (!c) return fail(ctx, DISTR_ERR_INVALID_ARG, "cfg is null");
-  if (c->H < 1 || c->W < 1 || (int64_t)c->H * c->W >= (1 << 28)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", c->H, c->W);
+  if (c->H < 1 || c->W < 1 || (int64_t)c->H * c->W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", c->H, c->W);
   if (c->buffer_size < 1 || c->buffer_size > MAX_BS) return fail(ctx, DISTR_ERR_UNSUPPORTED, "buffer_size %d not in [1,%d]", c->buffer_size, MAX_BS);
   if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
   int fine = c->march_step;
   if (c->marcher == DISTR_MARCH_PYRAMID_RECURSIVE) {
     if (c->coarse_steps[0] < 1 || c->coarse_steps[1] < 1) return fail(ctx, DISTR_ERR_UNSUPPORTED, "pyramid needs >=1 step per coarse level");
+    if (c->coarse_steps[0] > 15 || c->coarse_steps[1] > 15) return fail(ctx, DISTR_ERR_UNSUPPORTED, "at most 15 steps per coarse level");
     fine -= c->coarse_steps[0] + c->coarse_steps[1];
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
@@ -96,7 +98,7 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
 }
 
 // Lays the forward workspace out; with base==nullptr only sizes are computed.
-size_t make_view(const distr_render_cfg& c, void* base, View& V) {
+size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks) {
   Carver cv(base);
   memset(&V, 0, sizeof(V));
   V.cfg = c;
@@ -133,9 +135,18 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V) {
   V.minabs = cv.take<float>(P); V.first_sdf = cv.take<float>(P);
   V.tk_s = cv.take<float>(bs * P); V.tk_zb = cv.take<float>(bs * P); V.tk_za = cv.take<float>(bs * P);
   V.tk_src = cv.take<int32_t>(bs * P);
+  V.tk_slot = cv.take<int32_t>(bs * P);
   V.zdepth_s = cv.take<float>(P); V.depth_pre = cv.take<float>(P); V.nrm_t = cv.take<float>(3 * P);
   V.mask_s = cv.take<uint8_t>(P);
   V.nlist = cv.take<int32_t>(P); V.n_sdf = cv.take<float>(P); V.n_g = cv.take<float>(3 * P);
+  V.save_masks = (save_masks && c.save_for_backward && (c.grad_depth || c.grad_mask)) ? 1 : 0;
+  if (V.save_masks) {
+    V.mfine = (int64_t)P * (bs + 1);
+    int64_t off = 0;
+    for (int l = 1; l < V.nlev; ++l) { V.moff[l] = off; off += (int64_t)V.lv[l].steps * V.lv[l].n; }
+    V.morigin = V.mfine + off;
+    V.mstore = cv.take<uint4>((size_t)(V.morigin + 1) * 32);
+  }
   return (cv.off + 255) & ~(size_t)255;
 }
 
@@ -180,6 +191,7 @@ int distr_create(distr_ctx** out, int hip_device) {
   if (const char* e = getenv("DISTR_TILE_RB")) ctx->tile_rb = atoi(e);
   if (ctx->tile_rb < 0 || ctx->tile_rb > 2) ctx->tile_rb = 0;
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
+  if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || hip_device < 0 || hip_device >= n) {
@@ -277,7 +289,7 @@ int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* f
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
   View V;
-  if (fwd) *fwd = make_view(*cfg, nullptr, V);
+  if (fwd) *fwd = make_view(*cfg, nullptr, V, ctx->save_masks);
   if (bwd) *bwd = bwd_bytes(*cfg);
   return DISTR_OK;
 }
@@ -291,7 +303,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   if (rc) return rc;
   if (!latent || !R || !T || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
   View V;
-  const size_t need = make_view(*cfg, ws, V);
+  const size_t need = make_view(*cfg, ws, V, ctx->save_masks);
   if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const DecoderDev& D = ctx->D;
@@ -319,8 +331,13 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       origin_done = true;
       const unsigned tiles = (unsigned)((V.lv[l].n + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
       timer.begin();
-      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-      else hipLaunchKernelGGL((k_march<MODE_COARSE, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      if (V.save_masks) {
+        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      } else {
+        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      }
       timer.end();
       LAUNCH_CHECK("k_march<coarse>");
     }
@@ -334,13 +351,19 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     const bool hybrid = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
     timer.begin();
     A.count_lo = hybrid ? ctx->hybrid_threshold : 0; A.count_hi = 0x7fffffff;
-    if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-    else hipLaunchKernelGGL((k_march<MODE_FINE, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    if (V.save_masks) {
+      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    } else {
+      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+    }
     if (hybrid) {  // the same step on 32-ray tiles (two workgroups per CU) when fewer than `hybrid_threshold` rays are live
       MarchArgs A1 = A;
       A1.count_lo = 0; A1.count_hi = ctx->hybrid_threshold; A1.origin_tile = 0;
       const unsigned t1 = (unsigned)((std::min(P, ctx->hybrid_threshold) + 31) / 32);
-      hipLaunchKernelGGL((k_march<MODE_FINE, 1>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
+      if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
+      else hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
     }
     timer.end();
     LAUNCH_CHECK("k_march<fine>");
@@ -383,8 +406,9 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
   if (!ws || !ws_bwd) return fail(ctx, DISTR_ERR_INVALID_ARG, "null workspace");
+  if (!cfg->save_for_backward) return fail(ctx, DISTR_ERR_INVALID_ARG, "forward was run with save_for_backward=0");
   View V;
-  const size_t need = make_view(*cfg, const_cast<void*>(ws), V);
+  const size_t need = make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks);
   if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
   if (ws_bwd_bytes < bwd_bytes(*cfg)) return fail(ctx, DISTR_ERR_WORKSPACE, "backward workspace too small: %zu < %zu", ws_bwd_bytes, bwd_bytes(*cfg));
   hipStream_t s = (hipStream_t)stream;
@@ -407,8 +431,13 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_FULL, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
-  else hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  if (V.save_masks) {
+    if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+    else hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  } else {
+    if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_FULL, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+    else hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
+  }
   LAUNCH_CHECK("k_bwd<full>");
   const int chunk = 64;
   hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, (tiles + chunk - 1) / chunk), dim3(256), 0, s, V,
@@ -427,7 +456,7 @@ int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float
   if (rc) return rc;
   if (!latent || !R || !T || !zdepth || !mask || !normal3xP || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
   View V;
-  const size_t need = make_view(*cfg, ws, V);
+  const size_t need = make_view(*cfg, ws, V, ctx->save_masks);
   if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const DecoderDev& D = ctx->D;
@@ -471,8 +500,8 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
   const int TILE = 32 * rb_dense;
   timer.begin();
-  if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
-  else hipLaunchKernelGGL((k_march<MODE_EVAL, 2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  else hipLaunchKernelGGL((k_march<MODE_EVAL, 2, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
   timer.end();
   LAUNCH_CHECK("k_march<eval>");
   return DISTR_OK;
@@ -541,7 +570,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
   View V;
-  make_view(*cfg, const_cast<void*>(ws), V);
+  make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks);
   hipStream_t s = (hipStream_t)stream;
   static thread_local std::vector<char> hostbuf;
   hostbuf.resize(sizeof(Consts));

@@ -57,14 +57,27 @@ struct View {
   int32_t* live[2];
   float *m, *init_now, *maxbound, *minabs, *first_sdf;
   float *tk_s, *tk_zb, *tk_za;   // [bs][P] selected rows: sdf, depth before, depth after (pyramid) / marching depth after
-  int32_t* tk_src;               // [bs][P] (level<<28 | ray) or -1 for a padded row
+  int32_t* tk_src;               // [bs][P] row source (see src_* helpers) or -1 for a padded row
+  int32_t* tk_slot;              // [bs][P] physical ReLU-mask slot (0..bs) of the entry
+  // ReLU masks saved for the backward pass: one 512-byte block (8 layers x 512 bits) per kept row.
+  //   block = px*(bs+1) + slot                      rows of the full-resolution march
+  //   block = mfine + moff[lvl] + step*n_lvl + ray  rows of the coarse pyramid levels
+  uint4* mstore;
+  int64_t mfine, moff[3], morigin;   // morigin: block of f(origin) (sample point of padded rows)
+  int32_t save_masks;
   float *zdepth_s, *depth_pre, *nrm_t;
   uint8_t* mask_s;
   int32_t* nlist;
   float *n_sdf, *n_g;
 };
 
-struct Sample { int32_t src; float zb; float coef; int32_t flags; };
+struct Sample { int32_t src; float zb; float coef; int32_t flags; float sdf; int32_t mblock; int32_t pad0, pad1; };
+
+// row source encoding: fine rows (level 0): pixel id (< 2^28); coarse rows: level<<28 | step<<24 | ray (< 2^24)
+__device__ __forceinline__ int32_t src_coarse(int lvl, int step, int ray) { return (lvl << 28) | (step << 24) | ray; }
+__device__ __forceinline__ int src_level(int32_t src) { return src >> 28; }
+__device__ __forceinline__ int src_ray(int32_t src) { return (src >> 28) ? (src & 0x00ffffff) : (src & 0x0fffffff); }
+__device__ __forceinline__ int src_step(int32_t src) { return (src >> 24) & 15; }
 
 // ------------------------------------------------------------------------------------------ geometry
 struct RayGeo { float d[3], r[3], hx, hy, hz, rn, calib; };
@@ -241,7 +254,7 @@ __global__ void __launch_bounds__(256) k_coarse_init(View V, int lvl) {
 }
 
 // selected-row buffer: bs entries sorted by |sdf| ascending, earlier row wins ties (renderer.py:314-318 topk)
-__device__ __forceinline__ void topk_insert(const View& V, int px, float s, float zb, float za, int32_t src) {
+__device__ __forceinline__ int topk_insert(const View& V, int px, float s, float zb, float za, int32_t src) {
   const int bs = V.cfg.buffer_size;
   const size_t P = (size_t)V.P;
   const float key = fabsf(s);
@@ -250,17 +263,24 @@ __device__ __forceinline__ void topk_insert(const View& V, int px, float s, floa
     const float sk = V.tk_s[k * P + px];
     if (key < fabsf(sk)) pos = k; else break;
   }
-  if (pos >= bs) return;
+  if (pos >= bs) return -1;
+  // the new row takes the free mask slot (the one of {0..bs} no entry uses); the evicted entry's slot becomes free
+  int used = 0;
+  for (int k = 0; k < bs; ++k) used += V.tk_slot[k * P + px];
+  const int free_slot = bs * (bs + 1) / 2 - used;
   for (int k = bs - 1; k > pos; --k) {
     V.tk_s[k * P + px] = V.tk_s[(k - 1) * P + px];
     V.tk_zb[k * P + px] = V.tk_zb[(k - 1) * P + px];
     V.tk_za[k * P + px] = V.tk_za[(k - 1) * P + px];
     V.tk_src[k * P + px] = V.tk_src[(k - 1) * P + px];
+    V.tk_slot[k * P + px] = V.tk_slot[(k - 1) * P + px];
   }
   V.tk_s[pos * P + px] = s;
   V.tk_zb[pos * P + px] = zb;
   V.tk_za[pos * P + px] = za;
   V.tk_src[pos * P + px] = src;
+  V.tk_slot[pos * P + px] = free_slot;
+  return free_slot;
 }
 
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
@@ -291,6 +311,7 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
       V.tk_zb[k * P + px] = 0.f;
       V.tk_za[k * P + px] = V.pyramid ? init_now : 0.f;
       V.tk_src[k * P + px] = -1;
+      V.tk_slot[k * P + px] = k;
     }
     if (V.pyramid) {
       for (int lvl = V.nlev - 1; lvl >= 1; --lvl) {
@@ -298,7 +319,7 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
         const int par = (y >> lvl) * Lc.w + (x >> lvl);
         for (int st = 0; st < Lc.steps; ++st) {
           const size_t o = (size_t)st * Lc.n + par;
-          topk_insert(V, px, Lc.rs[o], Lc.rzb[o], Lc.rza[o], (lvl << 28) | par);
+          topk_insert(V, px, Lc.rs[o], Lc.rzb[o], Lc.rza[o], src_coarse(lvl, st, par));
         }
       }
     }
@@ -331,7 +352,9 @@ struct MarchArgs {
   int32_t count_lo, count_hi;  // MODE_FINE: this launch only runs if count_lo <= live count < count_hi (tile-size hybrid)
 };
 
-template <int MODE, int RB>
+// KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
+// that the backward pass does not have to recompute the decoder forward (View::mstore).
+template <int MODE, int RB, bool KEEP>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
   constexpr int TILE = 32 * RB;
   __shared__ Smem<RB> S;
@@ -389,44 +412,61 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
   uint32_t masks[8][4];
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward<RB, false>(D, c0, c4, S, masks);
+  const float pre = mlp_forward<RB, KEEP>(D, c0, c4, S, masks);
 
-  if (tid >= 64) return;  // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
-  const float s = tanh_spec(pre);
-  if (origin) { if (tid == 0) V.C->f_origin = s; return; }
-
-  if (MODE == MODE_EVAL) {
-    if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
-    return;
-  }
-  const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
-  if (MODE == MODE_COARSE) {
-    if (valid) {
-      const LevelView& L = V.lv[A.lvl];
-      const float mn = L.cm[id] + clampf(s, -cd, cd) * ratio;
-      L.cm[id] = mn;
-      const size_t o = (size_t)A.step * L.n + id;
-      L.rs[o] = s;
-      L.rzb[o] = zd;
-      L.rza[o] = mn + L.cinit[id];
+  // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
+  int64_t mblock = -1;   // mask block this ray's row goes to (KEEP), -1: row not kept
+  if (tid < 64) {
+    const float s = tanh_spec(pre);
+    if (origin) {
+      if (tid == 0) V.C->f_origin = s;
+    } else if (MODE == MODE_EVAL) {
+      if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
+    } else {
+      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+      if (MODE == MODE_COARSE) {
+        if (valid) {
+          const LevelView& L = V.lv[A.lvl];
+          const float mn = L.cm[id] + clampf(s, -cd, cd) * ratio;
+          L.cm[id] = mn;
+          const size_t o = (size_t)A.step * L.n + id;
+          L.rs[o] = s;
+          L.rzb[o] = zd;
+          L.rza[o] = mn + L.cinit[id];
+          mblock = V.mfine + V.moff[A.lvl] + (int64_t)o;
+        }
+      } else {  // MODE_FINE
+        bool stay = false;
+        if (valid) {
+          const float init_now = V.init_now[id];
+          const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
+          V.m[id] = mn;
+          const float za = mn + init_now;
+          const int slot = topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
+          if (slot >= 0) mblock = (int64_t)id * (V.cfg.buffer_size + 1) + slot;
+          const float a = fabsf(s);
+          if (a < V.minabs[id]) V.minabs[id] = a;
+          if (A.step == 0) V.first_sdf[id] = s;
+          stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+        }
+        if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
+          wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
+      }
     }
-    return;
   }
-  // MODE_FINE
-  bool stay = false;
-  if (valid) {
-    const float init_now = V.init_now[id];
-    const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
-    V.m[id] = mn;
-    const float za = mn + init_now;
-    topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
-    const float a = fabsf(s);
-    if (a < V.minabs[id]) V.minabs[id] = a;
-    if (A.step == 0) V.first_sdf[id] = s;
-    stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+  if (KEEP && MODE != MODE_EVAL) {
+    // hand every wave the mask-block index of each ray, then each lane stores the 64-byte chunks it owns
+    long long* mb = reinterpret_cast<long long*>(S.aux);    // 8*TILE bytes; aux is not used by the forward tile
+    if (tid < TILE) mb[tid] = origin ? (tid == 0 ? (long long)V.morigin : -1ll) : mblock;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const long long b = mb[32 * rb + (lane & 31)];
+      if (b >= 0) store_mask_chunk<RB>(V.mstore + (size_t)b * 32, masks, rb, wave, lane >> 5);
+    }
   }
-  if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
-    wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
 }
 
 // test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
@@ -545,7 +585,7 @@ __global__ void __launch_bounds__(256) k_depth2normal(View V, float* depth, floa
 // (dX chain with transposed weight fragments), and emits per tile: sum_n delta0, sum_n delta4 (for the shared-latent
 // gradient, multiplied once by W_lat^T afterwards) and the camera-gradient partials; or, in POINTGRAD mode, the
 // per-point sdf and d f/d xyz (decode_sdf_gradient, core/utils/decoder_utils.py:76-92).
-enum { BWD_FULL = 0, BWD_POINTGRAD = 1 };
+enum { BWD_FULL = 0, BWD_POINTGRAD = 1, BWD_SAVED = 2 };   // SAVED: masks come from View::mstore, no forward recompute
 
 struct BwdArgs {
   View V;
@@ -578,45 +618,70 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
   const int64_t base = (int64_t)tile * TILE;
   if (base >= count) return;
 
-  Sample sm; sm.src = -1; sm.zb = 0.f; sm.coef = 0.f; sm.flags = 0;
+  Sample sm; sm.src = -1; sm.zb = 0.f; sm.coef = 0.f; sm.flags = 0; sm.sdf = 0.f; sm.mblock = -1;
   bool valid = false;
   int64_t r = 0;
-  if (tid < TILE) {
-    float p[3] = {0.f, 0.f, 0.f};
-    r = base + tid;
-    valid = r < count;
-    if (valid) {
-      if (MODE == BWD_POINTGRAD && A.xyz) {
-        p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
-        sm.coef = 1.0f;
-      } else {
-        if (MODE == BWD_POINTGRAD) { sm.src = A.pix_list[r]; sm.zb = A.zdepth[sm.src]; sm.coef = 1.0f; }
-        else sm = A.samples[r];
-        if (sm.src >= 0) {
-          const int lvl = sm.src >> 28, ray = sm.src & 0x0fffffff;
-          const CamRegs cam = load_cam(V.C);
-          float cx, cy;
-          level_center(V.lv[lvl], ray, cx, cy);
-          const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-          make_point(V.cfg.M, cam.c, g.d, sm.zb, p);
+  uint32_t masks[8][4];
+  float y = 0.f;
+  if (MODE == BWD_SAVED) {
+    // the ReLU masks of every gradient sample were saved by the march kernel: no forward recompute
+    long long* mb = reinterpret_cast<long long*>(S.part);
+    if (tid < TILE) {
+      r = base + tid;
+      valid = r < count;
+      if (valid) sm = A.samples[r];
+      y = sm.sdf;
+      S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
+      mb[tid] = valid ? (long long)sm.mblock : -1ll;
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) masks[l][ob] = 0u;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const long long b = mb[32 * rb + (lane & 31)];
+      if (b >= 0) load_mask_chunk(V.mstore + (size_t)b * 32, masks, rb, wave, lane >> 5);
+    }
+    __syncthreads();   // mb (S.part) is reused by mlp_backward
+  } else {
+    if (tid < TILE) {
+      float p[3] = {0.f, 0.f, 0.f};
+      r = base + tid;
+      valid = r < count;
+      if (valid) {
+        if (MODE == BWD_POINTGRAD && A.xyz) {
+          p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
+          sm.coef = 1.0f;
+        } else {
+          if (MODE == BWD_POINTGRAD) { sm.src = A.pix_list[r]; sm.zb = A.zdepth[sm.src]; sm.coef = 1.0f; }
+          else sm = A.samples[r];
+          if (sm.src >= 0) {
+            const int lvl = src_level(sm.src), ray = src_ray(sm.src);
+            const CamRegs cam = load_cam(V.C);
+            float cx, cy;
+            level_center(V.lv[lvl], ray, cx, cy);
+            const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+            make_point(V.cfg.M, cam.c, g.d, sm.zb, p);
+          }
         }
       }
+      S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
     }
-    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+    __syncthreads();
+    const float* c0 = A.c0c4 ? A.c0c4 : V.C->c0;
+    const float* c4 = A.c0c4 ? A.c0c4 + HID : V.C->c4;
+    const float pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
+    if (tid < TILE) {
+      y = tanh_spec(pre);
+      S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-
-  uint32_t masks[8][4];
-  const float* c0 = A.c0c4 ? A.c0c4 : V.C->c0;
-  const float* c4 = A.c0c4 ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
-  float y = 0.f;
-  if (tid < TILE) {
-    y = tanh_spec(pre);
-    S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
-  }
-  __syncthreads();
-  float* part = (MODE == BWD_FULL) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
+  float* part = (MODE != BWD_POINTGRAD) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
   mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
 
   if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
@@ -634,7 +699,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.f;
   if (valid && sm.src >= 0 && (sm.flags & 1)) {
-    const int lvl = sm.src >> 28, ray = sm.src & 0x0fffffff;
+    const int lvl = src_level(sm.src), ray = src_ray(sm.src);
     const CamRegs cam = load_cam(V.C);
     float cx, cy;
     level_center(V.lv[lvl], ray, cx, cy);
@@ -808,7 +873,7 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
   }
   const size_t P = (size_t)V.P;
   for (int k = 0; k < bs; ++k) {
-    Sample s; s.src = -1; s.zb = 0.f; s.coef = 0.f; s.flags = 0;
+    Sample s; s.src = -1; s.zb = 0.f; s.coef = 0.f; s.flags = 0; s.sdf = 0.f; s.mblock = -1; s.pad0 = 0; s.pad1 = 0;
     bool emit = false;
     if (in) {
       s.src = V.tk_src[k * P + px];
@@ -822,7 +887,13 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
         } else {
           s.zb = V.tk_zb[k * P + px];
           s.coef = c;
-          const bool fine_row = (s.src >> 28) == 0;
+          s.sdf = sv;
+          if (V.save_masks) {
+            const int lv = src_level(s.src);
+            s.mblock = (lv == 0) ? (int32_t)((int64_t)px * (bs + 1) + V.tk_slot[k * P + px])
+                                 : (int32_t)(V.mfine + V.moff[lv] + (int64_t)src_step(s.src) * V.lv[lv].n + src_ray(s.src));
+          }
+          const bool fine_row = src_level(s.src) == 0;
           s.flags = (fine_row && !V.cfg.grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
           emit = true;
         }
@@ -849,7 +920,8 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
 // all padded rows sample the origin (points = 0, renderer.py:539): one combined sample, no camera dependence
 __global__ void k_bwd_pad(View V, Sample* samples) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && V.C->pad_coef != 0.f) {
-    Sample s; s.src = -1; s.zb = 0.f; s.coef = V.C->pad_coef; s.flags = 0;
+    Sample s; s.src = -1; s.zb = 0.f; s.coef = V.C->pad_coef; s.flags = 0; s.sdf = V.C->f_origin; s.mblock = (int32_t)V.morigin;
+    s.pad0 = 0; s.pad1 = 0;
     samples[V.C->cnt_samples] = s;
     V.C->cnt_samples = V.C->cnt_samples + 1;
   }

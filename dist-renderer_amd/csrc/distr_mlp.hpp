@@ -230,6 +230,39 @@ __device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][RB]
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---------------------------------------------------------------------------------------- saved ReLU masks
+// A ray's 512-byte mask block = 8 chunks of 64 bytes, chunk (wave, h) = the 32 16-bit words masks[l][ob] (l = 0..7,
+// ob = 0..3) that lane (j, h) of wave `wave` holds for that ray. The layout is per ray, so a block written by a
+// 32- or 64-ray forward tile can be read by any backward tile that puts the ray on lane j / block rb.
+template <int RB>
+__device__ __forceinline__ void store_mask_chunk(uint4* blk /*block base*/, const uint32_t (&masks)[8][4], int rb, int wave, int h) {
+  uint32_t q[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e0 = 2 * i, e1 = 2 * i + 1;
+    const uint32_t w0 = (masks[e0 >> 2][e0 & 3] >> (16 * rb)) & 0xffffu;
+    const uint32_t w1 = (masks[e1 >> 2][e1 & 3] >> (16 * rb)) & 0xffffu;
+    q[i] = w0 | (w1 << 16);
+  }
+  uint4* dst = blk + (wave * 2 + h) * 4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) dst[v] = make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]);
+}
+
+// masks[l][ob] |= chunk words << (16*rb)
+__device__ __forceinline__ void load_mask_chunk(const uint4* blk, uint32_t (&masks)[8][4], int rb, int wave, int h) {
+  const uint4* src = blk + (wave * 2 + h) * 4;
+  uint32_t q[16];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { const uint4 t = src[v]; q[4 * v] = t.x; q[4 * v + 1] = t.y; q[4 * v + 2] = t.z; q[4 * v + 3] = t.w; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e0 = 2 * i, e1 = 2 * i + 1;
+    masks[e0 >> 2][e0 & 3] |= (q[i] & 0xffffu) << (16 * rb);
+    masks[e1 >> 2][e1 & 3] |= (q[i] >> 16) << (16 * rb);
+  }
+}
+
 // ---------------------------------------------------------------------------------------- forward tile
 // Preconditions: S.xyz rows 0..2 hold the TILE points (x row, y row, z row), visible to all threads (barrier done).
 // Returns (every thread, for ray = tid & (TILE-1)) the pre-tanh output. masks[l] = ReLU bitmasks of layer l

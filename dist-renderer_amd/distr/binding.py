@@ -42,6 +42,7 @@ class RenderCfg(C.Structure):
         ('coarse_steps', C.c_int32 * 2),
         ('use_depth2normal', C.c_int32), ('normalize_normal', C.c_int32), ('want_normal', C.c_int32),
         ('grad_depth', C.c_int32), ('grad_mask', C.c_int32), ('grad_camera', C.c_int32),
+        ('save_for_backward', C.c_int32),
     ]
 
     def clone(self):
@@ -136,6 +137,7 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
     cfg.coarse_steps = (C.c_int32 * 2)(int(coarse_steps[0]), int(coarse_steps[1]))
     cfg.use_depth2normal, cfg.normalize_normal, cfg.want_normal = int(use_depth2normal), int(normalize_normal), int(want_normal)
     cfg.grad_depth, cfg.grad_mask, cfg.grad_camera = int(grad_depth), int(grad_mask), int(grad_camera)
+    cfg.save_for_backward = 1
     return cfg
 
 

@@ -108,6 +108,9 @@ class RenderFunction(torch.autograd.Function):
 
 
 def render_call(engine, cfg, latent, R, T):
+    # inference (torch.no_grad() or no input requires grad): skip saving the ReLU masks for the backward pass
+    need_bwd = torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (latent, R, T))
+    cfg.save_for_backward = 1 if need_bwd else 0
     return RenderFunction.apply(latent, R, T, engine, cfg)
 
 

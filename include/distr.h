@@ -71,6 +71,9 @@ typedef struct distr_render_cfg {
   int32_t grad_depth;         /* !no_grad_depth                                             renderer.py:410-411, 876-877 */
   int32_t grad_mask;          /* !no_grad_mask                                              renderer.py:388-389 */
   int32_t grad_camera;        /* !no_grad_camera                                            renderer.py:536-542 */
+  int32_t save_for_backward;  /* 1: distr_render_backward will be called on this forward's workspace: the march kernel also
+                                 saves the ReLU masks of the rows it keeps (512 B each) so that the backward pass need not
+                                 recompute the decoder; 0: inference only (smaller workspace, backward not allowed) */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */
