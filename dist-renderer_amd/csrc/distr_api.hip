@@ -21,10 +21,12 @@ struct distr_ctx {
   float* dec_buf = nullptr;  // one device allocation holding every packed array
   size_t dec_floats = 0;
   DecoderDev D{};
+  DecoderDev16 D16{};
   bool has_decoder = false;
   bool profiling = false;
   int tile_rb = 0;           // 0: hybrid (64-ray tiles, 32-ray tiles once few rays are live); 1 / 2: force 32 / 64-ray tiles
   int hybrid_threshold = 8192;  // live-ray count below which a march step runs on 32-ray tiles
+  int tail16_threshold = 4096;  // ... and below which it runs on 16-ray tiles (16x16x4 MFMA)
   bool save_masks = true;       // save ReLU masks in the forward so that the backward skips the decoder recompute
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -65,6 +67,20 @@ void pack_fragments(const float* W, int K, int O, float* dst) {
           const int o = w * 32 * NOB + 32 * ob + (lane & 31), h = lane >> 5;
           float* d = dst + ((((size_t)g * 4 + w) * NOB + ob) * 64 + lane) * 4;
           for (int s = 0; s < 4; ++s) d[s] = W[(size_t)o * K + 8 * g + 2 * s + h];
+        }
+}
+
+// A-fragments of v_mfma_f32_16x16x4_f32 (distr_mlp.hpp::dense16):
+//   float4 index ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + (lane&15)][16g + 4s + (lane>>4)] : s = 0..3 }
+void pack_fragments16(const float* W, int K, int O, float* dst) {
+  const int NB = O / 64, NG = K / 16;
+  for (int g = 0; g < NG; ++g)
+    for (int w = 0; w < 4; ++w)
+      for (int ob = 0; ob < NB; ++ob)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int o = w * 16 * NB + 16 * ob + (lane & 15), kq = lane >> 4;
+          float* d = dst + ((((size_t)g * 4 + w) * NB + ob) * 64 + lane) * 4;
+          for (int s = 0; s < 4; ++s) d[s] = W[(size_t)o * K + 16 * g + 4 * s + kq];
         }
 }
 
@@ -189,9 +205,10 @@ int distr_create(distr_ctx** out, int hip_device) {
   distr_ctx* ctx = new distr_ctx();
   ctx->device = hip_device;
   if (const char* e = getenv("DISTR_TILE_RB")) ctx->tile_rb = atoi(e);
-  if (ctx->tile_rb < 0 || ctx->tile_rb > 2) ctx->tile_rb = 0;
+  if (ctx->tile_rb < -1 || ctx->tile_rb > 2) ctx->tile_rb = 0;   // -1: force 16-ray tiles wherever they exist (tests)
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || hip_device < 0 || hip_device >= n) {
@@ -253,6 +270,14 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
     offWb[l] = reserve(Wt.size());
     pack_fragments(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], host.data() + offWb[l]);
   }
+  size_t offW16[8];
+  for (int l = 0; l < 8; ++l) {
+    const int K16 = (l == 0) ? 16 : Kp[l];
+    std::vector<float> W16((size_t)Op[l] * K16, 0.f);
+    for (int o = 0; o < Op[l]; ++o) for (int k = 0; k < Kp[l]; ++k) W16[(size_t)o * K16 + k] = Wp[l][(size_t)o * Kp[l] + k];
+    offW16[l] = reserve(W16.size());
+    pack_fragments16(W16.data(), K16, Op[l], host.data() + offW16[l]);
+  }
   for (int l : {1, 2, 3, 5, 6, 7}) {
     offB[l] = reserve(Op[l]);
     memcpy(host.data() + offB[l], b[l], sizeof(float) * OUT[l]);
@@ -281,6 +306,7 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
   D.W0lat_t = d + o_W0lat_t; D.W4lat_t = d + o_W4lat_t; D.W0lat = d + o_W0lat; D.W4lat = d + o_W4lat;
   D.b0 = d + o_b0; D.b4 = d + o_b4; D.w8 = d + o_w8; D.W0x = d + o_W0x;
   D.b8 = b[8][0];
+  for (int l = 0; l < 8; ++l) ctx->D16.Wf[l] = d + offW16[l];
   ctx->has_decoder = true;
   return DISTR_OK;
 }
@@ -351,6 +377,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     const bool hybrid = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
     timer.begin();
     A.count_lo = hybrid ? ctx->hybrid_threshold : 0; A.count_hi = 0x7fffffff;
+    if (ctx->tile_rb == -1 && cfg->marcher != DISTR_MARCH_TRIVIAL && !A.origin_tile) A.count_lo = 0x7fffffff;   // tests: everything on 16-ray tiles
     if (V.save_masks) {
       if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
@@ -358,9 +385,18 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
     }
+    const bool force16 = ctx->tile_rb == -1 && cfg->marcher != DISTR_MARCH_TRIVIAL && !A.origin_tile;
+    const int t16 = force16 ? 0x7fffffff : ((hybrid && ctx->tail16_threshold > 0) ? std::min(ctx->tail16_threshold, ctx->hybrid_threshold) : 0);
+    if (t16 > 0) {   // ... and on 16-ray tiles when fewer than `tail16_threshold` are
+      MarchArgs A2 = A;
+      A2.count_lo = 0; A2.count_hi = t16; A2.origin_tile = 0;
+      const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)t16) + 15) / 16);
+      if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+      else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+    }
     if (hybrid) {  // the same step on 32-ray tiles (two workgroups per CU) when fewer than `hybrid_threshold` rays are live
       MarchArgs A1 = A;
-      A1.count_lo = 0; A1.count_hi = ctx->hybrid_threshold; A1.origin_tile = 0;
+      A1.count_lo = t16; A1.count_hi = ctx->hybrid_threshold; A1.origin_tile = 0;
       const unsigned t1 = (unsigned)((std::min(P, ctx->hybrid_threshold) + 31) / 32);
       if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
       else hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
@@ -500,7 +536,8 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
   const int TILE = 32 * rb_dense;
   timer.begin();
-  if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  if (ctx->tile_rb == -1) hipLaunchKernelGGL((k_march16<MODE_EVAL, false>), dim3((unsigned)((n + 15) / 16)), dim3(NTHREADS), 0, s, A, ctx->D, ctx->D16);
+  else if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
   else hipLaunchKernelGGL((k_march<MODE_EVAL, 2, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
   timer.end();
   LAUNCH_CHECK("k_march<eval>");

@@ -469,6 +469,87 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
   }
 }
 
+// The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
+// MODE_FINE (recursive marchers) and MODE_EVAL only.
+template <int MODE, bool KEEP>
+__global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
+  constexpr int TILE = 16;
+  __shared__ Smem16 S;
+  const View& V = A.V;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  int64_t count;
+  const int32_t* list = nullptr;
+  if (MODE == MODE_EVAL) {
+    count = A.n;
+  } else {
+    count = V.C->cnt_live[A.step];
+    list = V.live[A.step & 1];
+  }
+  const int64_t base = (int64_t)tile * TILE;
+  if (base >= count) return;
+  if (MODE == MODE_FINE && (count < A.count_lo || count >= A.count_hi)) return;
+
+  int32_t id = -1;
+  float zd = 0.f;
+  bool valid = false;
+  if (tid < TILE) {
+    float p[3] = {0.f, 0.f, 0.f};
+    const int64_t r = base + tid;
+    valid = r < count;
+    if (valid) {
+      if (MODE == MODE_EVAL) {
+        id = (int32_t)r;
+        p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
+      } else {
+        id = list[r];
+        const CamRegs cam = load_cam(V.C);
+        float cx, cy;
+        level_center(V.lv[0], id, cx, cy);
+        const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+        zd = V.init_now[id] + V.m[id];
+        make_point(V.cfg.M, cam.c, g.d, zd, p);
+      }
+    }
+    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+  }
+  __syncthreads();
+
+  uint32_t nib[8];
+  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
+  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
+  const float pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+
+  long long mblock = -1;
+  if (tid < 64) {
+    const float s = tanh_spec(pre);
+    if (MODE == MODE_EVAL) {
+      if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
+    } else {
+      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+      bool stay = false;
+      if (valid) {
+        const float init_now = V.init_now[id];
+        const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
+        V.m[id] = mn;
+        const float za = mn + init_now;
+        const int slot = topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);
+        if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+        const float a = fabsf(s);
+        if (a < V.minabs[id]) V.minabs[id] = a;
+        if (A.step == 0) V.first_sdf[id] = s;
+        stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+      }
+      wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
+    }
+  }
+  if (KEEP && MODE == MODE_FINE) {
+    if (tid < TILE) S.mb[tid] = mblock;
+    __syncthreads();
+    store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+  }
+}
+
 // test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
 template <int RB>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer,

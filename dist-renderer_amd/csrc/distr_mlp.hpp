@@ -210,9 +210,13 @@ __device__ __forceinline__ void writeback(float* X, const f32x16 (&acc)[NOB][RB]
         float v = acc[ob][rb][r];
         if (GATE) {
           v = gate(v, (m >> (rb * 16 + r)) & 1u);
+        } else if (KEEP && RELU) {
+          // relu on the bit pattern (v_max_i32), then bit = min(bits, 1) (v_min_u32): 3 VALU ops per element
+          const int32_t rbits = max(__float_as_int(v), 0);
+          v = __int_as_float(rbits);
+          m |= min((uint32_t)rbits, 1u) << (rb * 16 + r);
         } else if (KEEP) {
           const uint32_t pb = pos_bit(v);
-          if (RELU) v = gate(v, pb);
           m |= pb << (rb * 16 + r);
         } else if (RELU) {
           v = __int_as_float(max(__float_as_int(v), 0));  // relu on the bit pattern (v_max_i32)
@@ -472,6 +476,180 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, u
     S.aux[(1 + c) * TILE + r] = S.aux[(1 + c) * TILE + r] + ((p[0] + p[TILE]) + (p[2 * TILE] + p[3 * TILE]));
   }
   __syncthreads();
+}
+
+// =====================================================================================================================
+// 16-ray tile (forward only) on v_mfma_f32_16x16x4_f32 -- used for the live-ray tail of the march, where a launch has
+// fewer tiles than CUs and its cost is ONE tile latency: 16 rays take half the MFMA time of 32.
+// Fragment maps of the 16x16x4 form: A lane (i = l&15, kq = l>>4) = A[i][kq]; B lane (j = l&15, kq) = B[kq][j];
+// D (4 registers) col = l&15, row = 4*(l>>4) + r. The chain order is again k-natural, so values are bit-identical to
+// the 32x32x2 tiles. Wave w owns rows [w*O/4, (w+1)*O/4) as NB blocks of 16.
+struct Smem16 {
+  float X[HID * 16];
+  float xyz[4 * 16];
+  float part[4 * 16];
+  long long mb[16];
+};
+
+struct DecoderDev16 {
+  const float* Wf[8];   // 16x16x4 A-fragments: float4 ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + i][16g + 4s + kq] : s=0..3 }
+};
+
+template <int NB>
+__device__ __forceinline__ void acc_init16(f32x4 (&acc)[NB], const float* __restrict__ init, int row0, int kq) {
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) acc[ob] = *reinterpret_cast<const f32x4*>(init + row0 + 16 * ob + 4 * kq);
+}
+
+template <int K, int NB>
+__device__ __forceinline__ void dense16(const float* __restrict__ Wp, const float* X, f32x4 (&acc)[NB], int wave, int lane) {
+  constexpr int NG = K / 16;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)wave * NB * 64 + lane;
+  const float* xb = X + lane;   // (16g + 4s + kq)*16 + j  with  kq*16 + j = lane
+  f32x4 a[NB];
+  float b[4];
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) a[ob] = wp[ob * 64];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b[s] = xb[4 * s * 16];
+#pragma unroll 2
+  for (int g = 0; g < NG; ++g) {
+    f32x4 an[NB];
+    float bn[4];
+    const int gn = (g + 1 < NG) ? g + 1 : g;
+    const f32x4* wn = wp + (size_t)gn * (4 * NB * 64);
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) an[ob] = wn[ob * 64];
+    const float* xg = xb + (size_t)gn * 16 * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bn[s] = xg[4 * s * 16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][s], b[s], acc[ob], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) a[ob] = an[ob];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = bn[s];
+  }
+}
+
+// relu + write back; nib (KEEP): bit (4*ob + r) = output (ob, r) > 0
+template <int NB, bool KEEP>
+__device__ __forceinline__ uint32_t writeback16(float* X, const f32x4 (&acc)[NB], int row0, int lane) {
+  const int kq = lane >> 4, j = lane & 15;
+  uint32_t m = 0u;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int32_t rbits = max(__float_as_int(acc[ob][r]), 0);
+      if (KEEP) m |= min((uint32_t)rbits, 1u) << (4 * ob + r);
+      X[(row0 + 16 * ob + 4 * kq + r) * 16 + j] = __int_as_float(rbits);
+    }
+  }
+  if (KEEP) asm volatile("" : "+v"(m));
+  __builtin_amdgcn_sched_barrier(0);
+  return m;
+}
+
+// nib[l]: per-lane nibble words of layer l (see writeback16). Returns pre-tanh for ray = tid & 15.
+template <bool KEEP>
+__device__ __forceinline__ float mlp_forward16(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
+                                               const float* __restrict__ c4, Smem16& S, uint32_t (&nib)[8]) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int kq = lane >> 4;
+  const int ray = tid & 15;
+  float* X = S.X;
+  X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;   // rows 0..15 of the layer-0 input: xyz + zero padding to K = 16
+  __syncthreads();
+  {
+    f32x4 acc[8];
+    acc_init16<8>(acc, c0, wave * 128, kq);
+    dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
+    __syncthreads();
+    nib[0] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 1; l <= 2; ++l) {
+    f32x4 acc[8];
+    acc_init16<8>(acc, D.bias[l], wave * 128, kq);
+    dense16<512, 8>(D16.Wf[l], X, acc, wave, lane);
+    __syncthreads();
+    nib[l] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    __syncthreads();
+  }
+  {
+    f32x4 acc[4];
+    acc_init16<4>(acc, D.bias[3], wave * 64, kq);
+    dense16<512, 4>(D16.Wf[3], X, acc, wave, lane);
+    __syncthreads();
+    nib[3] = writeback16<4, KEEP>(X, acc, wave * 64, lane);
+    __syncthreads();
+    if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
+    __syncthreads();
+  }
+  {
+    f32x4 acc[8];
+    acc_init16<8>(acc, c4, wave * 128, kq);
+    dense16<256, 8>(D16.Wf[4], X, acc, wave, lane);
+    __syncthreads();
+    nib[4] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 5; l <= 7; ++l) {
+    f32x4 acc[8];
+    acc_init16<8>(acc, D.bias[l], wave * 128, kq);
+    dense16<512, 8>(D16.Wf[l], X, acc, wave, lane);
+    __syncthreads();
+    nib[l] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    __syncthreads();
+  }
+  {
+    float p = 0.f;
+    const float* w8 = D.w8 + wave * 128;
+    const float* xr = X + (size_t)wave * 128 * 16 + ray;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * 16], p);
+    S.part[wave * 16 + ray] = p;
+  }
+  __syncthreads();
+  return ((S.part[ray] + S.part[16 + ray]) + (S.part[32 + ray] + S.part[48 + ray])) + D.b8;
+}
+
+// Stores the ray's mask chunks in the common per-ray format (store_mask_chunk): the 16-bit word of 32-row block ob and
+// half h is  nib(kq=h, 2ob) | nib(kq=2+h, 2ob)<<4 | nib(kq=h, 2ob+1)<<8 | nib(kq=2+h, 2ob+1)<<12.
+__device__ __forceinline__ void store_masks16(uint4* mstore, const long long* mb /*[16] LDS*/, const uint32_t (&nib)[8], int wave,
+                                              int lane) {
+  uint32_t partner[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) partner[l] = __shfl(nib[l], (lane + 32) & 63);
+  const int kq = lane >> 4, j = lane & 15;
+  if (kq >= 2) return;
+  const long long b = mb[j];
+  if (b < 0) return;
+  uint32_t q[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    uint32_t w2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = 2 * i + e, l = idx >> 2, ob = idx & 3;
+      const uint32_t M = nib[l], Pn = partner[l];
+      w2[e] = ((M >> (8 * ob)) & 0xfu) | (((Pn >> (8 * ob)) & 0xfu) << 4) | (((M >> (8 * ob + 4)) & 0xfu) << 8) |
+              (((Pn >> (8 * ob + 4)) & 0xfu) << 12);
+    }
+    q[i] = w2[0] | (w2[1] << 16);
+  }
+  uint4* dst = mstore + (size_t)b * 32 + (wave * 2 + kq) * 4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) dst[v] = make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]);
 }
 
 }  // namespace distr
