@@ -347,7 +347,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   MarchArgs A;
   memset(&A, 0, sizeof(A));
   A.V = V;
-  A.count_lo = 0; A.count_hi = 0x7fffffff;
+  A.t16 = 0; A.t32 = 0; A.which = 64;
   bool origin_done = false;
   for (int l = V.nlev - 1; l >= 1; --l) {
     hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
@@ -374,32 +374,38 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     A.lvl = 0; A.step = st; A.origin_tile = origin_done ? 0 : 1;
     origin_done = true;
     const unsigned tiles = (unsigned)((P + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
-    const bool hybrid = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
-    timer.begin();
-    A.count_lo = hybrid ? ctx->hybrid_threshold : 0; A.count_hi = 0x7fffffff;
-    if (ctx->tile_rb == -1 && cfg->marcher != DISTR_MARCH_TRIVIAL && !A.origin_tile) A.count_lo = 0x7fffffff;   // tests: everything on 16-ray tiles
-    if (V.save_masks) {
-      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-      else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-    } else {
-      if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-      else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-    }
+    // tile-size split of the step (fine_range): 64-ray kernel first, then the 32- and 16-ray kernels for the remainder
+    const bool split = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
     const bool force16 = ctx->tile_rb == -1 && cfg->marcher != DISTR_MARCH_TRIVIAL && !A.origin_tile;
-    const int t16 = force16 ? 0x7fffffff : ((hybrid && ctx->tail16_threshold > 0) ? std::min(ctx->tail16_threshold, ctx->hybrid_threshold) : 0);
-    if (t16 > 0) {   // ... and on 16-ray tiles when fewer than `tail16_threshold` are
-      MarchArgs A2 = A;
-      A2.count_lo = 0; A2.count_hi = t16; A2.origin_tile = 0;
-      const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)t16) + 15) / 16);
-      if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
-      else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+    A.t32 = split ? ctx->hybrid_threshold : 0;
+    A.t16 = split ? std::min(ctx->tail16_threshold, ctx->hybrid_threshold) : 0;
+    A.which = 32 * rb_dense;
+    if (force16) { A.t16 = 0x7fffffff; A.t32 = 0x7fffffff; }       // tests: whole step on 16-ray tiles (rem = count when < 16384...)
+    timer.begin();
+    if (!force16) {
+      if (V.save_masks) {
+        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      } else {
+        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      }
     }
-    if (hybrid) {  // the same step on 32-ray tiles (two workgroups per CU) when fewer than `hybrid_threshold` rays are live
-      MarchArgs A1 = A;
-      A1.count_lo = t16; A1.count_hi = ctx->hybrid_threshold; A1.origin_tile = 0;
-      const unsigned t1 = (unsigned)((std::min(P, ctx->hybrid_threshold) + 31) / 32);
-      if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
-      else hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(t1), dim3(NTHREADS), 0, s, A1, D);
+    if (split || force16) {
+      MarchArgs A2 = A;
+      A2.origin_tile = 0;
+      if (split && A.t32 > A.t16) {
+        A2.which = 32;
+        const unsigned n32 = (unsigned)((std::min(P, A.t32) + 31) / 32);
+        if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(n32), dim3(NTHREADS), 0, s, A2, D);
+        else hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(n32), dim3(NTHREADS), 0, s, A2, D);
+      }
+      if (A.t16 > 0) {
+        A2.which = 16;
+        const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16);
+        if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+        else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+      }
     }
     timer.end();
     LAUNCH_CHECK("k_march<fine>");

@@ -340,6 +340,19 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
 // workgroups beyond the device-side count exit immediately, so the host never synchronises inside the loop.
 enum { MODE_EVAL = 0, MODE_COARSE = 1, MODE_FINE = 2 };
 
+// A march step over `count` live rays is split by tile size so that no launch pays a full 64-ray tile latency for a
+// small remainder: rays [0, full) with full = floor(count / 16384) * 16384 (whole rounds of 256 CUs x 64 rays) go to
+// the 64-ray kernel; the remainder goes to 16-ray tiles if <= t16, to 32-ray tiles if <= t32, else also to 64-ray tiles.
+// Every kernel of the step evaluates this on the device-side count; the host never needs to know it.
+__device__ __forceinline__ void fine_range(int64_t count, int t16, int t32, int which, int64_t& lo, int64_t& hi) {
+  if (t32 <= 0) { lo = 0; hi = count; return; }                                   // single kernel per step
+  if (t16 == 0x7fffffff) { lo = 0; hi = (which == 16) ? count : 0; return; }      // tests: everything on 16-ray tiles
+  const int64_t full = (count / 16384) * 16384, rem = count - full;
+  const int small = (rem == 0) ? 64 : (rem <= t16 ? 16 : (rem <= t32 ? 32 : 64));
+  if (which == 64) { lo = 0; hi = (small == 64) ? count : full; }
+  else { lo = full; hi = (small == which) ? count : full; }
+}
+
 struct MarchArgs {
   View V;
   int32_t lvl, step;
@@ -349,7 +362,9 @@ struct MarchArgs {
   const float* c0c4;         // MODE_EVAL: latent constants
   int64_t n;
   float clamp;
-  int32_t count_lo, count_hi;  // MODE_FINE: this launch only runs if count_lo <= live count < count_hi (tile-size hybrid)
+  // MODE_FINE tile-size split (see fine_range): t16 / t32 = largest remainder handled by 16- / 32-ray tiles; which = tile
+  // size of THIS launch (16, 32, 64). t32 == 0: no split, the 64-ray (or forced) kernel takes everything.
+  int32_t t16, t32, which;
 };
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
@@ -375,11 +390,11 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
     if (V.cfg.marcher == DISTR_MARCH_TRIVIAL) { count = V.C->cnt_level[0]; list = V.lv[0].list; }
     else { count = V.C->cnt_live[A.step]; list = V.live[A.step & 1]; }
   }
-  const int64_t base = (int64_t)tile * TILE;
-  if (!origin) {
-    if (base >= count) return;
-    if (MODE == MODE_FINE && (count < A.count_lo || count >= A.count_hi)) return;   // the other tile size handles this step
-  }
+  int64_t lo = 0, hi = count;
+  if (MODE == MODE_FINE && V.cfg.marcher != DISTR_MARCH_TRIVIAL) fine_range(count, A.t16, A.t32, A.which, lo, hi);
+  const int64_t base = lo + (int64_t)tile * TILE;
+  if (!origin && base >= hi) return;
+  count = hi;
 
   int32_t id = -1;
   float zd = 0.f;
@@ -486,9 +501,11 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
     count = V.C->cnt_live[A.step];
     list = V.live[A.step & 1];
   }
-  const int64_t base = (int64_t)tile * TILE;
-  if (base >= count) return;
-  if (MODE == MODE_FINE && (count < A.count_lo || count >= A.count_hi)) return;
+  int64_t lo = 0, hi = count;
+  if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
+  const int64_t base = lo + (int64_t)tile * TILE;
+  if (base >= hi) return;
+  count = hi;
 
   int32_t id = -1;
   float zd = 0.f;
