@@ -145,6 +145,13 @@ def main():
                                                eng.ctx.stream()))
     stats = eng.ctx.render_stats(cfg, ws)
 
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see file
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))['bytes_per_launch']
+        except Exception:
+            traffic = None
     if rank == 0:
         n_fwd = args.steps * len(cams)
         evals = stats['num_point_evals'] * n_fwd
@@ -163,7 +170,8 @@ def main():
                        'decoder_evals_per_forward': stats['num_point_evals'], 'grad_samples_per_backward': None,
                        'march_launches_per_forward': stats['num_march_launches']},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_note': 'fabric-side bytes per march step from a separate rocprofv3 PMC pass (profiles/r01_traffic.json)',
                          'kernel': 'k_march (fused 9-layer decoder + march update), %d launches, %.3f ms total, avg %.1f us'
                                    % (launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
