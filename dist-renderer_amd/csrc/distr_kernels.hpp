@@ -24,7 +24,7 @@ struct Consts {
   float latent[LAT];
   float R[9], T[3], c[3];
   float cdist;
-  int32_t inside;         // camera inside the unit sphere (renderer.py:266-268)
+  int32_t reserved0;
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
   uint32_t maxinit_bits[3];
   int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
@@ -124,7 +124,7 @@ __device__ __forceinline__ void level_center(const LevelView& L, int i, float& p
   py = L.scale * (float)(i / L.w) + L.off;
 }
 
-struct CamRegs { float R[9], c[3], cdist; int inside; };
+struct CamRegs { float R[9], c[3], cdist; };
 __device__ __forceinline__ CamRegs load_cam(const Consts* C) {
   CamRegs k;
 #pragma unroll
@@ -132,7 +132,6 @@ __device__ __forceinline__ CamRegs load_cam(const Consts* C) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) k.c[i] = C->c[i];
   k.cdist = C->cdist;
-  k.inside = C->inside;
   return k;
 }
 
@@ -177,7 +176,6 @@ __global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const flo
       for (int i = 0; i < 3; ++i) { c[i] = -(R[0 * 3 + i] * T[0] + R[1 * 3 + i] * T[1] + R[2 * 3 + i] * T[2]); C->c[i] = c[i]; }
       const float cd = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       C->cdist = cd;
-      C->inside = cd < 1.0f ? 1 : 0;  // patched with cfg.radius by k_setup_level (radius is a cfg field)
       C->f_origin = 0.f;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
     }
@@ -204,7 +202,6 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const CamRegs cam = load_cam(C);
   const bool inside = cam.cdist < V.cfg.radius;
-  if (i == 0 && lvl == 0) C->inside = inside ? 1 : 0;
   bool valid = false;
   if (i < L.n) {
     float px, py;
@@ -865,11 +862,6 @@ __global__ void __launch_bounds__(256) k_normal_finish(View V, const int32_t* co
 __global__ void __launch_bounds__(256) k_mask_list(int P, const uint8_t* mask, int32_t* list, int32_t* counter) {
   const int px = blockIdx.x * 256 + threadIdx.x;
   wave_append(px < P && mask[px] != 0, px, list, counter);
-}
-
-__global__ void k_zero_i32(int32_t* p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------ backward: image side

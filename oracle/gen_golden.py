@@ -172,5 +172,48 @@ if __name__ == '__main__':
         rsn = np.random.RandomState(99)
         Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
         noise_floor_c2(rh.build_reference_decoder(Ws, bs), rh.build_reference_decoder(Wn, bs), latent)
+    elif sys.argv[1:2] == ['--g5']:
+        pass
     else:
         main()
+        golden_g5()
+
+
+def golden_g5():
+    """G5: five Adam iterations of the reference's single-view shape optimisation (optimize_single.py:50-84 with
+    compute_all_loss, loss_single.py:7) against a synthetic GT rendered from a perturbed latent. 48x48, 30 steps, bs 3."""
+    rh.install_shims()
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    SDFRenderer = rh.reference_modules()[0]
+    from core.inv_optimizer.loss_single import compute_all_loss
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(20, 15, 1.6, 0)
+    RT = torch.from_numpy(np.concatenate([R, T[:, None]], 1))
+    r = SDFRenderer(dec, K, img_hw=(H, W), march_step=30, buffer_size=3, use_gpu=False, use_depth2normal=True)
+    lat_gt = torch.from_numpy(latent + 0.05 * np.random.RandomState(77).standard_normal(latent.shape).astype(np.float32))
+    with torch.no_grad():
+        d, n, m, q = r.render(lat_gt, RT[:, :3], RT[:, 3], no_grad=True)
+    gt_pack = {'depth': d.clone(), 'normal': n.clone(), 'silhouette': m.clone()}
+    lat = torch.from_numpy(latent).clone().requires_grad_(True)
+    opt = torch.optim.Adam([lat], lr=1e-3)
+    wd = dict(w_depth=10.0, w_normal=5.0, w_mask_gt=1.0, w_mask_out=1.0, w_l2reg=1.0)      # run_single_shape.py:93-98
+    hist = []
+    for it in range(5):
+        opt.zero_grad()
+        pack, _ = compute_all_loss(r, lat, RT, gt_pack, threshold=r.get_threshold())
+        loss = wd['w_depth'] * pack['depth'] + wd['w_normal'] * pack['normal'] + wd['w_mask_gt'] * pack['mask_gt'] + \
+            wd['w_mask_out'] * pack['mask_out'] + wd['w_l2reg'] * pack['l2reg']
+        loss.backward()
+        hist.append([float(pack[k]) for k in ('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg')] + [float(loss), float(lat.grad.norm())])
+        opt.step()
+    np.savez_compressed(os.path.join(OUT, 'g5_adam_single_view.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent0=latent,
+                        latent_gt=lat_gt.numpy(), K=K, R=R, T=T, H=H, W=W, march_step=30, buffer_size=3,
+                        gt_depth=gt_pack['depth'].numpy(), gt_normal=gt_pack['normal'].numpy(), gt_mask=gt_pack['silhouette'].numpy(),
+                        history=np.array(hist), latent_final=lat.detach().numpy())
+    print('g5', np.array(hist))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == '--g5':
+    golden_g5()

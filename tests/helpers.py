@@ -34,7 +34,7 @@ def hip_render(engine, H, W, K, R, T, latent, seed=5, **kw):
     torch.cuda.synchronize()
     return dict(zdepth=zdepth.detach().cpu().numpy(), mask=mask.cpu().numpy(), min_sdf=min_sdf.detach().cpu().numpy(),
                 depth=depth.detach().cpu().numpy(), normal=normal.detach().cpu().numpy(),
-                g_latent=lat.grad.cpu().numpy(), g_R=Rt.grad.cpu().numpy(), g_T=Tt.grad.cpu().numpy(), cfg=cfg, loss=float(L))
+                g_latent=lat.grad.cpu().numpy(), g_R=Rt.grad.cpu().numpy(), g_T=Tt.grad.cpu().numpy(), cfg=cfg, loss=float(L.detach()))
 
 
 def compare(a, b, H, W, tol_depth=1e-4, tol_grad=1e-3, normal_p99=1e-4, max_flip_frac=0.001):

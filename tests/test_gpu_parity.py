@@ -296,3 +296,89 @@ def test_option_sweep_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, c
     b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
     res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=2e-4, normal_p99=1e-5, max_flip_frac=0.0)
     assert res['flips'] == 0, res
+
+
+def test_c5_size_runs(engine, fixture_decoder):
+    """C5-sized call (1024x1024, 100 march steps): workspace sizing (~3 GB incl. saved masks), step counters, and the
+    same size-independent properties as C3 on the bigger grid."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 1024
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(45, 25, 1.6, 0)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, march_step=100, buffer_size=3, marcher='pyramid_recursive',
+                           use_depth2normal=True)
+    m = a['mask'].reshape(H, W).astype(bool)
+    assert 0.10 * H * W < m.sum() < 0.45 * H * W
+    assert np.all(np.abs(a['min_sdf'][a['mask'].astype(bool)]) <= 5e-5)
+    assert np.isfinite(a['g_latent']).all() and np.abs(a['g_latent']).max() > 0
+    assert np.isfinite(a['g_R']).all() and np.isfinite(a['g_T']).all()
+    st = engine.ctx.render_stats(a['cfg'], _last_ws(engine, a['cfg'], latent, R, T))
+    assert st['num_march_launches'] == 100 and st['num_in_sphere'] == H * W
+    assert st['num_valid'] == int(m.sum())
+
+
+def _last_ws(engine, cfg, latent, R, T):
+    """Runs one more forward through the raw C ABI and returns its workspace (for distr_get_render_stats)."""
+    import ctypes as C
+    import torch
+    from distr import binding
+    dev = engine.device
+    P = cfg.H * cfg.W
+    fwd_bytes, _ = engine.ctx.workspace_bytes(cfg)
+    ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32).reshape(-1)).to(dev)
+    lat, Rt, Tt = t(latent), t(R), t(T)
+    z, q = torch.empty(P, device=dev), torch.empty(P, device=dev)
+    mk = torch.empty(P, dtype=torch.uint8, device=dev)
+    d, n = torch.empty(P, device=dev), torch.empty(3 * P, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_render_forward(engine.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt), p(z), p(mk), p(q), p(d), p(n),
+                                                      p(ws), ws.numel(), engine.ctx.stream()))
+    return ws
+
+
+def test_adam_single_view_matches_reference_golden(fixture_decoder):
+    """G5: five Adam iterations of the single-view shape optimisation (optimize_single.py:50-84) through the drop-in
+    API (SDFRenderer + core.inv_optimizer) against the trajectory the reference itself produced on CPU."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.inv_optimizer import optimize_single_view
+    g = dict(np.load(os.path.join(GOLDEN, 'g5_adam_single_view.npz')))
+    Ws, bs, _ = fixture_decoder
+    dec = Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs))
+                         for n, a in (('weight', W), ('bias', b))})
+    dec = dec.cuda()
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer(dec, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']),
+                    use_depth2normal=True)
+    RT = torch.from_numpy(np.concatenate([g['R'], g['T'][:, None]], 1)).cuda()
+    gt_pack = {'depth': torch.from_numpy(g['gt_depth']).cuda(), 'normal': torch.from_numpy(g['gt_normal']).cuda(),
+               'silhouette': torch.from_numpy(g['gt_mask']).cuda()}
+    # the GT itself was rendered by the reference from latent_gt: our render of it must agree
+    with torch.no_grad():
+        d, n, m, q = r.render(torch.from_numpy(g['latent_gt']).cuda(), RT[:, :3], RT[:, 3], no_grad=True)
+    both = (m.cpu().numpy() > 0) & (g['gt_mask'] > 0)
+    assert (m.cpu().numpy() != g['gt_mask']).sum() <= 2
+    assert np.abs(d.cpu().numpy() - g['gt_depth'])[both].max() <= 1e-4
+    lat = torch.from_numpy(g['latent0']).cuda().requires_grad_(True)
+    opt = torch.optim.Adam([lat], lr=1e-3)
+    wd = dict(w_depth=10.0, w_normal=5.0, w_mask_gt=1.0, w_mask_out=1.0, w_l2reg=1.0)
+    hist = []
+
+    def record(i, pack, loss):
+        hist.append([float(pack[k].detach()) for k in ('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg')] + [float(loss.detach())])
+    optimize_single_view([r], None, opt, lat, RT, gt_pack, wd, optimizer_type='shape', num_iters=5, on_iteration=record)
+    hist, ref = np.array(hist), g['history']
+    print('ours\n', hist, '\nreference\n', ref[:, :6])
+    # observed agreement is 5-6 significant digits; bars leave ~10x margin for threshold-borderline pixels
+    assert np.abs(hist[:, 0] - ref[:, 0]).max() <= 3e-4 * ref[:, 0].max()          # depth loss
+    assert np.abs(hist[:, 1] - ref[:, 1]).max() <= 2e-5                             # normal (cosine) loss
+    assert np.abs(hist[:, 2:4] - ref[:, 2:4]).max() <= 2e-6                          # mask hinge losses (threshold scale 5e-5)
+    assert np.abs(hist[:, 4] - ref[:, 4]).max() <= 1e-7                             # l2 regulariser
+    assert np.abs(hist[:, 5] - ref[:, 5]).max() <= 1e-4 * np.abs(ref[:, 5]).max()   # total
+    # Adam moves every coordinate by ~lr per step: the two trajectories must stay together
+    assert np.abs(lat.detach().cpu().numpy() - g['latent_final']).max() <= 1.5e-3
+    assert np.abs(lat.detach().cpu().numpy() - g['latent_final']).mean() <= 2e-4
