@@ -176,7 +176,7 @@ def main():
                                    % (launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.gpus == 1:      # reported baseline, rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np)
         print(json.dumps(out))
     parallel.barrier()

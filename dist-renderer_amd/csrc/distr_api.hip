@@ -166,10 +166,15 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
   return (cv.off + 255) & ~(size_t)255;
 }
 
+constexpr int BWD_CHUNK = 64;   // tiles per reduction chunk
+
 size_t bwd_bytes(const distr_render_cfg& c) {
-  const size_t smax = (size_t)c.H * c.W * c.buffer_size + 1;
+  const size_t P = (size_t)c.H * c.W;
+  const size_t smax = P * c.buffer_size + 1;
   const size_t tiles = (smax + 31) / 32;
-  return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + 256;
+  const size_t nblk = (P + 255) / 256, nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
+  return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + nchunks * PSTRIDE * sizeof(float) +
+         nblk * (2 * sizeof(int32_t) + 16 * sizeof(float)) + 2048;
 }
 
 inline dim3 grid1(int64_t n, int per = 256) { return dim3((unsigned)((n + per - 1) / per)); }
@@ -433,13 +438,6 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   return DISTR_OK;
 }
 
-__global__ void k_bwd_begin(Consts* C) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < PSTRIDE) C->red[t] = 0.f;
-  if (t < 12) C->cam_acc[t] = 0.f;
-  if (t == 0) { C->cnt_samples = 0; C->pad_coef = 0.f; }
-}
-
 int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, size_t ws_bytes, const float* g_zdepth,
                           const float* g_min_sdf, const float* g_depth, const float* g_normal, float* g_latent, float* g_R,
                           float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
@@ -464,12 +462,17 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
   float* partial = cv.take<float>((size_t)tiles * PSTRIDE);
 
-  hipLaunchKernelGGL(k_bwd_begin, dim3((PSTRIDE + 255) / 256), dim3(256), 0, s, V.C);
-  LAUNCH_CHECK("k_bwd_begin");
-  hipLaunchKernelGGL(k_bwd_prep, grid1(P), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples);
-  LAUNCH_CHECK("k_bwd_prep");
-  hipLaunchKernelGGL(k_bwd_pad, dim3(1), dim3(64), 0, s, V, samples);
-  LAUNCH_CHECK("k_bwd_pad");
+  const int nblk = (P + 255) / 256;
+  const unsigned nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
+  float* chunk_part = cv.take<float>((size_t)nchunks * PSTRIDE);
+  BwdBlocks BB;
+  BB.cnt = cv.take<int32_t>(nblk); BB.off = cv.take<int32_t>(nblk); BB.acc = cv.take<float>((size_t)nblk * 16);
+  hipLaunchKernelGGL(k_bwd_prep<false>, dim3(nblk), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples, BB);
+  LAUNCH_CHECK("k_bwd_prep<count>");
+  hipLaunchKernelGGL(k_bwd_scan, dim3(1), dim3(256), 0, s, V, BB, nblk, samples);
+  LAUNCH_CHECK("k_bwd_scan");
+  hipLaunchKernelGGL(k_bwd_prep<true>, dim3(nblk), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples, BB);
+  LAUNCH_CHECK("k_bwd_prep<emit>");
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
@@ -481,11 +484,11 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
     else hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
   }
   LAUNCH_CHECK("k_bwd<full>");
-  const int chunk = 64;
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, (tiles + chunk - 1) / chunk), dim3(256), 0, s, V,
-                     (const float*)partial, chunk, TILE);
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, nchunks), dim3(256), 0, s, V, (const float*)partial, chunk_part,
+                     BWD_CHUNK, TILE);
   LAUNCH_CHECK("k_bwd_reduce");
-  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, g_latent, g_R, g_T);
+  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, (const float*)chunk_part, (int)nchunks, BWD_CHUNK, TILE, g_latent,
+                     g_R, g_T);
   LAUNCH_CHECK("k_bwd_final");
   return DISTR_OK;
 }

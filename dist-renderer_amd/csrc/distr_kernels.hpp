@@ -896,8 +896,17 @@ __device__ __forceinline__ void ray_backward_acc(const RayGeo& g, const float* g
 // Turns the upstream image gradients into (i) per-sample coefficients on the selected rows (ii) camera-gradient
 // terms that do not pass through the decoder (rays missing the sphere, renderer.py:863; the explicit R*n product,
 // renderer.py:978). SURVEY.md Appendix A.6 steps 1-3, 5.
+// Deterministic two-pass form: pass 0 (EMIT=false) counts the samples of every 256-pixel block and stores the block's
+// camera / pad partial sums; k_bwd_scan turns the counts into offsets and adds the partials in block order; pass 1
+// (EMIT=true) writes the samples at their fixed positions (block, row index k, thread). No atomics: the sample order
+// and every reduction order are reproducible, so gradients are bit-reproducible run to run.
+struct BwdBlocks { int32_t* cnt; int32_t* off; float* acc; };   // [nblk], [nblk], [nblk][16]
+
+template <bool EMIT>
 __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth, const float* g_min_sdf,
-                                                  const float* g_depth, const float* g_normal, Sample* samples) {
+                                                  const float* g_depth, const float* g_normal, Sample* samples, BwdBlocks B) {
+  __shared__ int32_t s_cnt[MAX_BS][4];
+  __shared__ float s_acc[4][16];
   const int px = blockIdx.x * 256 + threadIdx.x;
   Consts* C = V.C;
   const LevelView& L0 = V.lv[0];
@@ -962,76 +971,131 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
     }
   }
   const size_t P = (size_t)V.P;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // per-row coefficient of this pixel (0: no sample); pad rows accumulate into pad_acc
+  auto row_coef = [&](int k, int32_t& src, float& sv) -> float {
+    if (!in) return 0.f;
+    src = V.tk_src[k * P + px];
+    sv = src < 0 ? C->f_origin : V.tk_s[k * P + px];
+    float c = 0.f;
+    if (V.cfg.grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
+    if (k == 0 && V.cfg.grad_mask) c += gq;
+    return c;
+  };
   for (int k = 0; k < bs; ++k) {
-    Sample s; s.src = -1; s.zb = 0.f; s.coef = 0.f; s.flags = 0; s.sdf = 0.f; s.mblock = -1; s.pad0 = 0; s.pad1 = 0;
-    bool emit = false;
-    if (in) {
-      s.src = V.tk_src[k * P + px];
-      const float sv = s.src < 0 ? C->f_origin : V.tk_s[k * P + px];
-      float c = 0.f;
-      if (V.cfg.grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
-      if (k == 0 && V.cfg.grad_mask) c += gq;
-      if (c != 0.f) {
-        if (s.src < 0) {
-          pad_acc += c;
-        } else {
-          s.zb = V.tk_zb[k * P + px];
-          s.coef = c;
-          s.sdf = sv;
-          if (V.save_masks) {
-            const int lv = src_level(s.src);
-            s.mblock = (lv == 0) ? (int32_t)((int64_t)px * (bs + 1) + V.tk_slot[k * P + px])
-                                 : (int32_t)(V.mfine + V.moff[lv] + (int64_t)src_step(s.src) * V.lv[lv].n + src_ray(s.src));
-          }
-          const bool fine_row = src_level(s.src) == 0;
-          s.flags = (fine_row && !V.cfg.grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
-          emit = true;
-        }
-      }
-    }
+    int32_t src = -1; float sv = 0.f;
+    const float c = row_coef(k, src, sv);
+    const bool emit = (c != 0.f) && src >= 0;
+    if (!EMIT && c != 0.f && src < 0) pad_acc += c;
     const unsigned long long ball = __ballot(emit);
-    if (ball) {
-      const int lane = threadIdx.x & 63;
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&C->cnt_samples, __popcll(ball));
-      base = __shfl(base, 0);
-      if (emit) samples[base + __popcll(ball & ((1ull << lane) - 1ull))] = s;
+    if (lane == 0) s_cnt[k][wave] = __popcll(ball);
+  }
+  __syncthreads();
+  if (!EMIT) {
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int k = 0; k < bs; ++k) tot += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+      B.cnt[blockIdx.x] = tot;
     }
-  }
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    const float v = wave_sum(acc[i]);
-    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(&C->cam_acc[i], v);
+    for (int i = 0; i < 12; ++i) { const float v = wave_sum(acc[i]); if (lane == 0) s_acc[wave][i] = v; }
+    { const float v = wave_sum(pad_acc); if (lane == 0) s_acc[wave][12] = v; }
+    __syncthreads();
+    if (threadIdx.x < 13) B.acc[blockIdx.x * 16 + threadIdx.x] = ((s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + s_acc[2][threadIdx.x]) + s_acc[3][threadIdx.x];
+    return;
   }
-  const float pv = wave_sum(pad_acc);
-  if ((threadIdx.x & 63) == 0 && pv != 0.f) atomicAdd(&C->pad_coef, pv);
+  int base = B.off[blockIdx.x];
+  for (int k = 0; k < bs; ++k) {
+    int32_t src = -1; float sv = 0.f;
+    const float c = row_coef(k, src, sv);
+    const bool emit = (c != 0.f) && src >= 0;
+    const unsigned long long ball = __ballot(emit);
+    int wbase = base;
+    for (int w = 0; w < wave; ++w) wbase += s_cnt[k][w];
+    if (emit) {
+      Sample sm; sm.src = src; sm.zb = V.tk_zb[k * P + px]; sm.coef = c; sm.sdf = sv; sm.mblock = -1; sm.pad0 = 0; sm.pad1 = 0;
+      if (V.save_masks) {
+        const int lv = src_level(src);
+        sm.mblock = (lv == 0) ? (int32_t)((int64_t)px * (bs + 1) + V.tk_slot[k * P + px])
+                              : (int32_t)(V.mfine + V.moff[lv] + (int64_t)src_step(src) * V.lv[lv].n + src_ray(src));
+      }
+      const bool fine_row = src_level(src) == 0;
+      sm.flags = (fine_row && !V.cfg.grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
+      samples[wbase + __popcll(ball & ((1ull << lane) - 1ull))] = sm;
+    }
+    base += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+  }
 }
 
-// all padded rows sample the origin (points = 0, renderer.py:539): one combined sample, no camera dependence
-__global__ void k_bwd_pad(View V, Sample* samples) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && V.C->pad_coef != 0.f) {
-    Sample s; s.src = -1; s.zb = 0.f; s.coef = V.C->pad_coef; s.flags = 0; s.sdf = V.C->f_origin; s.mblock = (int32_t)V.morigin;
-    s.pad0 = 0; s.pad1 = 0;
-    samples[V.C->cnt_samples] = s;
+// exclusive scan of the per-block sample counts, ordered sum of the per-block partials, pad sample (one block)
+__global__ void __launch_bounds__(256) k_bwd_scan(View V, BwdBlocks B, int nblk, Sample* samples) {
+  __shared__ int32_t s_part[256];
+  __shared__ float s_accp[256][13];
+  const int t = threadIdx.x;
+  const int per = (nblk + 255) / 256;
+  const int b0 = t * per, b1 = min(nblk, b0 + per);
+  int sum = 0;
+  float a[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) a[i] = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    sum += B.cnt[b];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) a[i] += B.acc[b * 16 + i];
+  }
+  s_part[t] = sum;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) s_accp[t][i] = a[i];
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int c = s_part[i]; s_part[i] = run; run += c; }
+    V.C->cnt_samples = run;
+  }
+  __syncthreads();
+  int off = s_part[t];
+  for (int b = b0; b < b1; ++b) { B.off[b] = off; off += B.cnt[b]; }
+  if (t < 13) {
+    float v = 0.f;
+    for (int i = 0; i < 256; ++i) v += s_accp[i][t];
+    if (t < 12) V.C->cam_acc[t] = v; else V.C->pad_coef = v;
+  }
+  __syncthreads();
+  if (t == 0 && V.C->pad_coef != 0.f) {
+    // all padded rows sample the origin (points = 0, renderer.py:539): one combined sample, no camera dependence
+    Sample sm; sm.src = -1; sm.zb = 0.f; sm.coef = V.C->pad_coef; sm.flags = 0; sm.sdf = V.C->f_origin; sm.mblock = (int32_t)V.morigin;
+    sm.pad0 = 0; sm.pad1 = 0;
+    samples[V.C->cnt_samples] = sm;
     V.C->cnt_samples = V.C->cnt_samples + 1;
   }
 }
 
-// column sums of the tile partials (deterministic order), chunked over tiles
-__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, int chunk, int tile) {
+// column sums of the tile partials over one chunk of tiles -> chunk_part[chunk][col] (fixed order, no atomics)
+__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, float* chunk_part, int chunk, int tile) {
   const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= 2 * HID + 12) return;
   const int ntiles = (V.C->cnt_samples + tile - 1) / tile;
   const int t0 = blockIdx.y * chunk, t1 = min(ntiles, t0 + chunk);
-  if (col >= 2 * HID + 12 || t0 >= t1) return;
   float s = 0.f;
   for (int t = t0; t < t1; ++t) s += partial[(size_t)t * PSTRIDE + col];
-  atomicAdd(&V.C->red[col], s);
+  chunk_part[(size_t)blockIdx.y * PSTRIDE + col] = s;
 }
 
 // g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)
-__global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, float* g_latent, float* g_R, float* g_T) {
+__global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, const float* chunk_part, int nchunks_max, int chunk, int tile,
+                                                   float* g_latent, float* g_R, float* g_T) {
   const int k = threadIdx.x;
   Consts* C = V.C;
+  {
+    const int ntiles = (C->cnt_samples + tile - 1) / tile;
+    const int nchunks = min(nchunks_max, (ntiles + chunk - 1) / chunk);
+    for (int col = k; col < 2 * HID + 12; col += 256) {
+      float s = 0.f;
+      for (int c = 0; c < nchunks; ++c) s += chunk_part[(size_t)c * PSTRIDE + col];
+      C->red[col] = s;
+    }
+  }
+  __syncthreads();
   const float* sd0 = C->red;
   const float* sd4 = C->red + HID;
   float a = 0.f;

@@ -184,10 +184,10 @@ def test_c3_full_size_properties(engine, fixture_decoder):
     kw = dict(march_step=50, buffer_size=3, use_depth2normal=True)
     a = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='pyramid_recursive', **kw)
     b = helpers.hip_render(engine, H, W, K, R, T, latent, marcher='pyramid_recursive', **kw)
-    # idempotence: same inputs -> same bits (forward is deterministic; compaction order does not enter the values)
-    for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal'):
+    # idempotence: same inputs -> same bits, forward AND backward (live-ray compaction order never enters a value; the
+    # gradient-sample list and every reduction of the backward have a fixed order)
+    for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
         assert np.array_equal(a[k], b[k]), k
-    assert np.abs(a['g_latent'] - b['g_latent']).max() <= 1e-4 * np.abs(a['g_latent']).max()   # atomics: order only
     m = a['mask'].reshape(H, W).astype(bool)
     assert 0.15 * H * W < m.sum() < 0.40 * H * W
     # silhouette is inside the unit-sphere footprint, depth is within the sphere's extent, normals are unit length
@@ -375,7 +375,7 @@ def test_adam_single_view_matches_reference_golden(fixture_decoder):
     print('ours\n', hist, '\nreference\n', ref[:, :6])
     # Observed agreement: 3-6 significant digits. The first iteration is exact to ~1e-7; later ones depend on Adam, whose
     # first update is lr*sign(g): a coordinate whose gradient is ~0 can flip sign through float-summation order alone
-    # (the backward's tile partial sums are combined with float atomics), which moves the loss by ~1e-5.
+    # (ours vs the reference's autograd), which moves the loss by ~1e-5.
     assert np.abs(hist[0, :] - ref[0, :6]).max() <= 2e-6
     assert np.abs(hist[:, 0] - ref[:, 0]).max() <= 1e-2 * ref[:, 0].max()          # depth loss
     assert np.abs(hist[:, 1] - ref[:, 1]).max() <= 5e-4                             # normal (cosine) loss
