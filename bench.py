@@ -73,8 +73,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--marcher', default='pyramid_recursive')
+    ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
+    ap.add_argument('--march-step', type=int, default=50)
     args = ap.parse_args()
 
+    global H, W, MARCH_STEP
+    H = W = args.size
+    MARCH_STEP = args.march_step
     from distr import binding, fixture, functions, parallel
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
@@ -107,7 +112,7 @@ def main():
             Tt.grad = None
             z, mask, q, depth, normal = functions.render_call(eng, cfg, lat, Rt, Tt)
             mb = mask.reshape(H, W).bool()
-            L = (depth * wd)[mb].sum() + (q.reshape(H, W) * wq).sum() + (normal * wn).sum()
+            L = torch.where(mb, depth * wd, torch.zeros_like(depth)).sum() + (q.reshape(H, W) * wq).sum() + (normal * wn).sum()
             total = L if total is None else total + L
         total.backward()
         loss_buf.copy_(total.detach().reshape(1))
@@ -159,12 +164,12 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         rays = float(args.gpus) * H * W * args.steps
         out = {
-            'metric': 'rays/sec (fwd+bwd) at 512x512, 50 march steps, DeepSDF 8x512',
+            'metric': 'rays/sec (fwd+bwd) at %dx%d, %d march steps, DeepSDF 8x512' % (H, W, MARCH_STEP),
             'value': rays / elapsed, 'unit': 'rays/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)',
-            'config': {'workload': 'C3: %dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
-                                   'fwd+loss+bwd, 1 view per GPU' % (H, W, MARCH_STEP, args.marcher, BUFFER_SIZE, RATIO),
+            'config': {'workload': '%s%dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
+                                   'fwd+loss+bwd, 1 view per GPU' % ('C3: ' if (H, MARCH_STEP) == (512, 50) else '', H, W, MARCH_STEP, args.marcher, BUFFER_SIZE, RATIO),
                        'parallelism': 'view-parallel x%d (RCCL all-reduce of packed latent grad)' % args.gpus,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
                        'decoder_evals_per_forward': stats['num_point_evals'], 'grad_samples_per_backward': None,

@@ -411,3 +411,28 @@ def test_bulk_sdf_grid(cpu_oracle, fixture_decoder):
     assert torch.equal(torch.sign(fast), torch.sign(full))                      # same inside/outside everywhere
     big = create_sdf_grid(dec, lat, 128)                                        # 2.1 M points in one launch
     assert big.shape == (128, 128, 128) and torch.isfinite(big).all()
+
+
+def test_rccl_allreduce_packed_single_rank():
+    """The collective path of bench.py --gpus N (backend 'nccl' = RCCL) on the one GPU this box has: process-group
+    init, packed all-reduce, max-reduce and barrier must work (world size 1: sums are identities)."""
+    import torch
+    import torch.distributed as dist
+    from distr import parallel
+    if dist.is_initialized():
+        pytest.skip('process group already initialised')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        g = torch.arange(256, dtype=torch.float32, device='cuda').reshape(1, 256)
+        loss = torch.tensor([3.5], device='cuda')
+        t = dist.all_reduce(torch.ones(4, device='cuda'))          # raw RCCL call
+        parallel.allreduce_packed([g, loss])                        # world size 1 -> untouched
+        assert float(g.sum()) == 255 * 128 and float(loss) == 3.5
+        x = torch.ones(8, device='cuda')
+        dist.all_reduce(x)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert float(x.sum()) == 8.0
+    finally:
+        dist.destroy_process_group()
