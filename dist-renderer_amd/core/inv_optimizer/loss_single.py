@@ -1,32 +1,45 @@
-"""compute_all_loss: one render + the single-view loss pack (reference: core/inv_optimizer/loss_single.py:7-65)."""
+"""Single-view loss pack: one `SDFRenderer.render` call followed by the silhouette / depth / normal / L2 terms.
+
+Drop-in for `compute_all_loss` of the reference (core/inv_optimizer/loss_single.py:7-65): same arguments, same
+returned dict keys ('mask_gt', 'mask_out', 'depth', 'normal', 'l2reg') and the same (pack, visualizer) tuple."""
 import torch
 
-from core.utils.loss_utils import compute_loss_depth, compute_loss_mask, compute_loss_normal, downsize_img_tensor
+from core.utils import loss_utils as LU
+
+_TERMS = ('depth', 'normal', 'silhouette')
+
+
+def _enabled(grad_settings, gt_pack):
+    """A term back-propagates only if it is switched on AND its ground truth is present."""
+    cfg = dict.fromkeys(_TERMS, True) if grad_settings is None else dict(grad_settings)
+    return {t: bool(cfg.get(t, False)) and gt_pack.get(t) is not None for t in _TERMS}
+
+
+def _maybe_detach(value, keep_grad):
+    return value if keep_grad else value.detach()
 
 
 def compute_all_loss(sdf_renderer, latent_tensor, extrinsic, gt_pack, threshold=5e-5, profile=False, visualizer=None,
                      ray_marching_type='pyramid_recursive', grad_settings=None):
-    want = {'depth': True, 'normal': True, 'silhouette': True} if grad_settings is None else dict(grad_settings)
-    for key in want:
-        want[key] = bool(want[key]) and (gt_pack.get(key) is not None)
-    depth, normal, mask, min_sdf = sdf_renderer.render(latent_tensor, extrinsic[:, :3], extrinsic[:, 3], profile=profile,
-                                                       sample_index_type='min_abs', ray_marching_type=ray_marching_type,
-                                                       no_grad_depth=not want['depth'], no_grad_normal=not want['normal'])
-    ratio = next(iter(gt_pack.values())).shape[0] / depth.shape[0]
-    gt = {k: downsize_img_tensor(v, ratio) for k, v in gt_pack.items() if v is not None}
-    pack = {'mask_gt': 0.0, 'mask_out': 0.0, 'depth': 0.0, 'normal': 0.0}
-    if 'silhouette' in gt:
-        pack['mask_gt'], pack['mask_out'], visualizer = compute_loss_mask(min_sdf, mask, gt['silhouette'], threshold=threshold,
-                                                                          visualizer=visualizer)
-        if not want['silhouette']:
-            pack['mask_gt'], pack['mask_out'] = pack['mask_gt'].detach(), pack['mask_out'].detach()
+    on = _enabled(grad_settings, gt_pack)
+    R, T = extrinsic[:, :3], extrinsic[:, 3]
+    rendered = sdf_renderer.render(latent_tensor, R, T, profile=profile, ray_marching_type=ray_marching_type,
+                                   no_grad_depth=not on['depth'], no_grad_normal=not on['normal'])
+    depth, normal, mask, min_sdf = rendered
+    # ground truth may come at a multiple of the render resolution (multi-scale renderer lists)
+    scale = next(iter(gt_pack.values())).shape[0] / depth.shape[0]
+    gt = {name: LU.downsize_img_tensor(img, scale) for name, img in gt_pack.items() if img is not None}
+    sil = gt.get('silhouette')
+
+    pack = dict(mask_gt=0.0, mask_out=0.0, depth=0.0, normal=0.0)
+    if sil is not None:
+        miss, extra, visualizer = LU.compute_loss_mask(min_sdf, mask, sil, threshold=threshold, visualizer=visualizer)
+        pack['mask_gt'], pack['mask_out'] = _maybe_detach(miss, on['silhouette']), _maybe_detach(extra, on['silhouette'])
     if 'depth' in gt:
-        pack['depth'], visualizer = compute_loss_depth(depth, mask, gt['depth'], gt['silhouette'], visualizer=visualizer)
-        if not want['depth']:
-            pack['depth'] = pack['depth'].detach()
+        value, visualizer = LU.compute_loss_depth(depth, mask, gt['depth'], sil, visualizer=visualizer)
+        pack['depth'] = _maybe_detach(value, on['depth'])
     if 'normal' in gt:
-        pack['normal'], visualizer = compute_loss_normal(normal, mask, gt['normal'], gt['silhouette'], visualizer=visualizer)
-        if not want['normal']:
-            pack['normal'] = pack['normal'].detach()
-    pack['l2reg'] = torch.mean(latent_tensor.pow(2))
+        value, visualizer = LU.compute_loss_normal(normal, mask, gt['normal'], sil, visualizer=visualizer)
+        pack['normal'] = _maybe_detach(value, on['normal'])
+    pack['l2reg'] = latent_tensor.pow(2).mean()
     return pack, visualizer

@@ -172,11 +172,12 @@ if __name__ == '__main__':
         rsn = np.random.RandomState(99)
         Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
         noise_floor_c2(rh.build_reference_decoder(Ws, bs), rh.build_reference_decoder(Wn, bs), latent)
-    elif sys.argv[1:2] == ['--g5']:
+    elif sys.argv[1:2] in (['--g5'], ['--g4']):
         pass
     else:
         main()
         golden_g5()
+        golden_g4()
 
 
 def golden_g5():
@@ -217,3 +218,36 @@ def golden_g5():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == '--g5':
     golden_g5()
+
+
+def golden_g4():
+    """G4: SDFRenderer_warp.render_warp (renderer_warp.py:103-144) on two synthetic views with procedural images:
+    loss_color, masks, min-sdf maps, visualisation normal/depth and the latent gradient of loss_color."""
+    rh.install_shims()
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    SDFRenderer_warp = rh.reference_modules()[1]
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    R1, T1 = fixture.make_camera(10, 15, 1.6, 0)
+    R2, T2 = fixture.make_camera(22, 15, 1.6, 0)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    img1 = np.stack([0.5 + 0.5 * np.sin(xx / 3.0), 0.5 + 0.5 * np.cos(yy / 4.0), ((xx // 6 + yy // 6) % 2).astype(np.float64)], -1).astype(np.float32)
+    img2 = np.stack([0.5 + 0.5 * np.sin(xx / 3.0 + 0.7), 0.5 + 0.5 * np.cos(yy / 4.0 - 0.3), ((xx // 5 + yy // 7) % 2).astype(np.float64)], -1).astype(np.float32)
+    r = SDFRenderer_warp(dec, K, img_hw=(H, W), march_step=50, buffer_size=1, use_gpu=False)
+    r.device = torch.device('cpu')
+    lat = torch.from_numpy(latent).clone().requires_grad_(True)
+    out = r.render_warp(lat, torch.from_numpy(R1), torch.from_numpy(T1), torch.from_numpy(R2), torch.from_numpy(T2),
+                        torch.from_numpy(img1), torch.from_numpy(img2), no_grad_normal=True)
+    loss_color, c1, c2, m1, m2, q1, q2, n1, d1 = out
+    loss_color.backward()
+    np.savez_compressed(os.path.join(OUT, 'g4_render_warp.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent, K=K,
+                        R1=R1, T1=T1, R2=R2, T2=T2, img1=img1, img2=img2, H=H, W=W, march_step=50, buffer_size=1,
+                        loss_color=np.float64(loss_color.item()), color_valid_1=c1.detach().numpy(), color_valid_2=c2.detach().numpy(),
+                        mask1=m1.numpy(), mask2=m2.numpy(), min_sdf1=q1.detach().numpy(), min_sdf2=q2.detach().numpy(),
+                        normal1=n1.detach().numpy(), depth1=d1.detach().numpy(), g_latent=lat.grad.numpy())
+    print('g4 loss_color', loss_color.item(), 'valid', int(m1.sum()), int(m2.sum()), 'glat', float(lat.grad.norm()))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == '--g4':
+    golden_g4()
