@@ -353,7 +353,10 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   memset(&A, 0, sizeof(A));
   A.V = V;
   A.t16 = 0; A.t32 = 0; A.which = 64;
-  bool origin_done = false;
+  // f(origin) (padded rows) is evaluated by one extra workgroup of ONE march launch: with the tile-size split it rides on
+  // the 16-ray launch of the last step (free: a tail step); otherwise on the first march launch of the render
+  const bool split_cfg = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0 && ctx->tail16_threshold > 0;
+  bool origin_done = split_cfg;
   for (int l = V.nlev - 1; l >= 1; --l) {
     hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
     LAUNCH_CHECK("k_coarse_init");
@@ -407,7 +410,8 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       }
       if (A.t16 > 0) {
         A2.which = 16;
-        const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16);
+        A2.origin_tile = (split_cfg && st == V.fine_steps - 1) ? 1 : 0;
+        const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
         if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
         else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
       }

@@ -498,10 +498,13 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
     count = V.C->cnt_live[A.step];
     list = V.live[A.step & 1];
   }
+  // the last workgroup of the launch that carries `origin_tile` evaluates f(0,0,0) (sample point of padded rows): on a
+  // 16-ray tile of a tail step it rides along for free instead of adding a 257th tile to a full round elsewhere
+  const bool origin = (MODE == MODE_FINE) && A.origin_tile && tile == (int)gridDim.x - 1;
   int64_t lo = 0, hi = count;
   if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
   const int64_t base = lo + (int64_t)tile * TILE;
-  if (base >= hi) return;
+  if (!origin && base >= hi) return;
   count = hi;
 
   int32_t id = -1;
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   if (tid < TILE) {
     float p[3] = {0.f, 0.f, 0.f};
     const int64_t r = base + tid;
-    valid = r < count;
+    valid = !origin && r < count;
     if (valid) {
       if (MODE == MODE_EVAL) {
         id = (int32_t)r;
@@ -537,7 +540,9 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   long long mblock = -1;
   if (tid < 64) {
     const float s = tanh_spec(pre);
-    if (MODE == MODE_EVAL) {
+    if (origin) {
+      if (tid == 0) { V.C->f_origin = s; mblock = V.morigin; }
+    } else if (MODE == MODE_EVAL) {
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
     } else {
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;

@@ -31,11 +31,20 @@ def main():
         march = [(r['Kernel_Name'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r.get('Grid_Size', ''), r.get('VGPR_Count', ''),
                   r.get('Accum_VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Scratch_Size', '')) for r in rows if 'k_march' in r['Kernel_Name']]
         if march:
-            lines.append('## k_march launches in order (us), last forward of the run, with register/LDS usage of the dispatch\n')
-            n = 50 if len(march) >= 50 else len(march)
-            last = march[-n:]
-            lines.append('VGPR %s AGPR %s LDS %s scratch %s' % (last[0][3], last[0][4], last[0][5], last[0][6]))
-            lines.append(' '.join('%.0f' % m[1] for m in last))
+            lines.append('## k_march-family launches of the last forward in launch order: <tile size>:<us> (16/32/64-ray kernels; c = coarse level)\n')
+            def tag(name):
+                if 'k_march16' in name: return '16'
+                if 'k_march<1' in name: return 'c'
+                return '32' if ', 1, ' in name else '64'
+            # last forward = everything after the last coarse-level launch block
+            idx = [i for i, m in enumerate(march) if 'k_march<1' in m[0]]
+            start = 0
+            if idx:
+                j = idx[-1]
+                while j > 0 and 'k_march<1' in march[j - 1][0]: j -= 1
+                start = j
+            last = march[start:]
+            lines.append(' '.join('%s:%.0f' % (tag(m[0]), m[1]) for m in last))
             lines.append('')
         tot = defaultdict(float)
         t0, t1 = int(rows[0]['Start_Timestamp']), max(int(r['End_Timestamp']) for r in rows)
