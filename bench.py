@@ -135,6 +135,20 @@ def main():
     eng.ctx.profile_enable(False)
     elapsed = parallel.allreduce_max_scalar(elapsed, device=dev)
 
+    # forward / backward split of one step (outside the timed region; hipEvents on the current stream)
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return r, e0.elapsed_time(e1)
+    Rt0, Tt0 = cams[0]
+    outs0, fwd_ms = timed(lambda: functions.render_call(eng, cfg, lat, Rt0, Tt0))
+    Lsplit = torch.where(outs0[1].reshape(H, W).bool(), outs0[3] * wd, torch.zeros_like(outs0[3])).sum() + \
+        (outs0[2].reshape(H, W) * wq).sum() + (outs0[4] * wn).sum()
+    _, bwd_ms = timed(lambda: Lsplit.backward())
+
     # counters of one forward (identical every step: same inputs)
     with torch.no_grad():
         fwd_bytes, _ = eng.ctx.workspace_bytes(cfg)
@@ -172,8 +186,9 @@ def main():
                                    'fwd+loss+bwd, 1 view per GPU' % ('C3: ' if (H, MARCH_STEP) == (512, 50) else '', H, W, MARCH_STEP, args.marcher, BUFFER_SIZE, RATIO),
                        'parallelism': 'view-parallel x%d (RCCL all-reduce of packed latent grad)' % args.gpus,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
-                       'decoder_evals_per_forward': stats['num_point_evals'], 'grad_samples_per_backward': None,
-                       'march_launches_per_forward': stats['num_march_launches']},
+                       'decoder_evals_per_forward': stats['num_point_evals'],
+                       'march_launches_per_forward': stats['num_march_launches'],
+                       'forward_ms_one_view': fwd_ms, 'backward_ms_one_view': bwd_ms},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'fabric-side bytes per march step from a separate rocprofv3 PMC pass (profiles/r01_traffic.json)',
