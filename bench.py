@@ -69,8 +69,8 @@ def cpu_baseline(fixture, Ws, bs, latent, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
@@ -188,7 +188,8 @@ def main():
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
                        'decoder_evals_per_forward': stats['num_point_evals'],
                        'march_launches_per_forward': stats['num_march_launches'],
-                       'forward_ms_one_view': fwd_ms, 'backward_ms_one_view': bwd_ms},
+                       'forward_ms_one_view': fwd_ms, 'backward_ms_one_view': bwd_ms,
+                       'decoder_evals_per_s_march': evals / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'fabric-side bytes per march step from a separate rocprofv3 PMC pass (profiles/r01_traffic.json)',

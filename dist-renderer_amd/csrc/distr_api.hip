@@ -110,23 +110,36 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
   if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
+  if (c->rows != 0) {
+    if (c->rows < 0 || c->row0 < 0 || c->row0 + c->rows > c->H) return fail(ctx, DISTR_ERR_INVALID_ARG, "row band [%d,+%d) outside the %d-row image", c->row0, c->rows, c->H);
+    if ((c->row0 & 3) || ((c->rows & 3) && c->row0 + c->rows != c->H))
+      return fail(ctx, DISTR_ERR_INVALID_ARG, "row band [%d,+%d) must start on a multiple of 4 and span a multiple of 4 rows (or end at H)", c->row0, c->rows);
+  }
   return DISTR_OK;
 }
+
+inline int band_rows(const distr_render_cfg& c) { return c.rows > 0 ? c.rows : c.H; }
+inline int band_row0(const distr_render_cfg& c) { return c.rows > 0 ? c.row0 : 0; }
 
 // Lays the forward workspace out; with base==nullptr only sizes are computed.
 size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks) {
   Carver cv(base);
   memset(&V, 0, sizeof(V));
   V.cfg = c;
-  V.P = c.H * c.W;
+  V.rows = band_rows(c); V.row0 = band_row0(c);
+  V.band = (V.rows != c.H) ? 1 : 0;
+  V.P = V.rows * c.W;
   V.pyramid = (c.marcher == DISTR_MARCH_PYRAMID_RECURSIVE) ? 1 : 0;
   V.nlev = V.pyramid ? 3 : 1;
   V.fine_steps = c.march_step - (V.pyramid ? c.coarse_steps[0] + c.coarse_steps[1] : 0);
   V.C = cv.take<Consts>(1);
-  V.lv[0].h = c.H; V.lv[0].w = c.W; V.lv[0].scale = 1.f; V.lv[0].off = 0.f;
+  V.lv[0].h = V.rows; V.lv[0].w = c.W; V.lv[0].scale = 1.f; V.lv[0].off = 0.f;
+  V.lv[0].y0 = V.row0; V.lv[0].full_h = c.H;
   for (int l = 1; l < V.nlev; ++l) {
     V.lv[l].h = (V.lv[l - 1].h + 1) / 2;
     V.lv[l].w = (V.lv[l - 1].w + 1) / 2;
+    V.lv[l].y0 = V.lv[l - 1].y0 / 2;                 // row0 is a multiple of 4: exact
+    V.lv[l].full_h = (V.lv[l - 1].full_h + 1) / 2;
     V.lv[l].scale = V.lv[l - 1].scale * 2.f;
     V.lv[l].off = (V.lv[l].scale - 1.f) / 2.f;
   }
@@ -169,7 +182,7 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
 constexpr int BWD_CHUNK = 64;   // tiles per reduction chunk
 
 size_t bwd_bytes(const distr_render_cfg& c) {
-  const size_t P = (size_t)c.H * c.W;
+  const size_t P = (size_t)band_rows(c) * c.W;
   const size_t smax = P * c.buffer_size + 1;
   const size_t tiles = (smax + 31) / 32;
   const size_t nblk = (P + 255) / 256, nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
@@ -347,6 +360,10 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   for (int l = 0; l < V.nlev; ++l) {
     hipLaunchKernelGGL(k_setup_level, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
     LAUNCH_CHECK("k_setup_level");
+    if (V.band) {
+      hipLaunchKernelGGL(k_maxinit_full, grid1((int64_t)V.lv[l].full_h * V.lv[l].w), dim3(256), 0, s, V, l);
+      LAUNCH_CHECK("k_maxinit_full");
+    }
   }
   MarchTimer timer(ctx, s);
   MarchArgs A;
@@ -412,8 +429,12 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
         A2.which = 16;
         A2.origin_tile = (split_cfg && st == V.fine_steps - 1) ? 1 : 0;
         const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
-        if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
-        else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), 0, s, A2, D, ctx->D16);
+        // a 16-ray tile keeps its SIMDs' MFMA pipes busy: two of them on one CU take twice as long. The launch that carries the
+        // origin tile asks for 48 KiB of (unused) dynamic LDS so that only one workgroup fits per CU and the extra tile goes
+        // to an idle CU instead of doubling up with a live one.
+        const unsigned pad16 = A2.origin_tile ? 48u * 1024u : 0u;
+        if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
+        else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
       }
     }
     timer.end();

@@ -39,6 +39,7 @@ struct Consts {
 
 struct LevelView {
   int32_t h, w, n, steps;
+  int32_t y0, full_h;     // row band: first row of this level's grid in the full image's level grid; rows of the full grid
   float scale, off;       // pixel centre = scale*i + off  (renderer.py:616-617)
   uint8_t* valid;
   int32_t* list;
@@ -54,6 +55,7 @@ struct View {
   Consts* C;
   LevelView lv[3];
   int32_t nlev, P, fine_steps, pyramid;
+  int32_t row0, rows, band;   // band: rows [row0, row0+rows) of cfg.H are rendered (band != 0: a proper sub-range)
   int32_t* live[2];
   float *m, *init_now, *maxbound, *minabs, *first_sdf;
   float *tk_s, *tk_zb, *tk_za;   // [bs][P] selected rows: sdf, depth before, depth after (pyramid) / marching depth after
@@ -121,7 +123,7 @@ __device__ __forceinline__ void make_point(const float* M, const float* c, const
 
 __device__ __forceinline__ void level_center(const LevelView& L, int i, float& px, float& py) {
   px = L.scale * (float)(i % L.w) + L.off;
-  py = L.scale * (float)(i / L.w) + L.off;
+  py = L.scale * (float)(i / L.w + L.y0) + L.off;
 }
 
 struct CamRegs { float R[9], c[3], cdist; };
@@ -222,9 +224,23 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
         }
     }
     L.valid[i] = valid ? 1 : 0;
-    if (s.in && !inside) atomicMax(&C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
+    if (!V.band && s.in && !inside) atomicMax(&C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
   }
   wave_append(valid, i, L.list, &C->cnt_level[lvl]);
+}
+
+// row band: the fill depth of rays that miss the sphere is the maximum over the FULL image's level grid
+// (renderer.py:268-270), not over the band -> one cheap pass over all of the level's pixel centres
+__global__ void __launch_bounds__(256) k_maxinit_full(View V, int lvl) {
+  const LevelView& L = V.lv[lvl];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L.full_h * L.w) return;
+  const CamRegs cam = load_cam(V.C);
+  if (cam.cdist < V.cfg.radius) return;
+  const float px = L.scale * (float)(i % L.w) + L.off, py = L.scale * (float)(i / L.w) + L.off;
+  const RayGeo g = make_ray(V.cfg.K_inv, cam.R, px, py);
+  const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+  if (s.in) atomicMax(&V.C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
 }
 
 // start depth of a coarse level: unit-sphere entry (coarsest) or the parent's last marched depth (renderer.py:766-769)
@@ -659,18 +675,25 @@ __device__ __forceinline__ float bg_depth(const float* dp, int i) {
   return ((d > 1e5f) || (d == 0.f)) ? 0.f : d;
 }
 
+// rows whose vertical neighbours exist: not an image border row (render_utils.py:31-37 leaves those at zero) and, for a
+// row band, not the band's first/last row (halo rows, cropped by the caller)
+__device__ __forceinline__ bool d2n_row_inner(const View& V, int y) {
+  const int gy = y + V.row0;
+  return gy >= 1 && gy <= V.cfg.H - 2 && y >= 1 && y <= V.rows - 2;
+}
+
 // depth2normal (core/utils/render_utils.py:9-43) incl. its in-place zeroing of the background depth
 __global__ void __launch_bounds__(256) k_depth2normal(View V, float* depth, float* normal) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= V.P) return;
-  const int Ww = V.cfg.W, Hh = V.cfg.H;
+  const int Ww = V.cfg.W;
   const int y = i / Ww, x = i % Ww;
   const float* dp = V.depth_pre;
   const float d0 = bg_depth(dp, i);
   if (depth) depth[i] = d0;
   float n0 = 0.f, n1 = 0.f, n2 = 0.f;
   if (d0 != 0.f) {
-    const bool ix = (x >= 1 && x <= Ww - 2), iy = (y >= 1 && y <= Hh - 2);
+    const bool ix = (x >= 1 && x <= Ww - 2), iy = d2n_row_inner(V, y);
     const float l = ix ? bg_depth(dp, i - 1) : 0.f, r = ix ? bg_depth(dp, i + 1) : 0.f;
     const float u = iy ? bg_depth(dp, i - Ww) : 0.f, d = iy ? bg_depth(dp, i + Ww) : 0.f;
     const float dzdx = (r - l) * V.cfg.fx / 2.0f, dzdy = (d - u) * V.cfg.fy / 2.0f;
@@ -872,10 +895,10 @@ __global__ void __launch_bounds__(256) k_mask_list(int P, const uint8_t* mask, i
 // ------------------------------------------------------------------------------------------ backward: image side
 __device__ __forceinline__ void d2n_gv(const View& V, const float* g_normal, int i, float& gv0, float& gv1) {
   // gradient wrt (dzdx, dzdy) of pixel i of depth2normal's normalised vector
-  const int Ww = V.cfg.W, Hh = V.cfg.H;
+  const int Ww = V.cfg.W;
   const int y = i / Ww, x = i % Ww;
   const float* dp = V.depth_pre;
-  const bool ix = (x >= 1 && x <= Ww - 2), iy = (y >= 1 && y <= Hh - 2);
+  const bool ix = (x >= 1 && x <= Ww - 2), iy = d2n_row_inner(V, y);
   const float l = ix ? bg_depth(dp, i - 1) : 0.f, r = ix ? bg_depth(dp, i + 1) : 0.f;
   const float u = iy ? bg_depth(dp, i - Ww) : 0.f, d = iy ? bg_depth(dp, i + Ww) : 0.f;
   const float v0 = (r - l) * V.cfg.fx / 2.0f, v1 = (d - u) * V.cfg.fy / 2.0f;
@@ -952,13 +975,13 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
             if (bg_depth(V.depth_pre, px) == 0.f) {
               gd_eff = 0.f;
             } else if (g_normal) {
-              const int Ww = V.cfg.W, Hh = V.cfg.H;
+              const int Ww = V.cfg.W;
               const int y = px / Ww, x = px % Ww;
               float a0, a1, add = 0.f;
               if (x - 1 >= 1 && x - 1 <= Ww - 2 && bg_depth(V.depth_pre, px - 1) != 0.f) { d2n_gv(V, g_normal, px - 1, a0, a1); add += a0 * V.cfg.fx / 2.0f; }
               if (x + 1 >= 1 && x + 1 <= Ww - 2 && bg_depth(V.depth_pre, px + 1) != 0.f) { d2n_gv(V, g_normal, px + 1, a0, a1); add -= a0 * V.cfg.fx / 2.0f; }
-              if (y - 1 >= 1 && y - 1 <= Hh - 2 && bg_depth(V.depth_pre, px - Ww) != 0.f) { d2n_gv(V, g_normal, px - Ww, a0, a1); add += a1 * V.cfg.fy / 2.0f; }
-              if (y + 1 >= 1 && y + 1 <= Hh - 2 && bg_depth(V.depth_pre, px + Ww) != 0.f) { d2n_gv(V, g_normal, px + Ww, a0, a1); add -= a1 * V.cfg.fy / 2.0f; }
+              if (y >= 1 && d2n_row_inner(V, y - 1) && bg_depth(V.depth_pre, px - Ww) != 0.f) { d2n_gv(V, g_normal, px - Ww, a0, a1); add += a1 * V.cfg.fy / 2.0f; }
+              if (y + 1 < V.rows && d2n_row_inner(V, y + 1) && bg_depth(V.depth_pre, px + Ww) != 0.f) { d2n_gv(V, g_normal, px + Ww, a0, a1); add -= a1 * V.cfg.fy / 2.0f; }
               gd_eff += add;
             }
           }

@@ -43,7 +43,13 @@ class RenderCfg(C.Structure):
         ('use_depth2normal', C.c_int32), ('normalize_normal', C.c_int32), ('want_normal', C.c_int32),
         ('grad_depth', C.c_int32), ('grad_mask', C.c_int32), ('grad_camera', C.c_int32),
         ('save_for_backward', C.c_int32),
+        ('row0', C.c_int32), ('rows', C.c_int32),
     ]
+
+    @property
+    def band_rows(self):
+        """Number of image rows this cfg renders (H unless a row band is set)."""
+        return self.rows if self.rows > 0 else self.H
 
     def clone(self):
         c = RenderCfg()
@@ -112,7 +118,7 @@ def lib():
 def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
              marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
              use_depth2normal=False, normalize_normal=True, want_normal=True,
-             grad_depth=True, grad_mask=True, grad_camera=True):
+             grad_depth=True, grad_mask=True, grad_camera=True, band=None):
     """Host-side part of SDFRenderer.__init__ (core/sdfrenderer/renderer.py:13-59) as a C struct."""
     cfg = RenderCfg()
     cfg.H, cfg.W = int(img_hw[0]), int(img_hw[1])
@@ -138,6 +144,8 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
     cfg.use_depth2normal, cfg.normalize_normal, cfg.want_normal = int(use_depth2normal), int(normalize_normal), int(want_normal)
     cfg.grad_depth, cfg.grad_mask, cfg.grad_camera = int(grad_depth), int(grad_mask), int(grad_camera)
     cfg.save_for_backward = 1
+    if band is not None:       # (row0, rows): render only these image rows (strong scaling of one view, include/distr.h)
+        cfg.row0, cfg.rows = int(band[0]), int(band[1])
     return cfg
 
 

@@ -56,7 +56,7 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, latent, R, T, engine, cfg):
         dev = engine.device
-        H, W = cfg.H, cfg.W
+        H, W = cfg.band_rows, cfg.W
         P = H * W
         lat, Rc, Tc = _f32c(latent, dev).reshape(-1), _f32c(R, dev).reshape(-1), _f32c(T, dev).reshape(-1)
         if lat.numel() != 256 or Rc.numel() != 9 or Tc.numel() != 3:
@@ -91,7 +91,7 @@ class RenderFunction(torch.autograd.Function):
             if g is None or g.numel() != n:
                 return None
             return g.to(dtype=torch.float32).contiguous()
-        P = cfg.H * cfg.W
+        P = cfg.band_rows * cfg.W
         gz, gq = prep(g_zdepth, P), prep(g_min_sdf, P)
         gd, gn = (prep(g_depth, P), prep(g_normal, 3 * P)) if cfg.want_normal else (None, None)
         g_lat = torch.empty(256, dtype=torch.float32, device=dev)
@@ -114,12 +114,37 @@ def render_call(engine, cfg, latent, R, T):
     return RenderFunction.apply(latent, R, T, engine, cfg)
 
 
+HALO = 4   # rows; depth2normal needs 1, the 4x4 pyramid parents need the band aligned to 4
+
+
+def render_band_call(engine, cfg, latent, R, T, r0, r1):
+    """Rows [r0, r1) of the render `cfg` describes (r0, r1 multiples of 4, or r1 == H): what one rank computes when one
+    large view is split over several GPUs (row-band tiles whose height is a multiple of 4 px, halo
+    recomputed locally for depth2normal). Renders the band plus a HALO-row halo and crops it; autograd through the crop
+    zero-pads the halo's upstream gradients, so the sum over a partition of [0, H) of the bands' input gradients equals
+    the full render's. Returns (zdepth (n*W), mask (n*W) uint8, min_sdf (n*W), depth (n, W), normal (n, W, 3)), n = r1 - r0;
+    every value is bit-identical to the same pixel of the full render."""
+    H, W = cfg.H, cfg.W
+    if not (0 <= r0 < r1 <= H) or (r0 & 3) or ((r1 & 3) and r1 != H):
+        raise ValueError('band [%d, %d) must lie in [0, %d) on multiples of 4 (or end at H)' % (r0, r1, H))
+    halo = HALO if (cfg.want_normal and cfg.use_depth2normal) else 0
+    b0, b1 = max(0, r0 - halo), min(H, r1 + halo)
+    bcfg = cfg.clone()
+    bcfg.row0, bcfg.rows = b0, b1 - b0
+    z, mask, q, depth, normal = render_call(engine, bcfg, latent, R, T)
+    lo, n = r0 - b0, r1 - r0
+    z, mask, q = (t.reshape(b1 - b0, W)[lo:lo + n].reshape(-1) for t in (z, mask, q))
+    if cfg.want_normal:
+        depth, normal = depth[lo:lo + n], normal[lo:lo + n]
+    return z, mask, q, depth, normal
+
+
 def render_normal_call(engine, cfg, latent, R, T, zdepth, mask):
     """SDFRenderer.render_normal forward (renderer.py:880-910) -> (3, P). Gradient-free: for ReLU decoders the
     normalised SDF gradient is piecewise constant in (latent, point), its autograd contribution is identically ~0
     (SURVEY.md A.6-1)."""
     dev = engine.device
-    P = cfg.H * cfg.W
+    P = cfg.band_rows * cfg.W
     lat, Rc, Tc = _f32c(latent, dev).reshape(-1), _f32c(R, dev).reshape(-1), _f32c(T, dev).reshape(-1)
     z = _f32c(zdepth, dev).reshape(-1)
     m = mask.detach().to(device=dev).reshape(-1).to(torch.uint8).contiguous()

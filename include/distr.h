@@ -74,6 +74,14 @@ typedef struct distr_render_cfg {
   int32_t save_for_backward;  /* 1: distr_render_backward will be called on this forward's workspace: the march kernel also
                                  saves the ReLU masks of the rows it keeps (512 B each) so that the backward pass need not
                                  recompute the decoder; 0: inference only (smaller workspace, backward not allowed) */
+  int32_t row0, rows;         /* row band (strong scaling of one large view over several GPUs): render only image
+                                 rows [row0, row0+rows) of the H x W image; rows == 0: the whole image. row0 must be a multiple
+                                 of 4 and rows a multiple of 4 unless the band ends at H (keeps the 4x4 pyramid parents of
+                                 renderer.py:732-749 intact), so every ray of the band is bit-identical to the same ray of a
+                                 full render. All per-pixel buffers (outputs, upstream gradients, P in the workspace sizes) then
+                                 cover rows*W band pixels. depth2normal needs the rows above/below: the first/last band row that
+                                 is not an image border row gets an undefined normal -- callers render a halo of 4 rows and
+                                 crop it (distr/functions.py::render_band_call). */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */

@@ -468,3 +468,68 @@ def test_render_warp_matches_reference_golden(fixture_decoder):
     assert np.abs(c1.cpu().numpy() - g['color_valid_1']).max() <= 1e-5 or (np.abs(c1.cpu().numpy() - g['color_valid_1']) > 1e-5).sum() <= 6
     rel = np.abs(lat.grad.cpu().numpy() - g['g_latent']).max() / np.abs(g['g_latent']).max()
     assert rel <= 5e-3, rel
+
+
+BAND_CASES = [  # (H, W, bands, marcher, d2n)
+    (128, 96, [(0, 32), (32, 100), (100, 128)], 'pyramid_recursive', True),
+    (70, 64, [(0, 36), (36, 70)], 'pyramid_recursive', True),          # H not a multiple of 4: last band ends at H
+    (96, 96, [(0, 48), (48, 96)], 'recursive', False),
+    (64, 64, [(0, 16), (16, 32), (32, 48), (48, 64)], 'trivial', True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', range(len(BAND_CASES)))
+def test_row_bands_equal_full_render(engine, fixture_decoder, case):
+    """SURVEY.md 8e (strong scaling of one view): a partition of the image into row bands, each rendered on its own
+    (what separate ranks do), reproduces the full render bit for bit per pixel, and the bands' input gradients sum to the
+    full render's (different summation order only)."""
+    import torch
+    from distr import binding, fixture, functions
+    H, W, bands, marcher, d2n = BAND_CASES[case]
+    Ws, bs, latent = fixture_decoder
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(20.0, 15.0, 1.7, 5.0)
+    dev = engine.device
+    cfg = binding.make_cfg((H, W), K, march_step=24, buffer_size=3, marcher=marcher, use_depth2normal=d2n)
+    wd, wq, wn = (torch.from_numpy(a).to(dev) for a in helpers.loss_weights(H, W, 3))
+
+    def run(r0, r1):
+        lat = torch.from_numpy(latent).to(dev).requires_grad_(True)
+        Rt = torch.from_numpy(R).to(dev).requires_grad_(True)
+        Tt = torch.from_numpy(T).to(dev).requires_grad_(True)
+        if (r0, r1) == (0, H):
+            z, m, q, d, n = functions.render_call(engine, cfg, lat, Rt, Tt)
+        else:
+            z, m, q, d, n = functions.render_band_call(engine, cfg, lat, Rt, Tt, r0, r1)
+        rows = r1 - r0
+        mb = m.reshape(rows, W).bool()
+        L = torch.where(mb, d * wd[r0:r1], torch.zeros_like(d)).sum() + (q.reshape(rows, W) * wq[r0:r1]).sum() + (n * wn[r0:r1]).sum()
+        L.backward()
+        out = [t.detach().reshape(rows, -1).cpu().numpy() for t in (z, m, q, d, n)]
+        return out, [g.grad.double().cpu().numpy() for g in (lat, Rt, Tt)]
+
+    full, gfull = run(0, H)
+    assert full[1].sum() > 50
+    parts = [run(r0, r1) for (r0, r1) in bands]
+    for k, name in enumerate(('zdepth', 'mask', 'min_sdf', 'depth', 'normal')):
+        cat = np.concatenate([p[0][k] for p in parts], axis=0)
+        assert cat.shape == full[k].shape
+        assert cat.tobytes() == full[k].tobytes(), name
+    for k, name in enumerate(('g_latent', 'g_R', 'g_T')):
+        tot = sum(p[1][k] for p in parts)
+        rel = np.abs(tot - gfull[k]).max() / np.abs(gfull[k]).max()
+        assert rel < 2e-5, (name, rel)
+
+
+@pytest.mark.gpu
+def test_row_band_argument_checks(engine, fixture_decoder):
+    from distr import binding, fixture
+    K = fixture.make_intrinsic(64, 64)
+    for band in [(2, 16), (0, 18), (60, 8), (-4, 8)]:
+        cfg = binding.make_cfg((64, 64), K, band=band)
+        with pytest.raises(binding.DistrError):
+            engine.ctx.workspace_bytes(cfg)
+    f_full, _ = engine.ctx.workspace_bytes(binding.make_cfg((64, 64), K))
+    f_band, _ = engine.ctx.workspace_bytes(binding.make_cfg((64, 64), K, band=(16, 32)))
+    assert f_band < 0.6 * f_full
