@@ -10,6 +10,10 @@ ray_marching_ratio 1.5 ("aggressive"), finite-difference normal channel (use_dep
 image loss + backward to the latent/camera gradients (+ for N>1 the RCCL all-reduce of the packed latent gradient).
 Inputs are resident in HBM before the timed region. Views shard over ranks (view-parallel, weak scaling).
 
+`--workload c5` runs BASELINE.json configs[4] instead (not the headline metric; the strong-scaling curve of SURVEY.md 8e):
+4 shapes (latent seeds 1234..1237) x one 1024x1024 view x 100 march steps, a FIXED total amount of work split over the
+ranks shape-major then into row bands (distr.parallel.shard_rows, distr.functions.render_band_call); "scaling": "strong".
+
 Extra objects on the JSON line:
   roofline     the dominant kernel (fused march/MLP kernel k_march): algorithmic FLOP (3 146 752 per decoder
                evaluation, latent hoisted) / summed hipEvent kernel time on the launch stream, vs the 157.3 TFLOP/s
@@ -75,9 +79,15 @@ def main():
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
     ap.add_argument('--march-step', type=int, default=50)
+    ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
+                    help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
+                         'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
     args = ap.parse_args()
 
     global H, W, MARCH_STEP
+    c5 = args.workload == 'c5'
+    if c5 and (args.size, args.march_step) == (512, 50):
+        args.size, args.march_step = 1024, 100
     H = W = args.size
     MARCH_STEP = args.march_step
     from distr import binding, fixture, functions, parallel
@@ -92,31 +102,55 @@ def main():
     Ws, bs, latent_np = fixture.make_decoder_weights()
     eng = functions.engine_from_weights(Ws, bs, local)
     K = fixture.make_intrinsic(H, W)
-    views = parallel.shard_views(args.gpus, rank, world)          # one view per GPU
     cfg = binding.make_cfg((H, W), K, march_step=MARCH_STEP, buffer_size=BUFFER_SIZE, ratio=RATIO, marcher=args.marcher,
                            use_depth2normal=True)
-    cams = []
-    for v in views:
-        R, T = view_camera(fixture, v)
-        cams.append((torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True)))
-    lat = torch.from_numpy(latent_np).to(dev).requires_grad_(True)
+    # work items of this rank: (shape, view, r0, r1)
+    if c5:
+        n_shapes = 4
+        items = [(img, 0, r0, r1) for (img, r0, r1) in parallel.shard_rows(n_shapes, H, rank, world)]
+        lats_np = [latent_np] + [fixture.make_latent(1234 + i) for i in range(1, n_shapes)]
+    else:
+        n_shapes = 1
+        items = [(0, v, 0, H) for v in parallel.shard_views(args.gpus, rank, world)]          # one view per GPU
+        lats_np = [latent_np]
+    cams = {}
+    for (_, v, _, _) in items:
+        if v not in cams:
+            R, T = view_camera(fixture, v)
+            cams[v] = (torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True))
+    lats = [torch.from_numpy(l).to(dev).requires_grad_(True) for l in lats_np]
+    lat = lats[0]
     rs = np.random.RandomState(5)
     wd, wq, wn = (torch.from_numpy(rs.rand(*s).astype(np.float32)).to(dev) for s in ((H, W), (H, W), (H, W, 3)))
     loss_buf = torch.zeros(1, device=dev)
+    zero_grad = torch.zeros(1, 256, device=dev)
+
+    def image_loss(outs, r0, r1):
+        z, mask, q, depth, normal = outs
+        mb = mask.reshape(r1 - r0, W).bool()
+        return torch.where(mb, depth * wd[r0:r1], torch.zeros_like(depth)).sum() + (q.reshape(r1 - r0, W) * wq[r0:r1]).sum() + \
+            (normal * wn[r0:r1]).sum()
 
     def step():
-        lat.grad = None
+        for l in lats:
+            l.grad = None
         total = None
-        for (Rt, Tt) in cams:
+        for (shape, v, r0, r1) in items:
+            Rt, Tt = cams[v]
             Rt.grad = None
             Tt.grad = None
-            z, mask, q, depth, normal = functions.render_call(eng, cfg, lat, Rt, Tt)
-            mb = mask.reshape(H, W).bool()
-            L = torch.where(mb, depth * wd, torch.zeros_like(depth)).sum() + (q.reshape(H, W) * wq).sum() + (normal * wn).sum()
+            if (r0, r1) == (0, H):
+                outs = functions.render_call(eng, cfg, lats[shape], Rt, Tt)
+            else:
+                outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
+            L = image_loss(outs, r0, r1)
             total = L if total is None else total + L
         total.backward()
         loss_buf.copy_(total.detach().reshape(1))
-        parallel.allreduce_packed([lat.grad, loss_buf])            # one RCCL all-reduce: [latent grad | loss]
+        for l in lats:
+            if l.grad is None:
+                l.grad = zero_grad.clone()
+        parallel.allreduce_packed([l.grad for l in lats] + [loss_buf])   # one RCCL all-reduce: [latent grads | loss]
         return total
 
     for _ in range(args.warmup):
@@ -143,26 +177,32 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return r, e0.elapsed_time(e1)
-    Rt0, Tt0 = cams[0]
-    outs0, fwd_ms = timed(lambda: functions.render_call(eng, cfg, lat, Rt0, Tt0))
-    Lsplit = torch.where(outs0[1].reshape(H, W).bool(), outs0[3] * wd, torch.zeros_like(outs0[3])).sum() + \
-        (outs0[2].reshape(H, W) * wq).sum() + (outs0[4] * wn).sum()
+    shape0, v0, r00, r01 = items[0]
+    Rt0, Tt0 = cams[v0]
+    one = (lambda: functions.render_call(eng, cfg, lats[shape0], Rt0, Tt0)) if (r00, r01) == (0, H) else \
+        (lambda: functions.render_band_call(eng, cfg, lats[shape0], Rt0, Tt0, r00, r01))
+    outs0, fwd_ms = timed(one)
+    Lsplit = image_loss(outs0, r00, r01)
     _, bwd_ms = timed(lambda: Lsplit.backward())
 
-    # counters of one forward (identical every step: same inputs)
-    with torch.no_grad():
-        fwd_bytes, _ = eng.ctx.workspace_bytes(cfg)
-    ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
-    outs = [torch.empty(H * W, device=dev), torch.empty(H * W, dtype=torch.uint8, device=dev), torch.empty(H * W, device=dev),
-            torch.empty(H, W, device=dev), torch.empty(H, W, 3, device=dev)]
+    # counters of one forward of every work item of this rank (identical every step: same inputs)
     import ctypes as C
     p = binding.ptr
-    Rt, Tt = cams[0]
-    eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat.detach().reshape(-1).contiguous()),
-                                               p(Rt.detach().reshape(-1).contiguous()), p(Tt.detach().contiguous()),
-                                               p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(),
-                                               eng.ctx.stream()))
-    stats = eng.ctx.render_stats(cfg, ws)
+    stats = None
+    for (shape, v, r0, r1) in items:
+        icfg = cfg if (r0, r1) == (0, H) else functions.band_cfg(cfg, r0, r1)[0]
+        n = icfg.band_rows * W
+        fwd_bytes, _ = eng.ctx.workspace_bytes(icfg)
+        ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+        outs = [torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, device=dev),
+                torch.empty(n, device=dev), torch.empty(n, 3, device=dev)]
+        Rt, Tt = cams[v]
+        eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(icfg), p(lats[shape].detach().reshape(-1).contiguous()),
+                                                   p(Rt.detach().reshape(-1).contiguous()), p(Tt.detach().contiguous()),
+                                                   p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(),
+                                                   eng.ctx.stream()))
+        st = eng.ctx.render_stats(icfg, ws)
+        stats = st if stats is None else {k: stats[k] + st[k] for k in st}
 
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see file
@@ -172,23 +212,25 @@ def main():
         except Exception:
             traffic = None
     if rank == 0:
-        n_fwd = args.steps * len(cams)
-        evals = stats['num_point_evals'] * n_fwd
+        evals = stats['num_point_evals'] * args.steps
         flops = FLOP_PER_EVAL * evals
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        rays = float(args.gpus) * H * W * args.steps
+        rays = (4.0 if c5 else float(args.gpus)) * H * W * args.steps     # c5: fixed total work (4 images); c3: one view per GPU
         out = {
             'metric': 'rays/sec (fwd+bwd) at %dx%d, %d march steps, DeepSDF 8x512' % (H, W, MARCH_STEP),
             'value': rays / elapsed, 'unit': 'rays/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if c5 else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)',
             'config': {'workload': '%s%dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
-                                   'fwd+loss+bwd, 1 view per GPU' % ('C3: ' if (H, MARCH_STEP) == (512, 50) else '', H, W, MARCH_STEP, args.marcher, BUFFER_SIZE, RATIO),
-                       'parallelism': 'view-parallel x%d (RCCL all-reduce of packed latent grad)' % args.gpus,
+                                   'fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
+                                                         args.marcher, BUFFER_SIZE, RATIO,
+                                                         'fixed total work split shape-major then in row bands' if c5 else '1 view per GPU'),
+                       'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + ' (RCCL all-reduce of packed latent grad)',
+                       'rank0_items': [list(it) for it in items],
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
-                       'decoder_evals_per_forward': stats['num_point_evals'],
-                       'march_launches_per_forward': stats['num_march_launches'],
-                       'forward_ms_one_view': fwd_ms, 'backward_ms_one_view': bwd_ms,
+                       'decoder_evals_per_step_rank0': stats['num_point_evals'],
+                       'march_launches_per_step_rank0': stats['num_march_launches'],
+                       'forward_ms_one_item': fwd_ms, 'backward_ms_one_item': bwd_ms,
                        'decoder_evals_per_s_march': evals / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,

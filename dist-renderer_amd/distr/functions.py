@@ -117,6 +117,18 @@ def render_call(engine, cfg, latent, R, T):
 HALO = 4   # rows; depth2normal needs 1, the 4x4 pyramid parents need the band aligned to 4
 
 
+def band_cfg(cfg, r0, r1):
+    """cfg of the launch that produces rows [r0, r1): the band plus its depth2normal halo. Returns (cfg, b0, b1)."""
+    H = cfg.H
+    if not (0 <= r0 < r1 <= H) or (r0 & 3) or ((r1 & 3) and r1 != H):
+        raise ValueError('band [%d, %d) must lie in [0, %d) on multiples of 4 (or end at H)' % (r0, r1, H))
+    halo = HALO if (cfg.want_normal and cfg.use_depth2normal) else 0
+    b0, b1 = max(0, r0 - halo), min(H, r1 + halo)
+    bcfg = cfg.clone()
+    bcfg.row0, bcfg.rows = b0, b1 - b0
+    return bcfg, b0, b1
+
+
 def render_band_call(engine, cfg, latent, R, T, r0, r1):
     """Rows [r0, r1) of the render `cfg` describes (r0, r1 multiples of 4, or r1 == H): what one rank computes when one
     large view is split over several GPUs (row-band tiles whose height is a multiple of 4 px, halo
@@ -124,13 +136,8 @@ def render_band_call(engine, cfg, latent, R, T, r0, r1):
     zero-pads the halo's upstream gradients, so the sum over a partition of [0, H) of the bands' input gradients equals
     the full render's. Returns (zdepth (n*W), mask (n*W) uint8, min_sdf (n*W), depth (n, W), normal (n, W, 3)), n = r1 - r0;
     every value is bit-identical to the same pixel of the full render."""
-    H, W = cfg.H, cfg.W
-    if not (0 <= r0 < r1 <= H) or (r0 & 3) or ((r1 & 3) and r1 != H):
-        raise ValueError('band [%d, %d) must lie in [0, %d) on multiples of 4 (or end at H)' % (r0, r1, H))
-    halo = HALO if (cfg.want_normal and cfg.use_depth2normal) else 0
-    b0, b1 = max(0, r0 - halo), min(H, r1 + halo)
-    bcfg = cfg.clone()
-    bcfg.row0, bcfg.rows = b0, b1 - b0
+    W = cfg.W
+    bcfg, b0, b1 = band_cfg(cfg, r0, r1)
     z, mask, q, depth, normal = render_call(engine, bcfg, latent, R, T)
     lo, n = r0 - b0, r1 - r0
     z, mask, q = (t.reshape(b1 - b0, W)[lo:lo + n].reshape(-1) for t in (z, mask, q))

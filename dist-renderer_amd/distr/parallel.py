@@ -36,6 +36,24 @@ def shard_views(num_views, rank, world_size):
     return list(range(rank, num_views, world_size))
 
 
+def shard_rows(num_images, H, rank, world_size, align=4):
+    """Strong-scaling partition of `num_images` H-row images over the ranks (shape-major, then row
+    bands whose height is a multiple of `align` = 4 px so the 4x4 pyramid parents stay intact): the num_images*ceil(H/4)
+    row units are cut into world_size contiguous runs. Returns this rank's [(image, r0, r1), ...]; over all ranks the
+    pieces tile every image exactly once. Each piece is rendered with distr.functions.render_band_call."""
+    upi = (H + align - 1) // align                    # row units per image
+    total = num_images * upi
+    lo, hi = (rank * total) // world_size, ((rank + 1) * total) // world_size
+    out = []
+    u = lo
+    while u < hi:
+        img = u // upi
+        end = min(hi, (img + 1) * upi)
+        out.append((img, (u - img * upi) * align, min(H, (end - img * upi) * align)))
+        u = end
+    return out
+
+
 def allreduce_packed(tensors, group=None):
     """Sums every tensor of `tensors` over all ranks with ONE all-reduce of a packed flat f32 buffer (in place)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -36,7 +36,12 @@ def _worker(rank, world, port, q):
         out = helpers.oracle_render(O, orc, H, W, K, R, T, latent, march_step=12, buffer_size=2, marcher='recursive')
         g += torch.from_numpy(out['g_latent'])
         loss += float(out['mask'].sum())
-    parallel.allreduce_packed([g, loss])
+    # strong-scaling partition (C5): the ranks' row bands tile every image exactly once
+    cover = torch.zeros(3, 72)
+    for (img, r0, r1) in parallel.shard_rows(3, 70, rank, world):
+        cover[img, r0:r1] += 1
+    parallel.allreduce_packed([g, loss, cover])
+    assert bool((cover[:, :70] == 1).all()) and bool((cover[:, 70:] == 0).all())
     mx = parallel.allreduce_max_scalar(float(rank))
     parallel.barrier()
     q.put((rank, g.numpy().copy(), float(loss), mx))

@@ -142,3 +142,16 @@ def test_view_sharding():
     assert parallel.shard_views(8, 3, 8) == [3]
     assert parallel.shard_views(8, 1, 4) == [1, 5]
     assert sorted(sum((parallel.shard_views(8, r, 3) for r in range(3)), [])) == list(range(8))
+
+
+def test_row_sharding_tiles_every_image_once():
+    from distr import parallel
+    for (n, H, world) in [(4, 1024, 8), (4, 1024, 1), (4, 1024, 3), (1, 70, 4), (3, 64, 16), (2, 512, 2)]:
+        cover = np.zeros((n, H), np.int32)
+        for r in range(world):
+            for (img, r0, r1) in parallel.shard_rows(n, H, r, world):
+                assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H) and r0 < r1
+                cover[img, r0:r1] += 1
+        assert (cover == 1).all()
+    assert parallel.shard_rows(4, 1024, 5, 8) == [(2, 512, 1024)]
+    assert parallel.shard_rows(4, 1024, 1, 2) == [(2, 0, 1024), (3, 0, 1024)]
