@@ -380,13 +380,22 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     for (int st = 0; st < V.lv[l].steps; ++st) {
       A.lvl = l; A.step = st; A.origin_tile = origin_done ? 0 : 1;
       origin_done = true;
-      const unsigned tiles = (unsigned)((V.lv[l].n + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
+      // tile size of a coarse level from its (host-known) pixel count: a level that fits one round of 16- / 32-ray tiles
+      // runs on those (small images: 111 / 212 us per step instead of 380 us), see fine_range
+      const int64_t ln = V.lv[l].n;
+      const bool c16 = !A.origin_tile && ((split_cfg && ln <= ctx->tail16_threshold) || ctx->tile_rb == -1);
+      const int crb = (split_cfg && ln <= ctx->hybrid_threshold) ? 1 : rb_dense;
+      const int ctile = c16 ? 16 : 32 * crb;
+      const unsigned tiles = (unsigned)((ln + ctile - 1) / ctile) + (A.origin_tile ? 1u : 0u);
       timer.begin();
-      if (V.save_masks) {
-        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      if (c16) {
+        if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_COARSE, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+        else hipLaunchKernelGGL((k_march16<MODE_COARSE, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+      } else if (V.save_masks) {
+        if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
         else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       } else {
-        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
         else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       }
       timer.end();
@@ -406,8 +415,12 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     A.t16 = split ? std::min(ctx->tail16_threshold, ctx->hybrid_threshold) : 0;
     A.which = 32 * rb_dense;
     if (force16) { A.t16 = 0x7fffffff; A.t32 = 0x7fffffff; }       // tests: whole step on 16-ray tiles (rem = count when < 16384...)
+    // the live count never exceeds P: with P <= t32 the 64-ray range of the split is provably empty (and with P <= t16 the
+    // 32-ray range too), so those launches are skipped on the host
+    const bool skip64 = split && !A.origin_tile && P <= A.t32 && A.t16 > 0;
+    const bool skip32 = split && P <= A.t16;
     timer.begin();
-    if (!force16) {
+    if (!force16 && !skip64) {
       if (V.save_masks) {
         if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
         else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
@@ -419,7 +432,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     if (split || force16) {
       MarchArgs A2 = A;
       A2.origin_tile = 0;
-      if (split && A.t32 > A.t16) {
+      if (split && A.t32 > A.t16 && !skip32) {
         A2.which = 32;
         const unsigned n32 = (unsigned)((std::min(P, A.t32) + 31) / 32);
         if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(n32), dim3(NTHREADS), 0, s, A2, D);

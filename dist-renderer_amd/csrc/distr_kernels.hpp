@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
 }
 
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
-// MODE_FINE (recursive marchers) and MODE_EVAL only.
+// MODE_FINE (recursive marchers), MODE_COARSE (pyramid levels of small images) and MODE_EVAL.
 template <int MODE, bool KEEP>
 __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
   constexpr int TILE = 16;
@@ -510,6 +510,9 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   const int32_t* list = nullptr;
   if (MODE == MODE_EVAL) {
     count = A.n;
+  } else if (MODE == MODE_COARSE) {
+    count = V.C->cnt_level[A.lvl];
+    list = V.lv[A.lvl].list;
   } else {
     count = V.C->cnt_live[A.step];
     list = V.live[A.step & 1];
@@ -536,11 +539,12 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
         p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
       } else {
         id = list[r];
+        const LevelView& L = V.lv[MODE == MODE_COARSE ? A.lvl : 0];
         const CamRegs cam = load_cam(V.C);
         float cx, cy;
-        level_center(V.lv[0], id, cx, cy);
+        level_center(L, id, cx, cy);
         const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-        zd = V.init_now[id] + V.m[id];
+        zd = (MODE == MODE_COARSE) ? (L.cinit[id] + L.cm[id]) : (V.init_now[id] + V.m[id]);
         make_point(V.cfg.M, cam.c, g.d, zd, p);
       }
     }
@@ -560,6 +564,17 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
       if (tid == 0) { V.C->f_origin = s; mblock = V.morigin; }
     } else if (MODE == MODE_EVAL) {
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
+    } else if (MODE == MODE_COARSE) {
+      if (valid) {
+        const LevelView& L = V.lv[A.lvl];
+        const float mn = L.cm[id] + clampf(s, -V.cfg.clamp_dist, V.cfg.clamp_dist) * V.cfg.ratio;
+        L.cm[id] = mn;
+        const size_t o = (size_t)A.step * L.n + id;
+        L.rs[o] = s;
+        L.rzb[o] = zd;
+        L.rza[o] = mn + L.cinit[id];
+        mblock = V.mfine + V.moff[A.lvl] + (long long)o;
+      }
     } else {
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
       bool stay = false;
@@ -578,7 +593,7 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
       wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
     }
   }
-  if (KEEP && MODE == MODE_FINE) {
+  if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
     store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
