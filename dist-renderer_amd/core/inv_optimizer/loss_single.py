@@ -32,14 +32,25 @@ def compute_all_loss(sdf_renderer, latent_tensor, extrinsic, gt_pack, threshold=
     sil = gt.get('silhouette')
 
     pack = dict(mask_gt=0.0, mask_out=0.0, depth=0.0, normal=0.0)
-    if sil is not None:
-        miss, extra, visualizer = LU.compute_loss_mask(min_sdf, mask, sil, threshold=threshold, visualizer=visualizer)
-        pack['mask_gt'], pack['mask_out'] = _maybe_detach(miss, on['silhouette']), _maybe_detach(extra, on['silhouette'])
-    if 'depth' in gt:
-        value, visualizer = LU.compute_loss_depth(depth, mask, gt['depth'], sil, visualizer=visualizer)
-        pack['depth'] = _maybe_detach(value, on['depth'])
-    if 'normal' in gt:
-        value, visualizer = LU.compute_loss_normal(normal, mask, gt['normal'], sil, visualizer=visualizer)
-        pack['normal'] = _maybe_detach(value, on['normal'])
+    engine = getattr(sdf_renderer, '_engine', None)
+    if sil is not None and engine is not None and visualizer is None and depth.is_cuda:
+        # fused path (row f3): all four terms in two element-wise kernels, no host synchronisation
+        from distr import functions
+        terms = functions.single_view_losses(engine, depth, normal, mask, min_sdf, gt.get('depth'), gt.get('normal'), sil, threshold)
+        pack['mask_gt'], pack['mask_out'] = _maybe_detach(terms[0], on['silhouette']), _maybe_detach(terms[1], on['silhouette'])
+        if 'depth' in gt:
+            pack['depth'] = _maybe_detach(terms[2], on['depth'])
+        if 'normal' in gt:
+            pack['normal'] = _maybe_detach(terms[3], on['normal'])
+    else:
+        if sil is not None:
+            miss, extra, visualizer = LU.compute_loss_mask(min_sdf, mask, sil, threshold=threshold, visualizer=visualizer)
+            pack['mask_gt'], pack['mask_out'] = _maybe_detach(miss, on['silhouette']), _maybe_detach(extra, on['silhouette'])
+        if 'depth' in gt:
+            value, visualizer = LU.compute_loss_depth(depth, mask, gt['depth'], sil, visualizer=visualizer)
+            pack['depth'] = _maybe_detach(value, on['depth'])
+        if 'normal' in gt:
+            value, visualizer = LU.compute_loss_normal(normal, mask, gt['normal'], sil, visualizer=visualizer)
+            pack['normal'] = _maybe_detach(value, on['normal'])
     pack['l2reg'] = latent_tensor.pow(2).mean()
     return pack, visualizer

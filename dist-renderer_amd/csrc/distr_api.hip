@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "distr_kernels.hpp"
+#include "distr_losses.hpp"
 
 using namespace distr;
 
@@ -694,6 +695,101 @@ int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void
   if (launches) *launches = (int64_t)ctx->ev_used;
   if (total_ms) *total_ms = tot;
   ctx->ev_used = 0;
+  return DISTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ f2 / f3: fused losses
+size_t distr_loss_workspace_bytes(int32_t H, int32_t W) {
+  const size_t nblk = ((size_t)H * W + 255) / 256;
+  return nblk * 24 * sizeof(float) + 256;
+}
+
+static int loss_args(distr_ctx* ctx, int32_t H, int32_t W, const void* ws, size_t ws_bytes) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (H < 1 || W < 1 || (int64_t)H * W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", H, W);
+  if (ws_bytes < distr_loss_workspace_bytes(H, W) || !ws) return fail(ctx, DISTR_ERR_WORKSPACE, "loss workspace too small");
+  return DISTR_OK;
+}
+
+int distr_single_loss_forward(distr_ctx* ctx, int32_t H, int32_t W, const float* depth, const float* normal, const uint8_t* mask,
+                              const float* min_sdf, const float* gt_depth, const float* gt_normal, const uint8_t* gt_mask,
+                              float threshold, float* out8, void* ws, size_t ws_bytes, void* stream) {
+  int rc = loss_args(ctx, H, W, ws, ws_bytes);
+  if (rc) return rc;
+  if (!mask || !min_sdf || !gt_mask || !out8 || (gt_depth && !depth) || (gt_normal && !normal))
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  SingleLossArgs A{H * W, depth, normal, mask, min_sdf, gt_depth, gt_normal, gt_mask, threshold};
+  const int nblk = (A.P + 255) / 256;
+  hipLaunchKernelGGL(k_single_loss_partial, dim3(nblk), dim3(256), 0, s, A, (float*)ws);
+  LAUNCH_CHECK("k_single_loss_partial");
+  hipLaunchKernelGGL(k_single_loss_final, dim3(1), dim3(64), 0, s, (const float*)ws, nblk, out8);
+  LAUNCH_CHECK("k_single_loss_final");
+  return DISTR_OK;
+}
+
+int distr_single_loss_backward(distr_ctx* ctx, int32_t H, int32_t W, const float* depth, const float* normal, const uint8_t* mask,
+                               const float* min_sdf, const float* gt_depth, const float* gt_normal, const uint8_t* gt_mask,
+                               float threshold, const float* out8, const float* g4, float* g_depth, float* g_normal,
+                               float* g_min_sdf, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (H < 1 || W < 1 || (int64_t)H * W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", H, W);
+  if (!mask || !min_sdf || !gt_mask || !out8 || !g4 || (gt_depth && !depth) || (gt_normal && !normal))
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  SingleLossArgs A{H * W, depth, normal, mask, min_sdf, gt_depth, gt_normal, gt_mask, threshold};
+  hipLaunchKernelGGL(k_single_loss_bwd, grid1(A.P), dim3(256), 0, s, A, out8, g4, g_depth, g_normal, g_min_sdf);
+  LAUNCH_CHECK("k_single_loss_bwd");
+  return DISTR_OK;
+}
+
+static WarpArgs warp_args(const distr_warp_cfg* c, const float* z1, const uint8_t* m1, const float* z2, const float* img1,
+                          const float* img2, const float* R1, const float* T1, const float* R2, const float* T2) {
+  WarpArgs A;
+  A.H = c->H; A.W = c->W;
+  memcpy(A.K, c->K, sizeof(A.K));
+  memcpy(A.K_inv, c->K_inv, sizeof(A.K_inv));
+  A.thres_depth = c->thres_depth;
+  A.z1 = z1; A.m1 = m1; A.z2 = z2; A.img1 = img1; A.img2 = img2;
+  A.R1 = R1; A.T1 = T1; A.R2 = R2; A.T2 = T2;
+  return A;
+}
+
+int distr_warp_loss_forward(distr_ctx* ctx, const distr_warp_cfg* cfg, const float* zdepth1, const uint8_t* mask1,
+                            const float* zdepth2, const float* img1, const float* img2, const float* R1, const float* T1,
+                            const float* R2, const float* T2, float* out3, uint8_t* keep, float* color1, float* color2,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
+  int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
+  if (rc) return rc;
+  if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3)
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const WarpArgs A = warp_args(cfg, zdepth1, mask1, zdepth2, img1, img2, R1, T1, R2, T2);
+  const int nblk = (A.H * A.W + 255) / 256;
+  hipLaunchKernelGGL(k_warp_fwd, dim3(nblk), dim3(256), 0, s, A, keep, color1, color2, (float*)ws);
+  LAUNCH_CHECK("k_warp_fwd");
+  hipLaunchKernelGGL(k_warp_final, dim3(1), dim3(64), 0, s, (const float*)ws, nblk, out3);
+  LAUNCH_CHECK("k_warp_final");
+  return DISTR_OK;
+}
+
+int distr_warp_loss_backward(distr_ctx* ctx, const distr_warp_cfg* cfg, const float* zdepth1, const uint8_t* mask1,
+                             const float* zdepth2, const float* img1, const float* img2, const float* R1, const float* T1,
+                             const float* R2, const float* T2, const float* out3, const float* g_loss, float* g_zdepth1,
+                             float* g_cam, void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
+  int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
+  if (rc) return rc;
+  if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3 || !g_loss || !g_cam)
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const WarpArgs A = warp_args(cfg, zdepth1, mask1, zdepth2, img1, img2, R1, T1, R2, T2);
+  const int nblk = (A.H * A.W + 255) / 256;
+  hipLaunchKernelGGL(k_warp_bwd, dim3(nblk), dim3(256), 0, s, A, out3, g_loss, g_zdepth1, (float*)ws);
+  LAUNCH_CHECK("k_warp_bwd");
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, s, (const float*)ws, nblk, 24, g_cam);
+  LAUNCH_CHECK("k_sum_partials");
   return DISTR_OK;
 }
 

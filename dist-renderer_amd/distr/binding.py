@@ -19,7 +19,9 @@ MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
 EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
            'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
-           'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing']
+           'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
+           'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
+           'distr_warp_loss_forward', 'distr_warp_loss_backward']
 
 
 class DistrError(RuntimeError):
@@ -57,6 +59,20 @@ class RenderCfg(C.Structure):
         return c
 
 
+class WarpCfg(C.Structure):
+    _fields_ = [('H', C.c_int32), ('W', C.c_int32), ('K', C.c_float * 9), ('K_inv', C.c_float * 9), ('thres_depth', C.c_float)]
+
+
+def make_warp_cfg(img_hw, intrinsic, thres_depth):
+    cfg = WarpCfg()
+    cfg.H, cfg.W = int(img_hw[0]), int(img_hw[1])
+    K = np.asarray(intrinsic, dtype=np.float64)
+    cfg.K = (C.c_float * 9)(*K.astype(np.float32).reshape(-1))
+    cfg.K_inv = (C.c_float * 9)(*np.linalg.inv(K).astype(np.float32).reshape(-1))
+    cfg.thres_depth = float(thres_depth)
+    return cfg
+
+
 class RenderStats(C.Structure):
     _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
                 ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64)]
@@ -64,7 +80,7 @@ class RenderStats(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
-    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp')]
+    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_losses.hpp')]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -111,6 +127,12 @@ def lib():
             L.distr_get_render_stats.argtypes = [vp, C.POINTER(RenderCfg), vp, C.POINTER(RenderStats), vp]
             L.distr_profile_enable.argtypes = [vp, C.c_int]
             L.distr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), vp]
+            L.distr_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+            L.distr_loss_workspace_bytes.restype = C.c_size_t
+            L.distr_single_loss_forward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, u8p, fp, fp, fp, u8p, C.c_float, fp, vp, C.c_size_t, vp]
+            L.distr_single_loss_backward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, u8p, fp, fp, fp, u8p, C.c_float, fp, fp, fp, fp, fp, vp]
+            L.distr_warp_loss_forward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, u8p, fp, fp, vp, C.c_size_t, vp]
+            L.distr_warp_loss_backward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
             _lib = L
     return _lib
 

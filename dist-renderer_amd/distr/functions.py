@@ -220,3 +220,104 @@ def debug_tile_timing(engine, latent, points, tile):
     engine.ctx.check(engine.ctx.L.distr_debug_tile_timing(engine.ctx.h, p(lat), p(x), n, p(sdf), p(ts), p(ws), ws.numel(),
                                                          engine.ctx.stream()))
     return sdf, ts
+
+
+# ------------------------------------------------------------------------------------------ fused losses (rows f2, f3)
+def _u8c(t, device):
+    t = t.detach().to(device=device)
+    return (t if t.dtype == torch.uint8 else (t != 0).to(torch.uint8)).contiguous()
+
+
+def _loss_ws(engine, H, W):
+    return torch.empty(engine.ctx.L.distr_loss_workspace_bytes(H, W), dtype=torch.uint8, device=engine.device)
+
+
+class SingleViewLossFunction(torch.autograd.Function):
+    """(depth (H,W), normal (H,W,3), min_sdf (H,W)) + constants -> losses[4] = (mask_gt, mask_out, depth, normal):
+    distr_single_loss_forward / _backward (core/utils/loss_utils.py:59-172 in two element-wise kernels)."""
+
+    @staticmethod
+    def forward(ctx, depth, normal, min_sdf, engine, mask, gt_depth, gt_normal, gt_mask, threshold):
+        dev = engine.device
+        H, W = min_sdf.shape[0], min_sdf.shape[1]
+        d, n, q = _f32c(depth, dev), _f32c(normal, dev), _f32c(min_sdf, dev)
+        m, gm = _u8c(mask, dev), _u8c(gt_mask, dev)
+        gd = None if gt_depth is None else _f32c(gt_depth, dev)
+        gn = None if gt_normal is None else _f32c(gt_normal, dev)
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        ws = _loss_ws(engine, H, W)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_single_loss_forward(engine.ctx.h, H, W, p(d), p(n), p(m), p(q), p(gd), p(gn), p(gm),
+                                                               float(threshold), p(out8), p(ws), ws.numel(), engine.ctx.stream()))
+        ctx.engine, ctx.hw, ctx.threshold = engine, (H, W), float(threshold)
+        ctx.saved = (d, n, q, m, gd, gn, gm, out8)
+        return out8[:4].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        engine = ctx.engine
+        d, n, q, m, gd, gn, gm, out8 = ctx.saved
+        H, W = ctx.hw
+        g4 = g.to(dtype=torch.float32).contiguous()
+        g_d, g_n, g_q = torch.empty_like(d), torch.empty_like(n), torch.empty_like(q)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_single_loss_backward(engine.ctx.h, H, W, p(d), p(n), p(m), p(q), p(gd), p(gn), p(gm),
+                                                                ctx.threshold, p(out8), p(g4), p(g_d), p(g_n), p(g_q),
+                                                                engine.ctx.stream()))
+        return g_d, g_n, g_q, None, None, None, None, None, None
+
+
+def single_view_losses(engine, depth, normal, mask, min_sdf, gt_depth, gt_normal, gt_mask, threshold):
+    """-> tensor [mask_gt, mask_out, depth, normal] (terms whose ground truth is None are 0)."""
+    return SingleViewLossFunction.apply(depth, normal, min_sdf, engine, mask, gt_depth, gt_normal, gt_mask, threshold)
+
+
+class WarpLossFunction(torch.autograd.Function):
+    """(Zdepth1 (P), R1, T1, R2, T2) + constants -> (loss_color, keep (P) uint8, color1 (H,W,3), color2 (H,W,3)):
+    distr_warp_loss_forward / _backward (core/sdfrenderer/renderer_warp.py:18-101)."""
+
+    @staticmethod
+    def forward(ctx, z1, R1, T1, R2, T2, engine, wcfg, m1, z2, img1, img2):
+        dev = engine.device
+        H, W = wcfg.H, wcfg.W
+        P = H * W
+        z1c, z2c = _f32c(z1, dev).reshape(-1), _f32c(z2, dev).reshape(-1)
+        m1c = _u8c(m1, dev).reshape(-1)
+        i1, i2 = _f32c(img1, dev).reshape(-1), _f32c(img2, dev).reshape(-1)
+        cams = [_f32c(t, dev).reshape(-1) for t in (R1, T1, R2, T2)]
+        if z1c.numel() != P or i1.numel() != 3 * P or i2.numel() != 3 * P:
+            raise ValueError('render_warp: image / depth sizes do not match img_hw')
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        keep = torch.empty(P, dtype=torch.uint8, device=dev)
+        c1, c2 = torch.empty(H, W, 3, dtype=torch.float32, device=dev), torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+        ws = _loss_ws(engine, H, W)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_warp_loss_forward(engine.ctx.h, C.byref(wcfg), p(z1c), p(m1c), p(z2c), p(i1), p(i2),
+                                                             p(cams[0]), p(cams[1]), p(cams[2]), p(cams[3]), p(out3), p(keep),
+                                                             p(c1), p(c2), p(ws), ws.numel(), engine.ctx.stream()))
+        ctx.engine, ctx.wcfg = engine, wcfg
+        ctx.saved = (z1c, m1c, z2c, i1, i2, cams, out3)
+        ctx.shapes = (z1.shape, R1.shape, T1.shape, R2.shape, T2.shape)
+        ctx.mark_non_differentiable(keep, c1, c2)
+        return out3[0].clone(), keep, c1, c2
+
+    @staticmethod
+    def backward(ctx, g_loss, g_keep, g_c1, g_c2):
+        engine, wcfg = ctx.engine, ctx.wcfg
+        z1c, m1c, z2c, i1, i2, cams, out3 = ctx.saved
+        dev = engine.device
+        gl = g_loss.to(dtype=torch.float32).reshape(1).contiguous()
+        g_z = torch.empty_like(z1c)
+        g_cam = torch.empty(24, dtype=torch.float32, device=dev)
+        ws = _loss_ws(engine, wcfg.H, wcfg.W)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_warp_loss_backward(engine.ctx.h, C.byref(wcfg), p(z1c), p(m1c), p(z2c), p(i1), p(i2),
+                                                              p(cams[0]), p(cams[1]), p(cams[2]), p(cams[3]), p(out3), p(gl),
+                                                              p(g_z), p(g_cam), p(ws), ws.numel(), engine.ctx.stream()))
+        zs, r1s, t1s, r2s, t2s = ctx.shapes
+        return (g_z.reshape(zs), g_cam[0:9].reshape(r1s), g_cam[9:12].reshape(t1s), g_cam[12:21].reshape(r2s),
+                g_cam[21:24].reshape(t2s), None, None, None, None, None, None)
+
+
+def warp_loss(engine, wcfg, z1, m1, z2, img1, img2, R1, T1, R2, T2):
+    return WarpLossFunction.apply(z1, R1, T1, R2, T2, engine, wcfg, m1, z2, img1, img2)

@@ -163,6 +163,55 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
 int distr_profile_enable(distr_ctx* ctx, int enable);
 int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
 
+/* ---- Image-space consumers right after the hot path, fused into a few element-wise
+ * kernels. Same rules as above: caller-owned device buffers, everything enqueued on `stream`, no host sync. Scalars
+ * (losses, their upstream gradients) live in device memory so that nothing has to be read back. */
+
+/* Workspace of the loss entry points for an H x W image (per-block reduction partials). */
+size_t distr_loss_workspace_bytes(int32_t H, int32_t W);
+
+/* f3: the four single-view loss terms of compute_all_loss (core/inv_optimizer/loss_single.py:29-54):
+ *   out8[0] mask_gt  = mean over (gt & ~out) of max(min_sdf - threshold, 0)         core/utils/loss_utils.py:75-87
+ *   out8[1] mask_out = mean over (out & ~gt) of max(threshold - min_sdf, 0)         core/utils/loss_utils.py:89-101
+ *   out8[2] depth    = mean over (out & gt & 0 < gt_depth < 1e5) of |depth - gt_depth|   loss_utils.py:105-133
+ *   out8[3] normal   = mean over (out & gt & |normal| != 0) of -cos(normal, gt_normal)   loss_utils.py:140-172
+ *   out8[4..7] the four pixel counts (as floats); a term over an empty set is 0.
+ * depth/normal/mask/min_sdf are the outputs of distr_render_forward (H*W, row-major); gt_depth / gt_normal may be
+ * null (term = 0). */
+int distr_single_loss_forward(distr_ctx* ctx, int32_t H, int32_t W, const float* depth, const float* normal,
+                              const uint8_t* mask, const float* min_sdf, const float* gt_depth, const float* gt_normal,
+                              const uint8_t* gt_mask, float threshold, float* out8, void* ws, size_t ws_bytes, void* stream);
+/* Backward of the above: g4 = upstream gradients of out8[0..3] (device); writes the gradient images that
+ * distr_render_backward consumes (any of them may be null). */
+int distr_single_loss_backward(distr_ctx* ctx, int32_t H, int32_t W, const float* depth, const float* normal,
+                               const uint8_t* mask, const float* min_sdf, const float* gt_depth, const float* gt_normal,
+                               const uint8_t* gt_mask, float threshold, const float* out8, const float* g4,
+                               float* g_depth, float* g_normal, float* g_min_sdf, void* stream);
+
+/* f2: the photometric warp loss of SDFRenderer_warp.render_warp (core/sdfrenderer/renderer_warp.py:18-101): view-1
+ * surface points (camera ray * Zdepth1, with gradient) are projected into view 2, view 2's depth (Zdepth2 * calib_map)
+ * and colour are sampled bilinearly (grid_sample_on_img, core/utils/loss_utils.py:9-25: align_corners, zero padding),
+ * points whose projected depth disagrees by (err^2 >= thres_depth) are dropped, and the loss is the mean L1 colour
+ * difference of the kept points. */
+typedef struct distr_warp_cfg {
+  int32_t H, W;
+  float K[9];        /* float32(K), row-major            renderer.py:37-39  */
+  float K_inv[9];    /* float32(inv(K))                  renderer.py:161-164 */
+  float thres_depth; /* render_warp kwarg                renderer_warp.py:103 */
+} distr_warp_cfg;
+/* out3 (device) = { loss_color, #kept points, #valid view-1 pixels }; keep[P] (uint8), color1 / color2 [P][3] (the
+ * detached visualisation images, zeros off the kept set) may be null. */
+int distr_warp_loss_forward(distr_ctx* ctx, const distr_warp_cfg* cfg, const float* zdepth1, const uint8_t* mask1,
+                            const float* zdepth2, const float* img1, const float* img2, const float* R1, const float* T1,
+                            const float* R2, const float* T2, float* out3, uint8_t* keep, float* color1, float* color2,
+                            void* ws, size_t ws_bytes, void* stream);
+/* g_loss: upstream gradient of loss_color (device scalar). Writes g_zdepth1[P] (feeds distr_render_backward's
+ * g_zdepth) and g_cam[24] = { dR1[9], dT1[3], dR2[9], dT2[3] }. */
+int distr_warp_loss_backward(distr_ctx* ctx, const distr_warp_cfg* cfg, const float* zdepth1, const uint8_t* mask1,
+                             const float* zdepth2, const float* img1, const float* img2, const float* R1, const float* T1,
+                             const float* R2, const float* T2, const float* out3, const float* g_loss, float* g_zdepth1,
+                             float* g_cam, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""TEST INFRASTRUCTURE -- golden vectors for the fused loss kernels, produced by running the
+REFERENCE's own functions on CPU on synthetic inputs (needs /root/reference; see oracle/ref_harness.py for the shims).
+
+    python oracle/gen_golden_losses.py     # writes tests/golden/g7_single_losses.npz, tests/golden/g8_warp_loss.npz
+
+G7: core/utils/loss_utils.py compute_loss_mask / compute_loss_depth / compute_loss_normal on a synthetic render +
+    ground truth: the four loss values and their autograd gradients w.r.t. depth, normal, min_sdf.
+G8: SDFRenderer_warp.get_valid_points + compute_loss_color (core/sdfrenderer/renderer_warp.py:18-101) on analytic
+    sphere depth maps of two views: loss_color, the kept-point images, and the autograd gradients w.r.t. the view-1
+    depth and all four camera tensors.
+The goldens are data (inputs + reference outputs); no reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, '..', 'dist-renderer_amd'))
+sys.path.insert(0, _HERE)
+from distr import fixture  # noqa: E402
+import ref_harness as rh  # noqa: E402
+from gen_synth import sphere_view, procedural_images  # noqa: E402
+
+OUT = os.path.join(_HERE, '..', 'tests', 'golden')
+
+
+def golden_g7():
+    rh.install_shims()
+    rh.reference_modules()
+    from core.utils import loss_utils as LU
+    H, W = 40, 56
+    rs = np.random.RandomState(11)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    r2 = ((xx - 27.0) / 20.0) ** 2 + ((yy - 19.0) / 14.0) ** 2
+    mask = (r2 < 1.0)
+    gt_mask = (((xx - 30.0) / 19.0) ** 2 + ((yy - 18.0) / 15.0) ** 2) < 1.0
+    depth = np.where(mask, 1.2 + 0.3 * r2 + 0.01 * rs.standard_normal((H, W)), 1e11).astype(np.float32)
+    gt_depth = np.where(gt_mask, 1.22 + 0.28 * r2, 0.0).astype(np.float32)
+    gt_depth[5:9, 20:30] = 0.0          # sparse-depth holes (loss_utils.py:118)
+    normal = rs.standard_normal((H, W, 3)).astype(np.float32) * mask[:, :, None]
+    normal[18:20, 25:31] = 0.0          # depth2normal boundary zeros (loss_utils.py:156-157)
+    gt_normal = rs.standard_normal((H, W, 3)).astype(np.float32)
+    min_sdf = (np.where(mask, -2e-5, 8e-4 * np.sqrt(r2)) + 3e-5 * rs.standard_normal((H, W))).astype(np.float32)
+    thr = 5e-5
+    d, n, q = (torch.from_numpy(a).clone().requires_grad_(True) for a in (depth, normal, min_sdf))
+    m, g = torch.from_numpy(mask), torch.from_numpy(gt_mask)
+    lg, lo, _ = LU.compute_loss_mask(q, m, g, threshold=thr)
+    ld, _ = LU.compute_loss_depth(d, m, torch.from_numpy(gt_depth), g)
+    ln, _ = LU.compute_loss_normal(n, m, torch.from_numpy(gt_normal), g)
+    w = np.array([1.0, 0.7, 10.0, 5.0], np.float32)      # upstream gradients of the four terms
+    (w[0] * lg + w[1] * lo + w[2] * ld + w[3] * ln).backward()
+    np.savez_compressed(os.path.join(OUT, 'g7_single_losses.npz'), H=H, W=W, threshold=thr, depth=depth, normal=normal,
+                        mask=mask.astype(np.uint8), min_sdf=min_sdf, gt_depth=gt_depth, gt_normal=gt_normal,
+                        gt_mask=gt_mask.astype(np.uint8), weights=w,
+                        losses=np.array([lg.item(), lo.item(), ld.item(), ln.item()], np.float64),
+                        g_depth=d.grad.numpy(), g_normal=n.grad.numpy(), g_min_sdf=q.grad.numpy())
+    print('g7 losses', lg.item(), lo.item(), ld.item(), ln.item(), 'sets', int((g & ~m).sum()), int((m & ~g).sum()))
+    # empty-set case: identical masks -> both hinge terms are 0 with zero gradient
+    lg0, lo0, _ = LU.compute_loss_mask(q.detach().requires_grad_(True), m, m, threshold=thr)
+    assert lg0.item() == 0.0 and lo0.item() == 0.0
+
+
+def golden_g8():
+    rh.install_shims()
+    SDFRenderer_warp = rh.reference_modules()[1]
+    Ws, bs, _ = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    H, W = 40, 56
+    K = fixture.make_intrinsic(H, W)
+    R1, T1 = fixture.make_camera(10, 15, 1.6, 0)
+    R2, T2 = fixture.make_camera(24, 12, 1.7, 3.0)
+    z1, hit1 = sphere_view(K, R1, T1, H, W, 0.55, (0.03, -0.02, 0.05))
+    z2, hit2 = sphere_view(K, R2, T2, H, W, 0.55, (0.03, -0.02, 0.05))
+    z2 = z2.copy()
+    z2[hit2] += np.where(np.arange(int(hit2.sum())) % 7 == 0, 0.2, 0.0).astype(np.float32)   # inconsistent depth -> dropped points
+    img1, img2 = procedural_images(H, W)
+    r = SDFRenderer_warp(dec, K, img_hw=(H, W), march_step=10, buffer_size=1, use_gpu=False)
+    r.device = torch.device('cpu')
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32)).clone().requires_grad_(True)
+    Z1, tR1, tT1, tR2, tT2 = t(z1), t(R1), t(T1), t(R2), t(T2)
+    m1 = torch.from_numpy(hit1)
+    out1 = (Z1, m1, torch.zeros(H * W))
+    out2 = (torch.from_numpy(z2), torch.from_numpy(hit2), torch.zeros(H * W))
+    thres = 1e-3
+    xy, vmi, vdi = r.get_valid_points(out1, out2, tR1, tT1, tR2, tT2, thres)
+    loss, c1, c2 = r.compute_loss_color(torch.from_numpy(img1), torch.from_numpy(img2), xy, m1, vmi, vdi)
+    (2.5 * loss).backward()
+    keep = np.zeros(H * W, np.uint8)
+    keep[np.nonzero(hit1)[0][vdi.numpy().astype(bool)]] = 1
+    np.savez_compressed(os.path.join(OUT, 'g8_warp_loss.npz'), H=H, W=W, K=K, R1=R1, T1=T1, R2=R2, T2=T2, thres_depth=thres,
+                        zdepth1=z1, mask1=hit1.astype(np.uint8), zdepth2=z2, img1=img1, img2=img2, g_loss=np.float32(2.5),
+                        loss_color=np.float64(loss.item()), keep=keep, color_valid_1=c1.detach().numpy(), color_valid_2=c2.detach().numpy(),
+                        g_zdepth1=Z1.grad.numpy(), g_R1=tR1.grad.numpy(), g_T1=tT1.grad.numpy(), g_R2=tR2.grad.numpy(), g_T2=tT2.grad.numpy())
+    print('g8 loss', loss.item(), 'valid', int(hit1.sum()), 'kept', int(keep.sum()),
+          'gz', float(Z1.grad.abs().max()), 'gR1', float(tR1.grad.abs().max()), 'gT2', float(tT2.grad.abs().max()))
+
+
+if __name__ == '__main__':
+    golden_g7()
+    golden_g8()

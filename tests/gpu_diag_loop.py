@@ -17,6 +17,9 @@ from core.sdfrenderer import SDFRenderer  # noqa: E402
 from distr import fixture  # noqa: E402
 
 
+FUSED = os.environ.get('DIAG_FUSED', '1') == '1'   # 0: the PyTorch restatement of the losses (core/utils/loss_utils.py)
+
+
 def main():
     Ws, bs, latent = fixture.make_decoder_weights()
     dec = Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=(), latent_in=[4])
@@ -46,10 +49,16 @@ def main():
                 sync(); t1 = time.perf_counter()
                 # losses on the already rendered images (same code path as compute_all_loss after its render call)
                 from core.utils import loss_utils as LU
+                from distr import functions
                 depth, normal, mask, min_sdf = out
-                lg, lo, _ = LU.compute_loss_mask(min_sdf, mask, gt['silhouette'], threshold=r.get_threshold())
-                ld, _ = LU.compute_loss_depth(depth, mask, gt['depth'], gt['silhouette'])
-                ln, _ = LU.compute_loss_normal(normal, mask, gt['normal'], gt['silhouette'])
+                if FUSED:
+                    tm = functions.single_view_losses(r._engine, depth, normal, mask, min_sdf, gt['depth'], gt['normal'], gt['silhouette'],
+                                                      r.get_threshold())
+                    lg, lo, ld, ln = tm[0], tm[1], tm[2], tm[3]
+                else:
+                    lg, lo, _ = LU.compute_loss_mask(min_sdf, mask, gt['silhouette'], threshold=r.get_threshold())
+                    ld, _ = LU.compute_loss_depth(depth, mask, gt['depth'], gt['silhouette'])
+                    ln, _ = LU.compute_loss_normal(normal, mask, gt['normal'], gt['silhouette'])
                 loss = 10.0 * ld + 5.0 * ln + lg + lo + lat.pow(2).mean()
                 sync(); t2 = time.perf_counter()
                 loss.backward()
@@ -68,8 +77,8 @@ def main():
                 loss.backward()
                 opt.step()
             sync(); free = (time.perf_counter() - t0) * 1e3 / iters
-            print('%4dx%-4d d2n=%d valid=%6d | render %.2f  losses %.2f  backward %.2f  adam %.2f  sum %.2f ms | free-running %.2f ms/iter'
-                  % (size, size, d2n, int(m.sum()), acc[0], acc[1], acc[2], acc[3], acc[4], free))
+            print('fused=%d %4dx%-4d d2n=%d valid=%6d | render %.2f  losses %.2f  backward %.2f  adam %.2f  sum %.2f ms | free-running %.2f ms/iter'
+                  % (FUSED, size, size, d2n, int(m.sum()), acc[0], acc[1], acc[2], acc[3], acc[4], free))
 
 
 if __name__ == '__main__':

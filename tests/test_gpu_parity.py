@@ -533,3 +533,119 @@ def test_row_band_argument_checks(engine, fixture_decoder):
     f_full, _ = engine.ctx.workspace_bytes(binding.make_cfg((64, 64), K))
     f_band, _ = engine.ctx.workspace_bytes(binding.make_cfg((64, 64), K, band=(16, 32)))
     assert f_band < 0.6 * f_full
+
+
+# ------------------------------------------------------------------------------------------ fused losses (rows f2, f3)
+def _single_loss_hip(engine, g, weights):
+    import torch
+    from distr import functions
+    c = lambda k: None if g.get(k) is None else torch.from_numpy(np.ascontiguousarray(g[k])).cuda()
+    d, n, q = (c(k).requires_grad_(True) for k in ('depth', 'normal', 'min_sdf'))
+    terms = functions.single_view_losses(engine, d, n, c('mask'), q, c('gt_depth'), c('gt_normal'), c('gt_mask'), float(g['threshold']))
+    (terms * torch.from_numpy(np.asarray(weights, np.float32)).cuda()).sum().backward()
+    return terms.detach().cpu().numpy(), d.grad.cpu().numpy(), n.grad.cpu().numpy(), q.grad.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_fused_single_view_losses_match_reference_golden(engine):
+    """Row f3 / G7: distr_single_loss_forward/_backward against the reference's compute_loss_mask/_depth/_normal."""
+    g = dict(np.load(os.path.join(GOLDEN, 'g7_single_losses.npz')))
+    terms, gd, gn, gq = _single_loss_hip(engine, g, g['weights'])
+    assert np.allclose(terms, g['losses'], rtol=2e-6, atol=1e-9), (terms, g['losses'])
+    for name, a in (('g_depth', gd), ('g_normal', gn), ('g_min_sdf', gq)):
+        assert np.abs(a - g[name]).max() <= 2e-6 * np.abs(g[name]).max(), name
+    # empty sets (identical masks, no depth / normal ground truth): every term 0, every gradient 0
+    g2 = dict(g, gt_mask=g['mask'], gt_depth=None, gt_normal=None)
+    terms, gd, gn, gq = _single_loss_hip(engine, g2, g['weights'])
+    assert (terms == 0).all() and (gd == 0).all() and (gn == 0).all() and (gq == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size', [(37, 53), (512, 512)])
+def test_fused_single_view_losses_match_oracle(engine, size):
+    """Seeded random inputs at an odd size and at the C3 size against the CPU oracle (float summation order differs)."""
+    import torch
+    from oracle import loss_oracle
+    H, W = size
+    rs = np.random.RandomState(H * 1000 + W)
+    g = dict(threshold=5e-5, depth=(1 + rs.rand(H, W)).astype(np.float32), normal=rs.standard_normal((H, W, 3)).astype(np.float32),
+             mask=(rs.rand(H, W) < 0.5).astype(np.uint8), min_sdf=(2e-4 * rs.standard_normal((H, W))).astype(np.float32),
+             gt_depth=np.where(rs.rand(H, W) < 0.9, 1 + rs.rand(H, W), 0).astype(np.float32),
+             gt_normal=rs.standard_normal((H, W, 3)).astype(np.float32), gt_mask=(rs.rand(H, W) < 0.5).astype(np.uint8))
+    g['normal'][rs.rand(H, W) < 0.1] = 0
+    w = [1.0, 2.0, 10.0, 5.0]
+    terms, gd, gn, gq = _single_loss_hip(engine, g, w)
+    d, n, q = (torch.from_numpy(g[k]).clone().requires_grad_(True) for k in ('depth', 'normal', 'min_sdf'))
+    ref = loss_oracle.single_view_losses(d, n, torch.from_numpy(g['mask']), q, torch.from_numpy(g['gt_depth']),
+                                         torch.from_numpy(g['gt_normal']), torch.from_numpy(g['gt_mask']), 5e-5)
+    sum(wi * t for wi, t in zip(w, ref)).backward()
+    assert np.allclose(terms, [float(t) for t in ref], rtol=2e-5, atol=1e-9)
+    for a, t in ((gd, d), (gn, n), (gq, q)):
+        assert np.abs(a - t.grad.numpy()).max() <= 1e-5 * np.abs(t.grad.numpy()).max()
+    # bit-reproducible (ordered reductions)
+    again = _single_loss_hip(engine, g, w)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip((terms, gd, gn, gq), again))
+
+
+def _warp_hip(engine, g, g_loss):
+    import torch
+    from distr import binding, functions
+    H, W = int(g['H']), int(g['W'])
+    c = lambda k: torch.from_numpy(np.ascontiguousarray(np.asarray(g[k], np.float32))).cuda()
+    z1, R1, T1, R2, T2 = (c(k).requires_grad_(True) for k in ('zdepth1', 'R1', 'T1', 'R2', 'T2'))
+    wcfg = binding.make_warp_cfg((H, W), g['K'], float(g['thres_depth']))
+    loss, keep, c1, c2 = functions.warp_loss(engine, wcfg, z1, torch.from_numpy(g['mask1']).cuda(), c('zdepth2'), c('img1'), c('img2'),
+                                             R1, T1, R2, T2)
+    (float(g_loss) * loss).backward()
+    return (float(loss), keep.cpu().numpy(), c1.cpu().numpy(), c2.cpu().numpy(),
+            [t.grad.cpu().numpy() for t in (z1, R1, T1, R2, T2)])
+
+
+@pytest.mark.gpu
+def test_fused_warp_loss_matches_reference_golden(engine):
+    """Row f2 / G8: distr_warp_loss_forward/_backward against the reference's get_valid_points + compute_loss_color:
+    loss, kept set, sampled colours, gradients to the view-1 depth and all four camera tensors."""
+    g = dict(np.load(os.path.join(GOLDEN, 'g8_warp_loss.npz')))
+    loss, keep, c1, c2, grads = _warp_hip(engine, g, g['g_loss'])
+    assert (keep != g['keep']).sum() == 0
+    assert abs(loss - float(g['loss_color'])) <= 2e-6
+    assert np.abs(c1 - g['color_valid_1']).max() == 0 and np.abs(c2 - g['color_valid_2']).max() <= 2e-5
+    for name, a in zip(('g_zdepth1', 'g_R1', 'g_T1', 'g_R2', 'g_T2'), grads):
+        assert np.abs(a.reshape(-1) - g[name].reshape(-1)).max() <= 2e-4 * np.abs(g[name]).max(), name
+
+
+@pytest.mark.gpu
+def test_fused_warp_loss_matches_oracle_and_edge_cases(engine):
+    import torch
+    from oracle import loss_oracle
+    from oracle.gen_synth import sphere_view, procedural_images
+    from distr import fixture
+    H, W = 96, 128
+    K = fixture.make_intrinsic(H, W)
+    R1, T1 = fixture.make_camera(-20, 10, 1.5, 0)
+    R2, T2 = fixture.make_camera(-5, 25, 1.8, -4.0)
+    z1, hit1 = sphere_view(K, R1, T1, H, W, 0.6, (0.0, 0.05, -0.04))
+    z2, _ = sphere_view(K, R2, T2, H, W, 0.6, (0.0, 0.05, -0.04))
+    img1, img2 = procedural_images(H, W)
+    g = dict(H=H, W=W, K=K, R1=R1, T1=T1, R2=R2, T2=T2, thres_depth=1e-3, zdepth1=z1, mask1=hit1.astype(np.uint8), zdepth2=z2,
+             img1=img1, img2=img2)
+    loss, keep, c1, c2, grads = _warp_hip(engine, g, 1.0)
+    t = lambda k: torch.from_numpy(np.asarray(g[k], np.float32)).clone().requires_grad_(True)
+    tz, tR1, tT1, tR2, tT2 = t('zdepth1'), t('R1'), t('T1'), t('R2'), t('T2')
+    ol, okeep, oc1, oc2 = loss_oracle.warp_loss(K, H, W, tz, torch.from_numpy(g['mask1']), torch.from_numpy(z2), torch.from_numpy(img1),
+                                                torch.from_numpy(img2), tR1, tT1, tR2, tT2, 1e-3)
+    ol.backward()
+    flips = int((keep.astype(bool) != okeep.numpy()).sum())
+    assert keep.sum() > 500 and flips <= 2, flips
+    assert abs(loss - float(ol)) <= 1e-5 + 1e-3 * flips
+    if flips == 0:
+        for a, v in zip(grads, (tz, tR1, tT1, tR2, tT2)):
+            assert np.abs(a.reshape(-1) - v.grad.numpy().reshape(-1)).max() <= 5e-4 * np.abs(v.grad.numpy()).max()
+    # no valid pixel in view 1: loss 0, zero gradients (renderer_warp.py:111-113)
+    g0 = dict(g, mask1=np.zeros(H * W, np.uint8))
+    loss0, keep0, _, _, grads0 = _warp_hip(engine, g0, 1.0)
+    assert loss0 == 0.0 and keep0.sum() == 0 and all((a == 0).all() for a in grads0)
+    # every point fails the depth test: mean over an empty set is NaN, as torch.mean of an empty tensor
+    g1 = dict(g, zdepth2=(z2 + 5.0).astype(np.float32))
+    loss1, keep1, _, _, _ = _warp_hip(engine, g1, 1.0)
+    assert np.isnan(loss1) and keep1.sum() == 0

@@ -155,3 +155,34 @@ def test_noise_floor_recorded():
     # the reference's own sensitivity to 1e-7 relative weight noise (context for the tolerances above)
     assert f['recursive_flips'] == 0 and f['pyramid_recursive_flips'] == 0
     assert float(f['pyramid_recursive_normal']) > 1e-4     # normals are NOT reproducible to 1e-4 even by the reference
+
+
+def test_loss_oracle_single_view_vs_reference_golden():
+    """G7: the oracle's restatement of compute_loss_mask/_depth/_normal against the reference's own values + gradients."""
+    import torch
+    from oracle import loss_oracle
+    g = dict(np.load(os.path.join(GOLDEN, 'g7_single_losses.npz')))
+    d, n, q = (torch.from_numpy(g[k]).clone().requires_grad_(True) for k in ('depth', 'normal', 'min_sdf'))
+    terms = loss_oracle.single_view_losses(d, n, torch.from_numpy(g['mask']), q, torch.from_numpy(g['gt_depth']),
+                                           torch.from_numpy(g['gt_normal']), torch.from_numpy(g['gt_mask']), float(g['threshold']))
+    sum(float(w) * t for w, t in zip(g['weights'], terms)).backward()
+    assert np.allclose([float(t) for t in terms], g['losses'], rtol=1e-6, atol=1e-9)
+    for k, t in (('g_depth', d), ('g_normal', n), ('g_min_sdf', q)):
+        assert np.abs(t.grad.numpy() - g[k]).max() <= 1e-6 * max(np.abs(g[k]).max(), 1e-30), k
+
+
+def test_loss_oracle_warp_vs_reference_golden():
+    """G8: the oracle's restatement of get_valid_points + compute_loss_color against the reference's own outputs."""
+    import torch
+    from oracle import loss_oracle
+    g = dict(np.load(os.path.join(GOLDEN, 'g8_warp_loss.npz')))
+    t = lambda k: torch.from_numpy(np.asarray(g[k], np.float32)).clone().requires_grad_(True)
+    z1, R1, T1, R2, T2 = t('zdepth1'), t('R1'), t('T1'), t('R2'), t('T2')
+    loss, keep, c1, c2 = loss_oracle.warp_loss(g['K'], int(g['H']), int(g['W']), z1, torch.from_numpy(g['mask1']), torch.from_numpy(g['zdepth2']),
+                                               torch.from_numpy(g['img1']), torch.from_numpy(g['img2']), R1, T1, R2, T2, float(g['thres_depth']))
+    (float(g['g_loss']) * loss).backward()
+    assert abs(float(loss) - float(g['loss_color'])) <= 1e-6
+    assert (keep.numpy().astype(np.uint8) == g['keep']).all()
+    assert np.abs(c2.numpy() - g['color_valid_2']).max() <= 1e-6 and np.abs(c1.numpy() - g['color_valid_1']).max() == 0
+    for k, v in (('g_zdepth1', z1), ('g_R1', R1), ('g_T1', T1), ('g_R2', R2), ('g_T2', T2)):
+        assert np.abs(v.grad.numpy() - g[k]).max() <= 2e-6 * np.abs(g[k]).max(), k
