@@ -1,0 +1,118 @@
+"""optimize_multi_view: shape-code (+ optional sim(3)) optimisation on posed multi-view images (reference:
+core/inv_optimizer/optimize_multi.py:35-109). Same signature; the evaluator / visualiser hooks (mesh extraction,
+chamfer distance, plots: out of scope) are called only when such objects are passed in.
+
+MI355X-first difference: the `num_views_per_round` view pairs of one round are independent given (shape code, sim3), and
+each is two small latency-bound renders (137x137 in the PMO setting) that fill a few percent of the chip. They are
+therefore issued round-robin on a small pool of HIP streams (`streams=`): libdistr enqueues on the caller's current
+stream and never synchronises, PyTorch replays each pair's backward on the stream its forward ran on, so forward and
+backward of different pairs overlap on the idle CUs. The loss sum and every gradient are accumulated in the same order
+as in the sequential loop (the per-pair losses are added on the main stream in pair order), so results do not depend on
+the number of streams.
+"""
+import os
+
+import numpy as np
+import torch
+
+from core.utils.train_utils import params_to_mtrx
+
+from .loss_multi import compute_loss_color_warp
+
+
+class _StreamPool(object):
+    def __init__(self, n, device):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(int(n), 0))]
+
+    def run(self, i, fn):
+        """Runs fn() on stream i of the pool (fork from / join into the current stream). Returns fn's result."""
+        if not self.streams:
+            return fn()
+        main = torch.cuda.current_stream()
+        side = self.streams[i % len(self.streams)]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+        return out
+
+    def join(self, tensors=()):
+        if not self.streams:
+            return
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            main.wait_stream(s)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(main)
+
+
+def pair_indices(idx, i, rot_freq, sep_dist, num_images):
+    """The (idx1, idx2) view pair of slot i in round idx (optimize_multi.py:62-65)."""
+    idx1 = idx + int(np.floor(i * rot_freq))
+    idx2 = idx1 + sep_dist
+    if idx2 >= num_images:
+        idx1 = num_images - 1
+        idx2 = idx1 - sep_dist
+    return idx1, idx2
+
+
+def multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, sim3=None, sim3_scale=None, visualizer=None,
+                     pool=None):
+    """Sum of compute_loss_color_warp over `pairs` (the body of optimize_multi.py:59-76), pairs issued on the stream pool."""
+    results = []
+    for i, (idx1, idx2) in enumerate(pairs):
+        fn = (lambda a=idx1, b=idx2: compute_loss_color_warp(renderer, shape_code, images, cameras, a, b, weight_list,
+                                                             sim3=sim3, sim3_scale=sim3_scale, visualizer=visualizer))
+        results.append(pool.run(i, fn) if pool is not None else fn())
+    if pool is not None:
+        pool.join([r[0] for r in results])
+    loss_total = 0.0
+    for loss, _ in results:
+        loss_total = loss_total + loss
+    return loss_total, results[-1][1]
+
+
+def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images, cameras, weight_list,
+                        num_views_per_round=8, num_iters=20, num_sample_points=30000, sep_dist=1, test_step=5, points_gt=None,
+                        sim3=None, sim3_init=None, visualizer=None, vis_dir=None, vis_flag=None, full_flag=True, streams=4,
+                        on_round=None):
+    num_images = len(images)
+    rot_freq = num_images / num_views_per_round
+    pool = _StreamPool(streams if visualizer is None else 0, shape_code.device)
+    if evaluator is not None and vis_dir is not None:
+        evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points, fname=os.path.join(vis_dir, 'mesh_initial.ply'), silent=True)
+    best_chamfer, best_epoch = 100, 0
+    loss_pack = None
+    for epoch in range(num_iters):
+        for idx in range(0, int(np.ceil(rot_freq)), sep_dist):
+            shape_optimizer.zero_grad()
+            sim_mtrx, sim3_scale = None, None
+            if sim3 is not None:
+                m = params_to_mtrx(sim3)
+                rot = torch.matmul(m[:3, :3], sim3_init[:3, :3])
+                trans = torch.matmul(m[:3, :3], sim3_init[:, 3]) + m[:, 3]
+                sim_mtrx = torch.cat([rot, trans[:, None]], dim=1)
+                sim3_scale = torch.norm(rot) / np.sqrt(3)
+            pairs = [pair_indices(idx, i, rot_freq, sep_dist, num_images) for i in range(num_views_per_round)]
+            loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, sim3=sim_mtrx,
+                                                     sim3_scale=sim3_scale, visualizer=visualizer, pool=pool)
+            loss_total.backward()
+            shape_optimizer.step()
+            if on_round is not None:
+                on_round(epoch, idx, loss_total.detach(), loss_pack)
+        if vis_flag and visualizer is not None:
+            print('[{0}] loss_color: {1:.4f}, loss_l2reg: {2:.4f}\n'.format(epoch, loss_pack['color'], loss_pack['l2reg']))
+            visualizer.show_all_data_color_warp(os.path.join(vis_dir, 'vis_{}.png'.format(epoch)))
+        if evaluator is not None and vis_dir is not None and epoch % test_step == 0:
+            points_pred = evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points,
+                                                         fname=os.path.join(vis_dir, 'mesh_{}.ply'.format(epoch)), silent=True)
+            if points_pred is None:
+                print('The current latent code does not correspond to a valid shape.')
+            elif points_gt is not None and full_flag:
+                dist1, dist2 = evaluator.compute_chamfer_distance(points_gt, points_pred, separate=True)
+                if (dist1 + dist2) * 1000 < best_chamfer:
+                    best_chamfer, best_epoch = (dist1 + dist2) * 1000, epoch
+                    evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points, fname=os.path.join(vis_dir, 'mesh_best.ply'), silent=True)
+                print('CHAMFER DISTANCE: {0:.3f} & {1:.3f} at epoch {2}'.format(dist1 * 1000, dist2 * 1000, epoch))
+                print('BEST SUM CHAMFER DISTANCE: {0:.3f} at epoch {1}'.format(best_chamfer, best_epoch))
+    return shape_code, shape_optimizer

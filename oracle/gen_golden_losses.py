@@ -1,13 +1,15 @@
 """TEST INFRASTRUCTURE -- golden vectors for the fused loss kernels, produced by running the
 REFERENCE's own functions on CPU on synthetic inputs (needs /root/reference; see oracle/ref_harness.py for the shims).
 
-    python oracle/gen_golden_losses.py     # writes tests/golden/g7_single_losses.npz, tests/golden/g8_warp_loss.npz
+    python oracle/gen_golden_losses.py     # writes tests/golden/g7_single_losses.npz, g8_warp_loss.npz, g9_multi_view_round.npz
 
 G7: core/utils/loss_utils.py compute_loss_mask / compute_loss_depth / compute_loss_normal on a synthetic render +
     ground truth: the four loss values and their autograd gradients w.r.t. depth, normal, min_sdf.
 G8: SDFRenderer_warp.get_valid_points + compute_loss_color (core/sdfrenderer/renderer_warp.py:18-101) on analytic
     sphere depth maps of two views: loss_color, the kept-point images, and the autograd gradients w.r.t. the view-1
     depth and all four camera tensors.
+G9: two view pairs of the multi-view round (loss_multi.py:6-49 via optimize_multi.py:50-79) with a sim(3): summed loss
+    and gradients w.r.t. the shape code and the sim(3) parameters.
 The goldens are data (inputs + reference outputs); no reference source is copied.
 """
 import os
@@ -97,6 +99,58 @@ def golden_g8():
           'gz', float(Z1.grad.abs().max()), 'gR1', float(tR1.grad.abs().max()), 'gT2', float(tT2.grad.abs().max()))
 
 
+class _Cam(object):
+    def __init__(self, R, T):
+        self.extrinsic = np.concatenate([R, T[:, None]], 1).astype(np.float32)
+
+
+def golden_g9():
+    """G9: two view pairs of the multi-view round (optimize_multi.py:50-79 -> compute_loss_color_warp, loss_multi.py:6-49)
+    with a non-trivial sim(3): summed loss and its gradients w.r.t. the shape code and the sim(3) parameters."""
+    rh.install_shims()
+    rh.install_device_shims()
+    SDFRenderer_warp = rh.reference_modules()[1]
+    from core.inv_optimizer.loss_multi import compute_loss_color_warp
+    from core.utils.train_utils import params_to_mtrx
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    cams = [fixture.make_camera(az, 15, 1.6, 0) for az in (10, 22, 34)]
+    img_a, img_b = procedural_images(H, W)
+    imgs = [img_a, img_b, (0.5 * (img_a + img_b[::-1])).astype(np.float32)]
+    r = SDFRenderer_warp(dec, K, img_hw=(H, W), march_step=50, buffer_size=1, use_gpu=False)
+    r.device = torch.device('cpu')
+    lat = torch.from_numpy(latent).clone().requires_grad_(True)
+    sim3 = {'rot': torch.tensor([0.02, -0.01, 0.015], requires_grad=True), 'scale': torch.tensor(0.03, requires_grad=True),
+            'trans': torch.tensor([0.01, 0.02, -0.015], requires_grad=True)}
+    sim3_init = torch.cat([torch.eye(3), torch.zeros(3, 1)], 1)
+    sim_mtrx = params_to_mtrx(sim3).clone()
+    sim_mtrx[:, 3] = torch.matmul(sim_mtrx[:3, :3].clone(), sim3_init[:, 3]) + sim_mtrx[:, 3].clone()
+    sim_mtrx[:3, :3] = torch.matmul(sim_mtrx[:3, :3].clone(), sim3_init[:3, :3])
+    sim3_scale = torch.norm(sim_mtrx[:3, :3].clone()) / np.sqrt(3)
+    weights = {'color': 5.0, 'l2reg': 1.0}
+    cameras = [_Cam(R, T) for R, T in cams]
+    images = [torch.from_numpy(i) for i in imgs]
+    total, packs = 0.0, []
+    for (i1, i2) in ((0, 1), (1, 2)):
+        loss, pack = compute_loss_color_warp(r, lat, images, cameras, i1, i2, weights, sim3=sim_mtrx, sim3_scale=sim3_scale)
+        total = total + loss
+        packs.append([float(pack['color']), float(pack['l2reg'])])
+    total.backward()
+    np.savez_compressed(os.path.join(OUT, 'g9_multi_view_round.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent, K=K,
+                        H=H, W=W, march_step=50, buffer_size=1, extrinsics=np.stack([c.extrinsic for c in cameras]),
+                        images=np.stack(imgs), sim3_rot=sim3['rot'].detach().numpy(), sim3_scale=sim3['scale'].detach().numpy(),
+                        sim3_trans=sim3['trans'].detach().numpy(), w_color=5.0, w_l2reg=1.0, pairs=np.array([[0, 1], [1, 2]]),
+                        loss_total=np.float64(total.item()), packs=np.array(packs), sim_mtrx=sim_mtrx.detach().numpy(),
+                        g_latent=lat.grad.numpy(), g_rot=sim3['rot'].grad.numpy(), g_scale=sim3['scale'].grad.numpy(),
+                        g_trans=sim3['trans'].grad.numpy())
+    print('g9 total', total.item(), packs, 'glat', float(lat.grad.norm()), 'grot', sim3['rot'].grad.numpy(),
+          'gscale', float(sim3['scale'].grad), 'gtrans', sim3['trans'].grad.numpy())
+
+
 if __name__ == '__main__':
-    golden_g7()
-    golden_g8()
+    if sys.argv[1:2] != ['--g9']:
+        golden_g7()
+        golden_g8()
+    golden_g9()

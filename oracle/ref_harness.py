@@ -16,6 +16,8 @@ harness-side shims below (none of them edits reference code):
      accepted the (n,3) grad_outputs for an (n,1) output and summed it => 3x gradient);
   6. Tensor.cuda -> identity (renderer_warp.py:43);
   7. F.grid_sample forced to align_corners=True (torch 1.1 behaviour, loss_utils.py:24);
+  9. (install_device_shims, multi-view goldens only) torch.tensor / torch.eye with device='cuda' -> CPU
+     (train_utils.py:165-171);
   8. Tensor.type() reports 'torch.cuda.ByteTensor' for uint8 (loss_utils.py:43-47).
 """
 import os
@@ -87,6 +89,22 @@ def install_shims():
 
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def install_device_shims():
+    """Shim 9 (multi-view path only): torch.tensor / torch.eye called with a hard-coded device='cuda'
+    (core/utils/train_utils.py:165-171) build CPU tensors instead."""
+    for name in ('tensor', 'eye'):
+        orig = getattr(torch, name)
+        if getattr(orig, '_distr_shim', False):
+            continue
+
+        def wrapped(*a, _orig=orig, **k):
+            if k.get('device') == 'cuda':
+                k.pop('device')
+            return _orig(*a, **k)
+        wrapped._distr_shim = True
+        setattr(torch, name, wrapped)
 
 
 def reference_modules():

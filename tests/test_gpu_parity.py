@@ -649,3 +649,61 @@ def test_fused_warp_loss_matches_oracle_and_edge_cases(engine):
     g1 = dict(g, zdepth2=(z2 + 5.0).astype(np.float32))
     loss1, keep1, _, _, _ = _warp_hip(engine, g1, 1.0)
     assert np.isnan(loss1) and keep1.sum() == 0
+
+
+class _Cam(object):
+    def __init__(self, ext):
+        self.extrinsic = np.asarray(ext, np.float32)
+
+
+def _multi_view_setup(g):
+    import torch
+    from core.sdfrenderer import SDFRenderer_warp
+    from core.graph.deep_sdf_decoder import Decoder
+    from distr import fixture
+    Ws, bs, _ = fixture.make_decoder_weights()
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs))
+                         for n, a in (('weight', W), ('bias', b))})
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer_warp(dec.cuda(), g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']))
+    cams = [_Cam(e) for e in g['extrinsics']]
+    imgs = [torch.from_numpy(i).cuda() for i in g['images']]
+    return r, cams, imgs
+
+
+@pytest.mark.gpu
+def test_multi_view_round_matches_reference_golden():
+    """G9: two view pairs of the multi-view round (compute_loss_color_warp with a sim(3), loss_multi.py:6-49) against
+    the reference: summed loss, gradients w.r.t. the shape code and the sim(3) parameters; and the result does not
+    depend on how many HIP streams the pairs are issued on."""
+    import torch
+    from core.inv_optimizer import multi_view_round
+    from core.inv_optimizer.optimize_multi import _StreamPool
+    from core.utils.train_utils import params_to_mtrx
+    g = dict(np.load(os.path.join(GOLDEN, 'g9_multi_view_round.npz')))
+    r, cams, imgs = _multi_view_setup(g)
+    weights = {'color': float(g['w_color']), 'l2reg': float(g['w_l2reg'])}
+    outs = []
+    for nstreams in (0, 3):
+        lat = torch.from_numpy(g['latent']).cuda().requires_grad_(True)
+        sim3 = {'rot': torch.from_numpy(g['sim3_rot']).cuda().requires_grad_(True),
+                'scale': torch.tensor(float(g['sim3_scale']), device='cuda', requires_grad=True),
+                'trans': torch.from_numpy(g['sim3_trans']).cuda().requires_grad_(True)}
+        m = params_to_mtrx(sim3)
+        if nstreams == 0:
+            assert np.abs(m.detach().cpu().numpy() - g['sim_mtrx']).max() <= 1e-6
+        scale = torch.norm(m[:3, :3]) / np.sqrt(3)
+        total, pack = multi_view_round(r, lat, imgs, cams, [tuple(p) for p in g['pairs']], weights, sim3=m, sim3_scale=scale,
+                                       pool=_StreamPool(nstreams, lat.device))
+        total.backward()
+        torch.cuda.synchronize()
+        outs.append([float(total.detach())] + [t.grad.cpu().numpy() for t in (lat, sim3['rot'], sim3['scale'], sim3['trans'])])
+    tot, glat, grot, gscale, gtrans = outs[0]
+    assert abs(tot - float(g['loss_total'])) <= 2e-4 * abs(float(g['loss_total']))
+    assert abs(float(pack['color']) - g['packs'][-1, 0]) <= 1e-4
+    for name, a in (('g_latent', glat), ('g_rot', grot), ('g_scale', gscale), ('g_trans', gtrans)):
+        rel = np.abs(a - g[name]).max() / np.abs(g[name]).max()
+        assert rel <= 1e-2, (name, rel)
+    for a, b in zip(outs[0], outs[1]):     # stream count changes nothing
+        assert np.asarray(a).tobytes() == np.asarray(b).tobytes()
