@@ -19,24 +19,30 @@ def _engine(decoder, ref_tensor):
 
 
 def load_decoder(experiment_directory, checkpoint_num=None, color_size=None, experiment_directory_color=None, parallel=True):
-    """specs.json + ModelParameters/<ckpt>.pth -> Decoder (reference: decoder_utils.py:7-51); colour decoders are
-    out of scope."""
+    """specs.json + ModelParameters/<ckpt>.pth -> Decoder (reference: decoder_utils.py:7-51). With `color_size` the
+    colour decoder is built instead: latent = CodeLength + color_size, dims[3] += color_size, last_dim = 3, weights from
+    `experiment_directory_color` (saved without the DataParallel 'module.' prefix, decoder_utils.py:35-42)."""
     from core.graph.deep_sdf_decoder import Decoder
-    if color_size is not None:
-        raise NotImplementedError('colour decoders (SDFRenderer_color) are out of scope of this build')
     specs_filename = os.path.join(experiment_directory, 'specs.json')
     if not os.path.isfile(specs_filename):
         raise Exception('The experiment directory does not include specifications file "specs.json"')
     with open(specs_filename) as f:
         specs = json.load(f)
-    decoder = Decoder(specs['CodeLength'], **specs['NetworkSpecs'])
+    net = dict(specs['NetworkSpecs'])
+    if color_size is not None:
+        net['dims'] = list(net['dims'])
+        net['dims'][3] = net['dims'][3] + color_size
+        decoder = Decoder(specs['CodeLength'] + color_size, last_dim=3, **net)
+    else:
+        decoder = Decoder(specs['CodeLength'], **net)
     if parallel:
         decoder = torch.nn.DataParallel(decoder)
     if checkpoint_num is not None:
-        state = torch.load(os.path.join(experiment_directory, 'ModelParameters', checkpoint_num + '.pth'), map_location='cpu')
-        sd = state['model_state_dict']
-        if not parallel:
-            sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+        root = experiment_directory_color if color_size is not None else experiment_directory
+        state = torch.load(os.path.join(root, 'ModelParameters', checkpoint_num + '.pth'), map_location='cpu')
+        sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state['model_state_dict'].items()}
+        if parallel:
+            sd = {'module.' + k: v for k, v in sd.items()}
         decoder.load_state_dict(sd)
     return decoder
 
@@ -60,3 +66,15 @@ def decode_sdf_gradient(decoder, latent_vector, points, clamp_dist=0.1, MAX_POIN
     if clamp_dist is not None:
         g = g * (sdf.abs() <= clamp_dist).to(g.dtype)[:, None]
     return g
+
+
+def decode_color(decoder, color_code, shape_code, points, MAX_POINTS=100000, no_grad=False):
+    """(n,3) surface points -> (n,3) rgb of the colour decoder (decoder_utils.py:94-112). Forward-only, like every use in
+    the reference (demo/demo_360.py): no gradient reaches the codes or the points."""
+    if (not no_grad) and torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (color_code, shape_code, points)):
+        raise NotImplementedError('decode_color is forward-only here; pass no_grad=True or wrap in torch.no_grad().')
+    dev = points.device
+    if dev.type != 'cuda':
+        raise RuntimeError('decode_color: tensors must be on the GPU (no CPU path in this build)')
+    eng = functions.get_color_engine(decoder, dev.index if dev.index is not None else torch.cuda.current_device())
+    return functions.color_eval(eng, color_code, shape_code, points)

@@ -20,7 +20,9 @@ struct distr_ctx {
   int device = 0;
   std::string err;
   float* dec_buf = nullptr;  // one device allocation holding every packed array
-  size_t dec_floats = 0;
+  float* dec_buf_color = nullptr;   // same for the colour decoder (distr_set_color_decoder)
+  DecoderDev DC{};
+  bool has_color = false;
   DecoderDev D{};
   DecoderDev16 D16{};
   bool has_decoder = false;
@@ -243,19 +245,20 @@ int distr_create(distr_ctx** out, int hip_device) {
 void distr_destroy(distr_ctx* ctx) {
   if (!ctx) return;
   if (ctx->dec_buf) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf); }
+  if (ctx->dec_buf_color) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_color); }
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete ctx;
 }
 
 const char* distr_last_error(const distr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
-  if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
-  if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
-    return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
-                "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
-  static const int OUT[9] = {512, 512, 512, 253, 512, 512, 512, 512, 1};
-  static const int IN[9] = {259, 512, 512, 512, 512, 512, 512, 512, 512};
+// Packs one DeepSDF-8x512-shaped decoder for the tile kernels. nlat = latent length (the latent columns of lin0 / lin4 are
+// folded into per-call constants, so the tile itself never sees them); nout = rows of lin8 (1: SDF, 3: colour).
+static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, size_t n_floats, float** dev_buf, DecoderDev& D,
+                         DecoderDev16* D16) {
+  const int in0 = nlat + 3, in4 = 256 + nlat;
+  const int OUT[9] = {512, 512, 512, 253, 512, 512, 512, 512, nout};
+  const int IN[9] = {in0, 512, 512, 512, in4, 512, 512, 512, 512};
   size_t need = 0;
   for (int l = 0; l < 9; ++l) need += (size_t)OUT[l] * IN[l] + OUT[l];
   if (n_floats != need) return fail(ctx, DISTR_ERR_INVALID_ARG, "weight buffer has %zu floats, expected %zu", n_floats, need);
@@ -268,12 +271,12 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
   const int Op[8] = {512, 512, 512, 256, 512, 512, 512, 512};
   std::vector<std::vector<float>> Wp(8);
   for (int l = 0; l < 8; ++l) Wp[l].assign((size_t)Op[l] * Kp[l], 0.f);
-  for (int o = 0; o < 512; ++o) for (int k = 0; k < 3; ++k) Wp[0][(size_t)o * 8 + k] = W[0][(size_t)o * 259 + 256 + k];
+  for (int o = 0; o < 512; ++o) for (int k = 0; k < 3; ++k) Wp[0][(size_t)o * 8 + k] = W[0][(size_t)o * in0 + nlat + k];
   for (int l : {1, 2, 5, 6, 7}) memcpy(Wp[l].data(), W[l], sizeof(float) * 512 * 512);
   for (int o = 0; o < 253; ++o) memcpy(&Wp[3][(size_t)o * 512], &W[3][(size_t)o * 512], sizeof(float) * 512);
   for (int o = 0; o < 512; ++o) {
-    for (int k = 0; k < 253; ++k) Wp[4][(size_t)o * 256 + k] = W[4][(size_t)o * 512 + k];
-    for (int k = 0; k < 3; ++k) Wp[4][(size_t)o * 256 + 253 + k] = W[4][(size_t)o * 512 + 509 + k];
+    for (int k = 0; k < 253; ++k) Wp[4][(size_t)o * 256 + k] = W[4][(size_t)o * in4 + k];
+    for (int k = 0; k < 3; ++k) Wp[4][(size_t)o * 256 + 253 + k] = W[4][(size_t)o * in4 + 253 + nlat + k];
   }
 
   std::vector<float> host;
@@ -301,34 +304,73 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
     offB[l] = reserve(Op[l]);
     memcpy(host.data() + offB[l], b[l], sizeof(float) * OUT[l]);
   }
-  const size_t o_W0lat_t = reserve((size_t)LAT * HID), o_W4lat_t = reserve((size_t)LAT * HID);
-  const size_t o_W0lat = reserve((size_t)HID * LAT), o_W4lat = reserve((size_t)HID * LAT);
-  for (int o = 0; o < HID; ++o) for (int k = 0; k < LAT; ++k) {
-    const float v0 = W[0][(size_t)o * 259 + k], v4 = W[4][(size_t)o * 512 + 253 + k];
-    host[o_W0lat_t + (size_t)k * HID + o] = v0; host[o_W0lat + (size_t)o * LAT + k] = v0;
-    host[o_W4lat_t + (size_t)k * HID + o] = v4; host[o_W4lat + (size_t)o * LAT + k] = v4;
+  const size_t o_W0lat_t = reserve((size_t)nlat * HID), o_W4lat_t = reserve((size_t)nlat * HID);
+  const size_t o_W0lat = reserve((size_t)HID * nlat), o_W4lat = reserve((size_t)HID * nlat);
+  for (int o = 0; o < HID; ++o) for (int k = 0; k < nlat; ++k) {
+    const float v0 = W[0][(size_t)o * in0 + k], v4 = W[4][(size_t)o * in4 + 253 + k];
+    host[o_W0lat_t + (size_t)k * HID + o] = v0; host[o_W0lat + (size_t)o * nlat + k] = v0;
+    host[o_W4lat_t + (size_t)k * HID + o] = v4; host[o_W4lat + (size_t)o * nlat + k] = v4;
   }
-  const size_t o_b0 = reserve(HID), o_b4 = reserve(HID), o_w8 = reserve(HID), o_W0x = reserve(3 * HID);
+  const size_t o_b0 = reserve(HID), o_b4 = reserve(HID), o_w8 = reserve((size_t)nout * HID), o_W0x = reserve(3 * HID);
   memcpy(host.data() + o_b0, b[0], sizeof(float) * HID);
   memcpy(host.data() + o_b4, b[4], sizeof(float) * HID);
-  memcpy(host.data() + o_w8, W[8], sizeof(float) * HID);
-  for (int o = 0; o < HID; ++o) for (int k = 0; k < 3; ++k) host[o_W0x + (size_t)k * HID + o] = W[0][(size_t)o * 259 + 256 + k];
+  memcpy(host.data() + o_w8, W[8], sizeof(float) * nout * HID);
+  for (int o = 0; o < HID; ++o) for (int k = 0; k < 3; ++k) host[o_W0x + (size_t)k * HID + o] = W[0][(size_t)o * in0 + nlat + k];
 
   HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->dec_buf) { HIP_TRY(hipFree(ctx->dec_buf)); ctx->dec_buf = nullptr; }
-  HIP_TRY(hipMalloc((void**)&ctx->dec_buf, host.size() * sizeof(float)));
-  HIP_TRY(hipMemcpy(ctx->dec_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
-  ctx->dec_floats = host.size();
-  DecoderDev& D = ctx->D;
-  const float* d = ctx->dec_buf;
+  if (*dev_buf) { HIP_TRY(hipFree(*dev_buf)); *dev_buf = nullptr; }
+  HIP_TRY(hipMalloc((void**)dev_buf, host.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(*dev_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  const float* d = *dev_buf;
   for (int l = 0; l < 8; ++l) { D.Wf[l] = d + offWf[l]; D.Wb[l] = l ? d + offWb[l] : nullptr; D.bias[l] = (l == 0 || l == 4) ? nullptr : d + offB[l]; }
   D.W0lat_t = d + o_W0lat_t; D.W4lat_t = d + o_W4lat_t; D.W0lat = d + o_W0lat; D.W4lat = d + o_W4lat;
   D.b0 = d + o_b0; D.b4 = d + o_b4; D.w8 = d + o_w8; D.W0x = d + o_W0x;
   D.b8 = b[8][0];
-  for (int l = 0; l < 8; ++l) ctx->D16.Wf[l] = d + offW16[l];
+  D.b8x[0] = nout > 1 ? b[8][1] : 0.f; D.b8x[1] = nout > 2 ? b[8][2] : 0.f;
+  D.nlat = nlat;
+  if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
+  return DISTR_OK;
+}
+
+int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
+  if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
+    return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
+                "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
+  int rc = build_decoder(ctx, LAT, 1, w, n_floats, &ctx->dec_buf, ctx->D, &ctx->D16);
+  if (rc) return rc;
   ctx->has_decoder = true;
   return DISTR_OK;
 }
+
+int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
+  if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  if (desc->latent_size <= LAT || desc->latent_size > 4096 || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
+    return fail(ctx, DISTR_ERR_UNSUPPORTED, "colour decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: expected the "
+                "DeepSDF 8x512 shape with latent = 256 + color_size and last_dim = 3", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
+  int rc = build_decoder(ctx, desc->latent_size, 3, w, n_floats, &ctx->dec_buf_color, ctx->DC, nullptr);
+  if (rc) return rc;
+  ctx->has_color = true;
+  return DISTR_OK;
+}
+
+int distr_color_eval(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, float* rgb, void* ws, size_t ws_bytes,
+                     void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_color) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_color_decoder has not been called");
+  if (n < 0 || !latent_cat || (n > 0 && (!xyz || !rgb)) || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "colour workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)ws;
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->DC, latent_cat);
+  LAUNCH_CHECK("k_latent_consts");
+  if (n > 0) {
+    hipLaunchKernelGGL(k_color, dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, rgb, ctx->DC);
+    LAUNCH_CHECK("k_color");
+  }
+  return DISTR_OK;
+}
+
 
 int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* fwd, size_t* bwd) {
   int rc = check_cfg(ctx, cfg);

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, D
   const float* Wt = (gid < 512) ? D.W0lat_t : D.W4lat_t;
   float acc = (gid < 512) ? D.b0[o] : D.b4[o];
 #pragma unroll 8
-  for (int k = 0; k < LAT; ++k) acc = __builtin_fmaf(Wt[k * HID + o], latent[k], acc);
+  for (int k = 0; k < D.nlat; ++k) acc = __builtin_fmaf(Wt[k * HID + o], latent[k], acc);
   c0c4[gid] = acc;
 }
 
@@ -597,6 +597,36 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
     store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+  }
+}
+
+// decode_color (core/utils/decoder_utils.py:94-112) for the surface points of SDFRenderer_color.render_color
+// (core/sdfrenderer/renderer_rgb.py:20-38): the same fused tile on the colour decoder's weights (latent = shape code |
+// colour code, folded into c0 / c4), lin8 with three rows, tanh on each. Forward only.
+__global__ void __launch_bounds__(256, 1) k_color(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
+                                                  float* __restrict__ rgb, DecoderDev D) {
+  constexpr int RB = 2, TILE = 64;
+  __shared__ Smem<RB> S;
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  if (base >= n) return;
+  if (tid < TILE) {
+    const int64_t r = base + tid;
+    const bool v = r < n;
+    S.xyz[tid] = v ? xyz[r * 3] : 0.f; S.xyz[TILE + tid] = v ? xyz[r * 3 + 1] : 0.f; S.xyz[2 * TILE + tid] = v ? xyz[r * 3 + 2] : 0.f;
+  }
+  __syncthreads();
+  uint32_t masks[8][4];
+  float pre[3];
+  pre[0] = mlp_forward<RB, false>(D, c0c4, c0c4 + HID, S, masks);
+#pragma unroll
+  for (int c = 1; c < 3; ++c) {
+    __syncthreads();                       // S.part of the previous row has been read by everybody
+    pre[c] = lin8_row<RB>(D.w8 + c * HID, D.b8x[c - 1], S);
+  }
+  if (tid < TILE && base + tid < n) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[(base + tid) * 3 + c] = tanh_spec(pre[c]);
   }
 }
 

@@ -43,9 +43,11 @@ struct DecoderDev {
   const float* W4lat;   // [512][256]
   const float* b0;      // [512]
   const float* b4;      // [512]
-  const float* w8;      // [512]
+  const float* w8;      // [nout][512]  lin8 (nout = 1: SDF; 3: the colour decoder of decode_color)
   const float* W0x;     // [3][512]   lin0 xyz columns
-  float b8;
+  float b8;             // lin8 bias of row 0
+  float b8x[2];         // lin8 biases of rows 1, 2 (colour decoder)
+  int32_t nlat;         // latent length folded into c0 / c4 (256; 256 + color_size for the colour decoder)
 };
 
 // A tile = RB blocks of 32 rays. RB=2: 64 rays, 133 KiB LDS, one workgroup per CU. RB=1: 32 rays, 67 KiB LDS, two
@@ -269,6 +271,27 @@ __device__ __forceinline__ void load_mask_chunk(const uint4* blk, uint32_t (&mas
 
 // ---------------------------------------------------------------------------------------- forward tile
 // Preconditions: S.xyz rows 0..2 hold the TILE points (x row, y row, z row), visible to all threads (barrier done).
+// One row of lin8 on the h7 activations in S.X: four 128-long chains per ray (one per wave), combined in fixed order.
+// Returns (every thread, for ray = tid & (TILE-1)) the pre-tanh value. Ends with every thread past a barrier on S.part
+// reads only if the caller adds one before the next call (colour decoder: three rows).
+template <int RB>
+__device__ __forceinline__ float lin8_row(const float* __restrict__ w8row, float b8, Smem<RB>& S) {
+  constexpr int TILE = 32 * RB;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ray = tid & (TILE - 1);
+  {
+    float p = 0.f;
+    const float* w8 = w8row + wave * 128;
+    const float* xr = S.X + (size_t)wave * 128 * TILE + ray;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * TILE], p);
+    S.part[wave * TILE + ray] = p;   // (RB=1: both half-waves hold the same value)
+  }
+  __syncthreads();
+  return ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + b8;
+}
+
 // Returns (every thread, for ray = tid & (TILE-1)) the pre-tanh output. masks[l] = ReLU bitmasks of layer l
 // (bit rb*16+r of masks[l][ob]). DEBUG_STOP: (test builds only) return right after layer `stop` is in X.
 template <int RB, bool KEEP, bool DEBUG_STOP = false>
@@ -349,17 +372,7 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     DISTR_TS(2 * l + 2);
     if (DEBUG_STOP && stop == l) return 0.f;
   }
-  // lin8: four 128-long chains per ray (one per wave), combined in fixed order
-  {
-    float p = 0.f;
-    const float* w8 = D.w8 + wave * 128;
-    const float* xr = X + (size_t)wave * 128 * TILE + ray;
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * TILE], p);
-    S.part[wave * TILE + ray] = p;   // (RB=1: both half-waves hold the same value)
-  }
-  __syncthreads();
-  const float pre = ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+  const float pre = lin8_row<RB>(D.w8, D.b8, S);
   DISTR_TS(17);
 #undef DISTR_TS
   return pre;

@@ -21,7 +21,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
-           'distr_warp_loss_forward', 'distr_warp_loss_backward']
+           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval']
 
 
 class DistrError(RuntimeError):
@@ -133,6 +133,8 @@ def lib():
             L.distr_single_loss_backward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, u8p, fp, fp, fp, u8p, C.c_float, fp, fp, fp, fp, fp, vp]
             L.distr_warp_loss_forward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, u8p, fp, fp, vp, C.c_size_t, vp]
             L.distr_warp_loss_backward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
+            L.distr_set_color_decoder.argtypes = [vp, C.POINTER(DecoderDesc), C.POINTER(C.c_float), C.c_size_t]
+            L.distr_color_eval.argtypes = [vp, fp, fp, C.c_int64, fp, vp, C.c_size_t, vp]
             _lib = L
     return _lib
 
@@ -204,6 +206,11 @@ class Context(object):
         w = np.ascontiguousarray(flat_weights, dtype=np.float32)
         desc = DecoderDesc(256, 512, 9, 4)
         self.check(self.L.distr_set_decoder(self.h, C.byref(desc), w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
+
+    def set_color_decoder(self, flat_weights, latent_size):
+        w = np.ascontiguousarray(flat_weights, dtype=np.float32)
+        desc = DecoderDesc(int(latent_size), 512, 9, 4)
+        self.check(self.L.distr_set_color_decoder(self.h, C.byref(desc), w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
 
     def workspace_bytes(self, cfg):
         f, b = C.c_size_t(), C.c_size_t()

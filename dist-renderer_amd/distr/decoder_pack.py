@@ -63,6 +63,37 @@ def validate(Ws, bs):
                                      'latent 256, latent_in=[4], last_dim=1)' % (l, W.shape, _SHAPES[l]))
 
 
+def validate_color(Ws, bs):
+    """Colour decoder (load_decoder(color_size=cs), decoder_utils.py:16-24): returns its latent length 256 + cs."""
+    if len(Ws) != 9:
+        raise UnsupportedDecoder('expected 9 linear layers, got %d' % len(Ws))
+    cs = Ws[0].shape[1] - 3 - fixture.LATENT_SIZE
+    if cs <= 0:
+        raise UnsupportedDecoder('colour decoder must take latent = 256 + color_size (> 256), got %d' % (Ws[0].shape[1] - 3))
+    want = fixture.color_layer_shapes(cs)
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        if tuple(W.shape) != want[l] or b.shape != (want[l][0],):
+            raise UnsupportedDecoder('colour lin%d has shape %s, expected %s (DeepSDF 8x512 with latent 256+%d, latent_in=[4], '
+                                     'last_dim=3)' % (l, W.shape, want[l], cs))
+    return fixture.LATENT_SIZE + cs
+
+
+def flatten_color(Ws, bs):
+    """-> (flat f32 array for distr_set_color_decoder, latent length)."""
+    nlat = validate_color(Ws, bs)
+    parts = []
+    for W, b in zip(Ws, bs):
+        parts.append(np.asarray(W, np.float32).reshape(-1))
+        parts.append(np.asarray(b, np.float32).reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32), nlat
+
+
+def pack_color_module(decoder_color):
+    check_module_flags(decoder_color)
+    Ws, bs = effective_weights(decoder_color.state_dict())
+    return flatten_color(Ws, bs)
+
+
 def check_module_flags(decoder):
     """Rejects constructor options of core/graph/deep_sdf_decoder.py:19-73 that change the math."""
     d = decoder.module if hasattr(decoder, 'module') else decoder

@@ -67,6 +67,35 @@ def make_decoder_weights(seed=1234, latent_scale=0.003):
     return Ws, bs, latent
 
 
+def color_layer_shapes(color_size=256):
+    """(out, in) of lin0..lin8 of the colour decoder load_decoder(color_size=...) builds (decoder_utils.py:16-24):
+    latent = 256 + color_size, dims[3] += color_size (so lin3 still ends at 253 rows), last_dim = 3."""
+    lat = LATENT_SIZE + color_size
+    return [(512, lat + 3), (512, 512), (512, 512), (253, 512), (512, 512 + color_size), (512, 512), (512, 512), (512, 512), (3, 512)]
+
+
+def make_color_decoder_weights(seed=4321, color_size=256):
+    """Seed-defined synthetic colour decoder (no pretrained one exists in the tree): He-style hidden layers, small
+    latent columns, a last layer whose three rows differ so that r, g, b vary over the surface. Returns
+    (weights, biases, color_code (1, color_size))."""
+    rs = np.random.RandomState(seed)
+    Ws, bs = [], []
+    for l, (o, i) in enumerate(color_layer_shapes(color_size)):
+        W = rs.standard_normal((o, i)) * (math.sqrt(2.0) / math.sqrt(i))
+        b = 0.05 * rs.standard_normal((o,))
+        if l == 0:
+            W[:, :-3] *= 0.05                    # latent columns
+            W[:, -3:] *= 8.0                     # xyz columns: spatial variation
+        if l == 4:
+            W[:, 253:-3] *= 0.05
+        if l == 8:
+            W = rs.standard_normal((o, i)) * (1.5 / math.sqrt(i))
+        Ws.append(np.ascontiguousarray(W, dtype=np.float32))
+        bs.append(np.ascontiguousarray(b, dtype=np.float32))
+    color_code = (0.3 * rs.standard_normal((1, color_size))).astype(np.float32)
+    return Ws, bs, color_code
+
+
 def weights_sha256(Ws, bs):
     h = hashlib.sha256()
     for W, b in zip(Ws, bs):

@@ -46,6 +46,43 @@ def engine_from_weights(Ws, bs, device_index=0):
     return eng
 
 
+class ColorEngine(object):
+    """Packed colour decoder on one device (decode_color / SDFRenderer_color)."""
+
+    def __init__(self, decoder_color=None, device_index=0, weights=None):
+        self.ctx = binding.Context(device_index)
+        self.device = torch.device('cuda', device_index)
+        flat, nlat = decoder_pack.pack_color_module(decoder_color) if weights is None else decoder_pack.flatten_color(*weights)
+        self.latent_size = nlat
+        self.ctx.set_color_decoder(flat, nlat)
+
+
+_color_engines = weakref.WeakKeyDictionary()
+
+
+def get_color_engine(decoder_color, device_index):
+    per_dec = _color_engines.setdefault(decoder_color, {})
+    if device_index not in per_dec:
+        per_dec[device_index] = ColorEngine(decoder_color, device_index)
+    return per_dec[device_index]
+
+
+def color_eval(engine, color_code, shape_code, points):
+    """decode_color forward (core/utils/decoder_utils.py:94-112): points (n,3) -> rgb (n,3); the decoder input is
+    [shape_code | color_code | xyz] (decoder_utils.py:101-103)."""
+    dev = engine.device
+    lat = torch.cat([_f32c(shape_code, dev).reshape(-1), _f32c(color_code, dev).reshape(-1)])
+    if lat.numel() != engine.latent_size:
+        raise ValueError('shape code + colour code have %d entries, the colour decoder expects %d' % (lat.numel(), engine.latent_size))
+    x = _f32c(points, dev).reshape(-1, 3)
+    n = x.shape[0]
+    out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_color_eval(engine.ctx.h, p(lat), p(x), n, p(out), p(ws), ws.numel(), engine.ctx.stream()))
+    return out
+
+
 def _f32c(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 

@@ -163,6 +163,17 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
 int distr_profile_enable(distr_ctx* ctx, int enable);
 int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
 
+/* ---- Colour decoder: SDFRenderer_color.render_color (core/sdfrenderer/renderer_rgb.py:20-38) evaluates
+ * a second DeepSDF-8x512-shaped decoder with latent = [shape code | colour code] (256 + color_size) and last_dim = 3
+ * (load_decoder(color_size=...), core/utils/decoder_utils.py:16-24) at the surface points; decode_color
+ * (decoder_utils.py:94-112). Forward only, like the reference's demo use (demo/demo_360.py). Weights: same flat layout as
+ * distr_set_decoder with lin0 (512, 259+cs), lin4 (512, 512+cs), lin8 (3, 512); desc->latent_size = 256 + cs. */
+int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* weights, size_t n_floats);
+/* latent_cat[256+cs] = cat(shape_code, color_code) (device), xyz[n][3] -> rgb[n][3] = tanh(lin8(...)). Workspace:
+ * distr_mlp_workspace_bytes(n). */
+int distr_color_eval(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, float* rgb, void* ws, size_t ws_bytes,
+                     void* stream);
+
 /* ---- Image-space consumers right after the hot path, fused into a few element-wise
  * kernels. Same rules as above: caller-owned device buffers, everything enqueued on `stream`, no host sync. Scalars
  * (losses, their upstream gradients) live in device memory so that nothing has to be read back. */

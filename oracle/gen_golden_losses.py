@@ -10,6 +10,7 @@ G8: SDFRenderer_warp.get_valid_points + compute_loss_color (core/sdfrenderer/ren
     depth and all four camera tensors.
 G9: two view pairs of the multi-view round (loss_multi.py:6-49 via optimize_multi.py:50-79) with a sim(3): summed loss
     and gradients w.r.t. the shape code and the sim(3) parameters.
+G10 (--g10): decode_color + SDFRenderer_color.render with a seed-defined colour decoder (row f4).
 The goldens are data (inputs + reference outputs); no reference source is copied.
 """
 import os
@@ -149,7 +150,53 @@ def golden_g9():
           'gscale', float(sim3['scale'].grad), 'gtrans', sim3['trans'].grad.numpy())
 
 
+def golden_g10():
+    """G10 (row f4): the reference's decode_color (decoder_utils.py:94-112) on fixed points and
+    SDFRenderer_color.render (renderer_rgb.py:73-125) without and with a point light, using the seed-defined colour
+    decoder fixture (distr.fixture.make_color_decoder_weights)."""
+    rh.install_shims()
+    mods = rh.reference_modules()
+    Decoder, decoder_utils = mods[2], mods[3]
+    from core.sdfrenderer.renderer_rgb import SDFRenderer_color
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    cs = 256
+    Wc, bc, color_code = fixture.make_color_decoder_weights(color_size=cs)
+    dims = [512] * 8
+    dims[3] += cs
+    dec_c = Decoder(256 + cs, dims, last_dim=3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=(), latent_in=[4])
+    dec_c.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a.copy()) for l, (W, b) in enumerate(zip(Wc, bc))
+                           for n, a in (('weight', W), ('bias', b))})
+    dec_c.eval()
+    rs = np.random.RandomState(21)
+    pts = (rs.rand(2048, 3) * 1.6 - 0.8).astype(np.float32)
+    with torch.no_grad():
+        rgb = decoder_utils.decode_color(dec_c, torch.from_numpy(color_code), torch.from_numpy(latent), torch.from_numpy(pts), no_grad=True)
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(25, 20, 1.6, 0)
+    r = SDFRenderer_color(dec, dec_c, K, img_hw=(H, W), march_step=40, buffer_size=1, use_gpu=False)
+    r.device = torch.device('cpu')
+    tR, tT = torch.from_numpy(R), torch.from_numpy(T)
+    lat, cc = torch.from_numpy(latent), torch.from_numpy(color_code)
+    d, n, c, m, q = r.render(cc, lat, tR, tT, no_grad=True)
+    lights = np.array([[1.5, 1.0, -1.0]], np.float32)     # one light: the reference's torch.bmm(R[None], directions) (renderer_rgb.py:58) only accepts M = 1
+    energies = np.array([0.8], np.float32)
+    d2, n2, c2, m2, q2 = r.render(cc, lat, tR, tT, no_grad=True, lighting_locations=torch.from_numpy(lights),
+                                  lighting_energies=torch.from_numpy(energies))
+    np.savez_compressed(os.path.join(OUT, 'g10_color_render.npz'), weights_sha256=fixture.weights_sha256(Ws, bs),
+                        color_weights_sha256=fixture.weights_sha256(Wc, bc), color_size=cs, latent=latent, color_code=color_code,
+                        points=pts, rgb=rgb.numpy(), K=K, R=R, T=T, H=H, W=W, march_step=40, buffer_size=1,
+                        depth=d.detach().numpy(), normal=n.detach().numpy(), color=c.detach().numpy(), mask=m.numpy(), min_sdf=q.detach().numpy(),
+                        lights=lights, energies=energies, color_shaded=c2.detach().numpy())
+    print('g10 rgb range', float(rgb.min()), float(rgb.max()), 'valid', int(m.sum()), 'color mean', float(c.detach().abs().mean()),
+          'shaded mean', float(c2.detach().abs().mean()))
+
+
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--g10']:
+        golden_g10()
+        sys.exit(0)
     if sys.argv[1:2] != ['--g9']:
         golden_g7()
         golden_g8()

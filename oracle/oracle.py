@@ -49,6 +49,9 @@ def lib():
         fp = C.POINTER(C.c_float)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [fp, C.c_int64]
+        L.orc_create_color.restype = C.c_void_p
+        L.orc_create_color.argtypes = [fp, C.c_int64, C.c_int]
+        L.orc_color_eval.argtypes = [C.c_void_p, fp, fp, C.c_int64, fp]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
@@ -209,3 +212,31 @@ class Oracle(object):
                                        mask.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(min_sdf), _fp(depth), _fp(normal))
         return dict(zdepth=zdepth, mask=mask, min_sdf=min_sdf, depth=depth.reshape(cfg.H, cfg.W),
                     normal=normal.reshape(cfg.H, cfg.W, 3), state=RenderState(self, ptr, cfg))
+
+
+class ColorOracle(object):
+    """CPU restatement of decode_color (core/utils/decoder_utils.py:94-112) on the colour decoder
+    (latent = 256 + color_size, last_dim = 3)."""
+
+    def __init__(self, Ws, bs):
+        flat = flatten_decoder(Ws, bs)
+        self.nlat = int(np.asarray(Ws[0]).shape[1]) - 3
+        self.h = lib().orc_create_color(_fp(flat), flat.size, self.nlat)
+        if not self.h:
+            raise ValueError('not a DeepSDF 8x512-shaped colour decoder')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                lib().orc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def decode_color(self, color_code, shape_code, xyz):
+        lat = np.concatenate([_f32(shape_code).reshape(-1), _f32(color_code).reshape(-1)])
+        assert lat.size == self.nlat
+        x = _f32(xyz).reshape(-1, 3)
+        out = np.zeros((x.shape[0], 3), np.float32)
+        lib().orc_color_eval(self.h, _fp(lat), _fp(x), x.shape[0], _fp(out))
+        return out

@@ -110,7 +110,8 @@ def test_render_c1_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, marc
     assert res['flips'] == 0, res
 
 
-@pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))))
+@pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))
+                                          if not os.path.basename(p).startswith('g10')))
 def test_render_matches_reference_goldens(engine, name):
     """HIP path directly against outputs of the reference itself (tests/golden, made by oracle/gen_golden.py)."""
     from distr import fixture, decoder_pack, functions
@@ -707,3 +708,70 @@ def test_multi_view_round_matches_reference_golden():
         assert rel <= 1e-2, (name, rel)
     for a, b in zip(outs[0], outs[1]):     # stream count changes nothing
         assert np.asarray(a).tobytes() == np.asarray(b).tobytes()
+
+
+# ------------------------------------------------------------------------------------------ colour render (row f4)
+@pytest.mark.gpu
+def test_decode_color_matches_oracle_bitwise_and_reference(orc):
+    """distr_color_eval against the CPU oracle (same k-ordered chains -> bit-identical) at ragged sizes and against the
+    reference's decode_color (G10)."""
+    import torch
+    from distr import fixture, functions
+    g = dict(np.load(os.path.join(GOLDEN, 'g10_color_render.npz')))
+    Wc, bc, code = fixture.make_color_decoder_weights(color_size=int(g['color_size']))
+    eng = functions.ColorEngine(weights=(Wc, bc))
+    O = orc.ColorOracle(Wc, bc)
+    for n in (1, 63, 64, 65, 2048):
+        pts = g['points'][:n]
+        got = functions.color_eval(eng, torch.from_numpy(code).cuda(), torch.from_numpy(g['latent']).cuda(), torch.from_numpy(pts).cuda())
+        want = O.decode_color(code, g['latent'], pts)
+        assert got.shape == (n, 3) and got.cpu().numpy().tobytes() == want.tobytes(), n
+    assert np.abs(got.cpu().numpy() - g['rgb']).max() <= 2e-6
+    with pytest.raises(ValueError):
+        functions.color_eval(eng, torch.from_numpy(code[:, :10]).cuda(), torch.from_numpy(g['latent']).cuda(), torch.from_numpy(pts).cuda())
+
+
+@pytest.mark.gpu
+def test_color_render_matches_reference_golden(fixture_decoder):
+    """G10: SDFRenderer_color.render (renderer_rgb.py:73-125) through the drop-in API, plain and with a point light."""
+    import torch
+    from core.sdfrenderer import SDFRenderer_color
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.utils.decoder_utils import decode_color
+    from distr import fixture
+    g = dict(np.load(os.path.join(GOLDEN, 'g10_color_render.npz')))
+    Ws, bs, _ = fixture_decoder
+    cs = int(g['color_size'])
+    Wc, bc, code = fixture.make_color_decoder_weights(color_size=cs)
+
+    def module(W, b, latent, dims, last):
+        d = Decoder(latent, dims, last_dim=last, norm_layers=(), latent_in=[4])
+        d.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (Wl, bl) in enumerate(zip(W, b))
+                           for n, a in (('weight', Wl), ('bias', bl))})
+        return d.cuda()
+    dims_c = [512] * 8
+    dims_c[3] += cs
+    dec, dec_c = module(Ws, bs, 256, [512] * 8, 1), module(Wc, bc, 256 + cs, dims_c, 3)
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer_color(dec, dec_c, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']))
+    c = lambda k: torch.from_numpy(g[k]).cuda()
+    rgb = decode_color(dec_c, c('color_code'), c('latent'), c('points'), no_grad=True)
+    assert np.abs(rgb.cpu().numpy() - g['rgb']).max() <= 2e-6
+    d, n, col, m, q = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True)
+    mm = m.cpu().numpy().astype(bool)
+    both = mm & g['mask'].astype(bool)
+    assert (mm != g['mask'].astype(bool)).sum() <= 1
+    assert np.abs(d.cpu().numpy() - g['depth'])[both].max() <= 1e-4
+    assert np.abs(q.cpu().numpy() - g['min_sdf']).max() <= 1e-4
+    assert np.percentile(np.abs(n.cpu().numpy() - g['normal'])[both], 99) <= 1e-4
+    assert col.shape == (H, W, 3)
+    assert np.percentile(np.abs(col.cpu().numpy() - g['color'])[both], 99) <= 1e-4          # colours at surface points 1e-4 apart
+    d2, n2, col2, m2, q2 = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=c('lights'),
+                                    lighting_energies=c('energies'))
+    assert np.percentile(np.abs(col2.cpu().numpy() - g['color_shaded'])[both], 99) <= 1e-4
+    # several lights (the reference only runs with one): additive in the lights
+    two = torch.cat([c('lights'), c('lights') * torch.tensor([1.0, -1.0, 1.0], device='cuda')])
+    col3 = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=two)[2]
+    a = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=two[:1])[2]
+    b = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=two[1:])[2]
+    assert np.abs((col3 - (a + b)).cpu().numpy()).max() <= 1e-5

@@ -186,3 +186,13 @@ def test_loss_oracle_warp_vs_reference_golden():
     assert np.abs(c2.numpy() - g['color_valid_2']).max() <= 1e-6 and np.abs(c1.numpy() - g['color_valid_1']).max() == 0
     for k, v in (('g_zdepth1', z1), ('g_R1', R1), ('g_T1', T1), ('g_R2', R2), ('g_T2', T2)):
         assert np.abs(v.grad.numpy() - g[k]).max() <= 2e-6 * np.abs(g[k]).max(), k
+
+
+def test_color_oracle_vs_reference_golden():
+    """G10: the oracle's decode_color restatement against the reference's decode_color on the colour-decoder fixture."""
+    g = dict(np.load(os.path.join(GOLDEN, 'g10_color_render.npz')))
+    Wc, bc, code = fixture.make_color_decoder_weights(color_size=int(g['color_size']))
+    assert fixture.weights_sha256(Wc, bc) == str(g['color_weights_sha256']) and np.array_equal(code, g['color_code'])
+    orc.build()
+    rgb = orc.ColorOracle(Wc, bc).decode_color(g['color_code'], g['latent'], g['points'])
+    assert np.abs(rgb - g['rgb']).max() <= 2e-6
