@@ -33,6 +33,14 @@ struct distr_ctx {
   bool save_masks = true;       // save ReLU masks in the forward so that the backward skips the decoder recompute
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  // exchange regions of the cluster tiles (distr_mlp.hpp, "Cluster tile"): uncached device memory, one region per stream
+  // that renders through this context (concurrent renders on different streams must not share barrier words)
+  struct XRegion { float* buf = nullptr; uint32_t* flags = nullptr; uint32_t epoch = 0; hipStream_t stream = nullptr; bool used = false; };
+  bool xchg_ts = false;         // DISTR_XCHG_TS=1: cluster 0 / member 0 writes phase stamps behind the flag words (distr_debug_xchg_ts)
+  static constexpr int NXR = 8;
+  XRegion xr[NXR];
+  bool cluster = true;          // DISTR_CLUSTER=0: single-workgroup 16-ray tiles only
+  int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
 };
 
 namespace {
@@ -119,6 +127,37 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
       return fail(ctx, DISTR_ERR_INVALID_ARG, "row band [%d,+%d) must start on a multiple of 4 and span a multiple of 4 rows (or end at H)", c->row0, c->rows);
   }
   return DISTR_OK;
+}
+
+// Exchange region of `stream` (allocated on the stream's first render: 16 MiB + 128 KiB of uncached device memory; steady
+// state never allocates). Null (-> single-workgroup tiles) when disabled, out of regions, or the allocation fails.
+distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
+  if (!ctx->cluster) return nullptr;
+  distr_ctx::XRegion* free_slot = nullptr;
+  for (auto& r : ctx->xr) {
+    if (r.used && r.stream == stream) return &r;
+    if (!r.used && !free_slot) free_slot = &r;
+  }
+  if (!free_slot) return nullptr;
+  constexpr size_t buf_bytes = (size_t)256 * 2 * 8192 * sizeof(float), flag_bytes = (size_t)256 * 128 * sizeof(uint32_t) + 64 * sizeof(long long);
+  if (hipExtMallocWithFlags((void**)&free_slot->buf, buf_bytes, hipDeviceMallocUncached) != hipSuccess ||
+      hipExtMallocWithFlags((void**)&free_slot->flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess ||
+      hipMemset(free_slot->flags, 0, flag_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    if (free_slot->buf) { (void)hipFree(free_slot->buf); free_slot->buf = nullptr; }
+    if (free_slot->flags) { (void)hipFree(free_slot->flags); free_slot->flags = nullptr; }
+    ctx->cluster = false;
+    return nullptr;
+  }
+  free_slot->used = true; free_slot->stream = stream; free_slot->epoch = 0;
+  return free_slot;
+}
+
+inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8) {
+  Xchg x{nullptr, nullptr, 0, max_cl, nullptr};
+  if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
+  if (r) { if (++r->epoch == 0) ++r->epoch; x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch; }
+  return x;
 }
 
 inline int band_rows(const distr_render_cfg& c) { return c.rows > 0 ? c.rows : c.H; }
@@ -228,6 +267,8 @@ int distr_create(distr_ctx** out, int hip_device) {
   if (const char* e = getenv("DISTR_TILE_RB")) ctx->tile_rb = atoi(e);
   if (ctx->tile_rb < -1 || ctx->tile_rb > 2) ctx->tile_rb = 0;   // -1: force 16-ray tiles wherever they exist (tests)
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
+  if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
+  if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
   int n = 0;
@@ -246,6 +287,7 @@ void distr_destroy(distr_ctx* ctx) {
   if (!ctx) return;
   if (ctx->dec_buf) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf); }
   if (ctx->dec_buf_color) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_color); }
+  for (auto& r : ctx->xr) { if (r.buf) (void)hipFree(r.buf); if (r.flags) (void)hipFree(r.flags); }
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete ctx;
 }
@@ -417,6 +459,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   // the 16-ray launch of the last step (free: a tail step); otherwise on the first march launch of the render
   const bool split_cfg = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0 && ctx->tail16_threshold > 0;
   bool origin_done = split_cfg;
+  distr_ctx::XRegion* xr = (split_cfg || ctx->tile_rb == -1) ? xchg_region(ctx, s) : nullptr;
   for (int l = V.nlev - 1; l >= 1; --l) {
     hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
     LAUNCH_CHECK("k_coarse_init");
@@ -429,7 +472,9 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       const bool c16 = !A.origin_tile && ((split_cfg && ln <= ctx->tail16_threshold) || ctx->tile_rb == -1);
       const int crb = (split_cfg && ln <= ctx->hybrid_threshold) ? 1 : rb_dense;
       const int ctile = c16 ? 16 : 32 * crb;
-      const unsigned tiles = (unsigned)((ln + ctile - 1) / ctile) + (A.origin_tile ? 1u : 0u);
+      unsigned tiles = (unsigned)((ln + ctile - 1) / ctile) + (A.origin_tile ? 1u : 0u);
+      A.xc = next_xchg(c16 ? xr : nullptr, ctx->xchg_ts, ctx->max_cl);
+      if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
       if (c16) {
         if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_COARSE, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
@@ -484,11 +529,12 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       if (A.t16 > 0) {
         A2.which = 16;
         A2.origin_tile = (split_cfg && st == V.fine_steps - 1) ? 1 : 0;
-        const unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
-        // a 16-ray tile keeps its SIMDs' MFMA pipes busy: two of them on one CU take twice as long. The launch that carries the
-        // origin tile asks for 48 KiB of (unused) dynamic LDS so that only one workgroup fits per CU and the extra tile goes
-        // to an idle CU instead of doubling up with a live one.
-        const unsigned pad16 = A2.origin_tile ? 48u * 1024u : 0u;
+        A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl);
+        // grid: one workgroup per 16-ray tile of the largest possible remainder (+1 for f(origin) in the launch that
+        // carries it); cluster tiles (8 / 4 workgroups per tile of at most 31 / 63 tiles + the origin tile) need 256
+        unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
+        if (xr) n16 = std::max(n16, 256u);
+        const unsigned pad16 = 0u;
         if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
         else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
       }
@@ -715,6 +761,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   out->num_march_launches = launches;
   out->num_valid = C->cnt_valid;
   out->num_grad_samples = C->cnt_samples;
+  out->cluster_timeouts = C->xchg_err;
   return DISTR_OK;
 }
 
@@ -738,6 +785,17 @@ int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void
   if (total_ms) *total_ms = tot;
   ctx->ev_used = 0;
   return DISTR_OK;
+}
+
+int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64) {
+  if (!ctx || !out64) return DISTR_ERR_INVALID_ARG;
+  for (auto& r : ctx->xr)
+    if (r.used && r.stream == (hipStream_t)stream) {
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      HIP_TRY(hipMemcpy(out64, r.flags + 256 * 128, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+      return DISTR_OK;
+    }
+  return fail(ctx, DISTR_ERR_INVALID_ARG, "no exchange region for this stream");
 }
 
 // ------------------------------------------------------------------------------------------ f2 / f3: fused losses

@@ -24,7 +24,7 @@ struct Consts {
   float latent[LAT];
   float R[9], T[3], c[3];
   float cdist;
-  int32_t reserved0;
+  int32_t xchg_err;       // a cluster barrier timed out (should never happen; results of that render are invalid)
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
   uint32_t maxinit_bits[3];
   int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const flo
       const float cd = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       C->cdist = cd;
       C->f_origin = 0.f;
+      C->xchg_err = 0;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
     }
   }
@@ -378,6 +379,7 @@ struct MarchArgs {
   // MODE_FINE tile-size split (see fine_range): t16 / t32 = largest remainder handled by 16- / 32-ray tiles; which = tile
   // size of THIS launch (16, 32, 64). t32 == 0: no split, the 64-ray (or forced) kernel takes everything.
   int32_t t16, t32, which;
+  Xchg xc;                   // 16-ray launches: exchange region of the cluster tiles (buf == null: single-workgroup tiles only)
 };
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
@@ -502,10 +504,9 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
 template <int MODE, bool KEEP>
 __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
   constexpr int TILE = 16;
-  __shared__ Smem16 S;
+  __shared__ Smem16CL S;
   const View& V = A.V;
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
   int64_t count;
   const int32_t* list = nullptr;
   if (MODE == MODE_EVAL) {
@@ -517,11 +518,25 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
     count = V.C->cnt_live[A.step];
     list = V.live[A.step & 1];
   }
-  // the last workgroup of the launch that carries `origin_tile` evaluates f(0,0,0) (sample point of padded rows): on a
-  // 16-ray tile of a tail step it rides along for free instead of adding a 257th tile to a full round elsewhere
-  const bool origin = (MODE == MODE_FINE) && A.origin_tile && tile == (int)gridDim.x - 1;
   int64_t lo = 0, hi = count;
   if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
+  const int64_t n = hi - lo;
+  // Cluster size from the (device-side) number of rays of this launch: with at most 31 / 63 tiles, 8 / 4 compute units share
+  // each tile (+1 tile for f(origin) on the launch that carries it keeps the grid within 256 workgroups). Measured step
+  // time: 68 us (8), 80 us (4), 111 us (single workgroup); 2 per tile gains nothing (the two halves of a layer plus the
+  // exchange cost what the whole layer costs on one CU), so larger remainders stay on single-workgroup tiles.
+  int cl = 1;
+  if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : 1;
+  int tile = blockIdx.x, member = 0;
+  if (cl > 1) {   // members of a cluster = workgroups with equal blockIdx mod 8 (same XCD)
+    const int g = blockIdx.x / (8 * cl), r = blockIdx.x % (8 * cl);
+    tile = g * 8 + (r & 7);
+    member = r >> 3;
+  }
+  // the tile after the last real one evaluates f(0,0,0) (sample point of padded rows) in the launch that carries
+  // `origin_tile`: on a tail step it rides along for free instead of adding a 257th tile to a full round elsewhere
+  const int64_t ntiles = (n + TILE - 1) / TILE;
+  const bool origin = (MODE == MODE_FINE) && A.origin_tile && tile == ntiles;
   const int64_t base = lo + (int64_t)tile * TILE;
   if (!origin && base >= hi) return;
   count = hi;
@@ -555,7 +570,15 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   uint32_t nib[8];
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+  float pre;
+  if (MODE != MODE_EVAL && cl > 1) {
+    int* err = &V.C->xchg_err;
+    if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member, err);
+    else pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member, err);
+    if (member != 0) return;            // only the lead member runs the epilogue
+  } else {
+    pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+  }
 
   long long mblock = -1;
   if (tid < 64) {
@@ -596,7 +619,18 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
-    store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    if (cl > 1) {   // the lead member assembled the rays' mask blocks in LDS (masks_from_lds)
+      const int j = tid >> 4, q = tid & 15;
+      const long long b = S.mb[j];
+      if (b >= 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(&S.mk[j][0]);
+        uint4* dst = V.mstore + (size_t)b * 32;
+        dst[q] = src[q];
+        dst[q + 16] = src[q + 16];
+      }
+    } else {
+      store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    }
   }
 }
 

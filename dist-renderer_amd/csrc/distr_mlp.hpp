@@ -665,4 +665,240 @@ __device__ __forceinline__ void store_masks16(uint4* mstore, const long long* mb
   for (int v = 0; v < 4; ++v) dst[v] = make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]);
 }
 
+// =====================================================================================================================
+// Cluster tile: ONE 16-ray tile split over CL workgroups on CL compute units (the deep tail of the march, where a step
+// has at most a few hundred live rays: most of the chip idles and a step costs exactly one tile latency, which on one CU
+// cannot drop below ~100 us of MFMA issue). Member m computes rows [m*O/CL, (m+1)*O/CL) of every layer for all 16 rays
+// and the members exchange their slices after each layer through an UNCACHED device buffer owned by the context
+// (MTYPE UC: stores go to memory, loads bypass L1/L2, so no cache maintenance; measured 2.0 us per exchange for up to 64
+// clusters, profiles/ubench/cluster_exchange.hip; the same exchange through cached memory with agent-scope
+// release/acquire costs 3 us for 8 clusters and 16 us for 64). The members of a cluster are workgroups with equal
+// blockIdx mod 8, i.e. on the same XCD. Every output row is still one k-ordered fmaf chain computed by one wave, so the
+// values are bit-identical to every other tile size. Barrier = per-member epoch words (no atomics, no reset): a member
+// stores the launch's epoch into its word of barrier j and polls the CL words until all carry the epoch; polling is
+// bounded (a timeout sets *err and the launch finishes with garbage rather than hanging).
+struct Xchg {
+  float* buf;          // [256 clusters][2][8192]  activation slices, fragment layout (float4 index rb*64 + lane)
+  uint32_t* flags;     // [256 clusters][16 barriers][8 members]
+  uint32_t epoch;      // unique per launch (per region)
+  int32_t max_cl;      // largest cluster size to use (8 or 4)
+  long long* ts;       // debug (DISTR_XCHG_TS=1): wall-clock stamps of cluster 0 / member 0 at phase boundaries, else null
+};
+#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) xc.ts[(i)] = (long long)wall_clock64(); } while (0)
+
+struct Smem16CL : Smem16 {
+  uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
+};
+
+// Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
+// The A-fragments a wave needs for a layer are streamed in chunks of 16 float4 (G = 16/NBL feature groups of 16) through
+// two register buffers; chunk 0 of a layer is requested BEFORE the exchange barrier of the previous layer (weights do not
+// depend on activations), so its latency hides behind the exchange, and chunk c+1 is requested before chunk c is used.
+template <int K, int O, int CL>
+struct ClGeom {
+  static constexpr int RBT = O / 16, PER = RBT / CL, NBL = (PER >= 4) ? PER / 4 : 1, ACT = (PER >= 4) ? 4 : PER;
+  static constexpr int NG = K / 16, G = 16 / NBL, NCH = (NG + G - 1) / G;
+};
+
+template <int K, int O, int CL>
+__device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, f32x4 (&w)[16], int c, int member, int wave, int lane) {
+  using Ge = ClGeom<K, O, CL>;
+  if (wave >= Ge::ACT) return;
+  const int rb0 = member * Ge::PER + wave * Ge::NBL;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wf) + (size_t)rb0 * 64 + lane;   // float4 index (g*RBT + rb)*64 + lane
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int g = c * Ge::G + i / Ge::NBL, ob = i % Ge::NBL;
+    if (g < Ge::NG) w[i] = wp[((size_t)g * Ge::RBT + ob) * 64];
+  }
+}
+
+template <int CL>
+__device__ __forceinline__ void cl_barrier(uint32_t* flags /*this cluster: [16][8]*/, int j, int member, uint32_t epoch, int tid, int* err) {
+  // precondition: every wave has drained its global stores (s_waitcnt 0) and passed a __syncthreads()
+  if (tid == 0) __hip_atomic_store(flags + j * 8 + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 64) {
+    int spins = 0;
+    for (;;) {
+      const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + j * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      if (__ballot(v != epoch) == 0ull) break;
+      if (++spins > (1 << 21)) { if (tid == 0) *err = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+// One dense layer of the cluster tile: this member's row slice, ReLU, slice -> own LDS + exchange buffer, barrier, the
+// other members' slices -> LDS. On return X holds the full post-ReLU output of the layer (O rows) in every member.
+// w[START] holds chunk 0 of this layer on entry; on return w[(START + NCH) & 1] holds chunk 0 of the next layer (KN > 0).
+template <int K, int O, int CL, int START, int KN, int ON>
+__device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const float* __restrict__ init, const float* __restrict__ WfNext,
+                                         f32x4 (&w)[2][16], Smem16CL& S, const Xchg& xc, float* xbase, uint32_t* flags, int layer,
+                                         int member, int* err) {
+  using Ge = ClGeom<K, O, CL>;
+  constexpr int RBT = Ge::RBT, PER = Ge::PER, NBL = Ge::NBL, ACT = Ge::ACT, G = Ge::G, NCH = Ge::NCH, NG = Ge::NG;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  float* X = S.X;
+  float* slot = xbase + (layer & 1) * 8192;
+  f32x4 acc[NBL];
+  const int rb0 = member * PER + wave * NBL;
+  if (wave < ACT) {
+#pragma unroll
+    for (int ob = 0; ob < NBL; ++ob) acc[ob] = *reinterpret_cast<const f32x4*>(init + 16 * (rb0 + ob) + 4 * kq);
+  }
+  const float* xb = X + lane;
+  float b[4], bn[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) b[s4] = xb[(4 * s4) * 16];            // B fragments (LDS) run one feature group ahead
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) cl_load_chunk<K, O, CL>(Wf, w[(START + c + 1) & 1], c + 1, member, wave, lane);
+    else if (KN > 0) cl_load_chunk<(KN > 0 ? KN : 16), (KN > 0 ? ON : 16 * CL), CL>(WfNext, w[(START + c + 1) & 1], 0, member, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < ACT) {
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const int g = c * G + gi;
+        if (g < NG) {
+          const int gn = (g + 1 < NG) ? g + 1 : g;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bn[s4] = xb[(16 * gn + 4 * s4) * 16];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int ob = 0; ob < NBL; ++ob)
+              acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(START + c) & 1][gi * NBL + ob][s4], b[s4], acc[ob], 0, 0, 0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) b[s4] = bn[s4];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  DISTR_XTS(4 * layer);
+  __syncthreads();                         // everybody is done reading the layer input
+  if (wave < ACT) {
+#pragma unroll
+    for (int ob = 0; ob < NBL; ++ob) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = __int_as_float(max(__float_as_int(acc[ob][r]), 0));
+        X[(16 * (rb0 + ob) + 4 * kq + r) * 16 + j] = v[r];
+      }
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(slot) + (rb0 + ob) * 64 + lane);
+    }
+  }
+  // Wait for this wave's slice stores only (they were issued after the weight prefetch of the next layer, and memory
+  // operations of one wave complete in order, so waiting for ALL of them would also wait for the prefetch -- which is
+  // what we want to overlap with the exchange). vmcnt counts outstanding operations: the stores are the youngest, so a
+  // full wait is needed for them; the prefetch was issued earlier and has normally landed by now.
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  DISTR_XTS(4 * layer + 1);
+  cl_barrier<CL>(flags, layer, member, xc.epoch, tid, err);
+  DISTR_XTS(4 * layer + 2);
+  // other members' slices: float4 index i over the row blocks not owned by this member
+  constexpr int OTHER = (RBT - PER) * 64;
+  for (int i = tid; i < OTHER; i += NTHREADS) {
+    int rb = i >> 6;
+    const int l = i & 63;
+    rb += (rb >= member * PER) ? PER : 0;
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slot) + rb * 64 + l);
+    const int row = 16 * rb + 4 * (l >> 4), jj = l & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[(row + r) * 16 + jj] = v[r];
+  }
+  __syncthreads();
+  DISTR_XTS(4 * layer + 3);
+}
+
+// mask words of `layer` for the 16 rays from the post-ReLU activations in X (bit = activation > 0), into S.mk in the
+// per-ray block format of store_mask_chunk: chunk (w, h), word layer*4 + ob, bit r <-> row w*WR + 32*ob + (r&3) + 8*(r>>2) + 4*h,
+// WR = rows per wave of the 32x32 tiles (128; 64 for lin3, whose words ob = 2, 3 are zero)
+__device__ __forceinline__ void masks_from_lds(Smem16CL& S, int layer, int rows, int tid, int WR = 128) {
+  const int j = tid & 15, c = tid >> 4;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int om = c + 16 * e, w = om >> 3, h = (om >> 2) & 1, ob = om & 3;
+    const int base = w * WR + 32 * ob + 4 * h;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = base + (r & 3) + 8 * (r >> 2);
+      const float v = (row < rows && 32 * ob < WR) ? S.X[row * 16 + j] : 0.f;
+      m |= (v > 0.f ? 1u : 0u) << r;
+    }
+    S.mk[j][(w * 2 + h) * 32 + layer * 4 + ob] = (uint16_t)m;
+  }
+}
+
+// Cluster forward. Every member returns after its last contribution; member 0 returns the pre-tanh value (ray = tid & 15)
+// and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0.
+template <int CL, bool KEEP>
+__device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
+                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member,
+                                                  int* err) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int kq = lane >> 4;
+  const int ray = tid & 15;
+  float* X = S.X;
+  float* xbase = xc.buf + (size_t)cluster * 2 * 8192;
+  uint32_t* flags = xc.flags + (size_t)cluster * 128;
+  const bool lead = (member == 0);
+  f32x4 w[2][16];
+  DISTR_XTS(0);
+  cl_load_chunk<512, 512, CL>(D16.Wf[1], w[0], 0, member, wave, lane);      // lin1's first weights travel while lin0 runs
+  X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;
+  __syncthreads();
+  {  // lin0 (K = 16 padded): cheaper to compute whole in every member than to exchange
+    f32x4 acc[8];
+    acc_init16<8>(acc, c0, wave * 128, kq);
+    dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
+    __syncthreads();
+    (void)writeback16<8, false>(X, acc, wave * 128, lane);
+    __syncthreads();
+    if (KEEP && lead) masks_from_lds(S, 0, 512, tid);
+  }
+  DISTR_XTS(1);
+  // buffer parity of every layer's chunk 0 (see layer_cl)
+  constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
+  constexpr int S1 = 0, S2 = (S1 + N1) & 1, S3 = (S2 + N1) & 1, S4 = (S3 + N3) & 1, S5 = (S4 + N4) & 1, S6 = (S5 + N1) & 1, S7 = (S6 + N1) & 1;
+  layer_cl<512, 512, CL, S1, 512, 512>(D16.Wf[1], D.bias[1], D16.Wf[2], w, S, xc, xbase, flags, 1, member, err);
+  if (KEEP && lead) masks_from_lds(S, 1, 512, tid);
+  layer_cl<512, 512, CL, S2, 512, 256>(D16.Wf[2], D.bias[2], D16.Wf[3], w, S, xc, xbase, flags, 2, member, err);
+  if (KEEP && lead) masks_from_lds(S, 2, 512, tid);
+  layer_cl<512, 256, CL, S3, 256, 512>(D16.Wf[3], D.bias[3], D16.Wf[4], w, S, xc, xbase, flags, 3, member, err);
+  if (KEEP && lead) masks_from_lds(S, 3, 253, tid, 64);     // rows 253..255 are padding (bias 0 -> relu 0 -> bit 0), as in the other tiles
+  __syncthreads();
+  if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
+  __syncthreads();
+  layer_cl<256, 512, CL, S4, 512, 512>(D16.Wf[4], c4, D16.Wf[5], w, S, xc, xbase, flags, 4, member, err);
+  if (KEEP && lead) masks_from_lds(S, 4, 512, tid);
+  layer_cl<512, 512, CL, S5, 512, 512>(D16.Wf[5], D.bias[5], D16.Wf[6], w, S, xc, xbase, flags, 5, member, err);
+  if (KEEP && lead) masks_from_lds(S, 5, 512, tid);
+  layer_cl<512, 512, CL, S6, 512, 512>(D16.Wf[6], D.bias[6], D16.Wf[7], w, S, xc, xbase, flags, 6, member, err);
+  if (KEEP && lead) masks_from_lds(S, 6, 512, tid);
+  layer_cl<512, 512, CL, S7, 0, 0>(D16.Wf[7], D.bias[7], nullptr, w, S, xc, xbase, flags, 7, member, err);
+  if (!lead) return 0.f;
+  if (KEEP) masks_from_lds(S, 7, 512, tid);
+  DISTR_XTS(32);
+  {
+    float p = 0.f;
+    const float* w8 = D.w8 + wave * 128;
+    const float* xr = X + (size_t)wave * 128 * 16 + ray;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], xr[k * 16], p);
+    S.part[wave * 16 + ray] = p;
+  }
+  __syncthreads();
+  return ((S.part[ray] + S.part[16 + ray]) + (S.part[32 + ray] + S.part[48 + ray])) + D.b8;
+}
+
 }  // namespace distr

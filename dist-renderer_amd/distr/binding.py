@@ -21,7 +21,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
-           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval']
+           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts']
 
 
 class DistrError(RuntimeError):
@@ -75,7 +75,7 @@ def make_warp_cfg(img_hw, intrinsic, thres_depth):
 
 class RenderStats(C.Structure):
     _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
-                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64)]
+                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_timeouts', C.c_int64)]
 
 
 def build_library(force=False, verbose=False):
@@ -135,6 +135,7 @@ def lib():
             L.distr_warp_loss_backward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
             L.distr_set_color_decoder.argtypes = [vp, C.POINTER(DecoderDesc), C.POINTER(C.c_float), C.c_size_t]
             L.distr_color_eval.argtypes = [vp, fp, fp, C.c_int64, fp, vp, C.c_size_t, vp]
+            L.distr_debug_xchg_ts.argtypes = [vp, vp, C.POINTER(C.c_int64)]
             _lib = L
     return _lib
 

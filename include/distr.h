@@ -91,6 +91,8 @@ typedef struct distr_render_stats {
   int64_t num_point_evals;    /* decoder evaluations executed by the march kernel      */
   int64_t num_valid;          /* final valid pixels                                    */
   int64_t num_grad_samples;   /* (backward) gradient-carrying samples of the last backward on this workspace */
+  int64_t cluster_timeouts;   /* != 0: a cross-workgroup barrier of the cluster tiles timed out -> this render is invalid
+                                 (never observed; the bounded wait exists so that a scheduling surprise cannot hang the GPU) */
 } distr_render_stats;
 
 int distr_create(distr_ctx** out, int hip_device);
@@ -162,6 +164,9 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
                        void* stream);
 int distr_profile_enable(distr_ctx* ctx, int enable);
 int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
+/* Test aid (DISTR_XCHG_TS=1): 64 wall-clock stamps (100 MHz) of the last cluster-tile launch on `stream`: phase boundaries of
+ * cluster 0 / member 0 (csrc/distr_mlp.hpp, DISTR_XTS). */
+int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64);
 
 /* ---- Colour decoder: SDFRenderer_color.render_color (core/sdfrenderer/renderer_rgb.py:20-38) evaluates
  * a second DeepSDF-8x512-shaped decoder with latent = [shape code | colour code] (256 + color_size) and last_dim = 3

@@ -1,0 +1,31 @@
+"""Diagnostic (not a test): phase timing inside the cluster tile (DISTR_XCHG_TS=1) for a 64x64 render's last march step."""
+import ctypes as C
+import os
+import sys
+os.environ['DISTR_XCHG_TS'] = '1'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'dist-renderer_amd'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from distr import binding, fixture, functions  # noqa: E402
+
+Ws, bs, latent = fixture.make_decoder_weights()
+eng = functions.engine_from_weights(Ws, bs, 0)
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+K = fixture.make_intrinsic(size, size)
+R, T = fixture.make_camera(30.0, 20.0, 1.6, 0.0)
+cfg = binding.make_cfg((size, size), K, march_step=int(sys.argv[2]) if len(sys.argv) > 2 else 99, buffer_size=3, use_depth2normal=True)
+lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+Rt, Tt = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda()
+for _ in range(3):
+    functions.render_call(eng, cfg, lat, Rt, Tt)
+out = (C.c_int64 * 64)()
+eng.ctx.check(eng.ctx.L.distr_debug_xchg_ts(eng.ctx.h, eng.ctx.stream(), out))
+ts = np.array(list(out), np.int64)
+t0 = ts[0]
+print('lin0 done: %.2f us' % ((ts[1] - t0) / 100.0))
+for l in range(1, 8):
+    a, b, c, d = ts[4 * l: 4 * l + 4]
+    prev = ts[4 * (l - 1) + 3] if l > 1 else ts[1]
+    print('layer %d: compute %.2f | relu+store+drain %.2f | barrier %.2f | read others %.2f   (us)' % (l, (a - prev) / 100.0, (b - a) / 100.0, (c - b) / 100.0, (d - c) / 100.0))
+print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))

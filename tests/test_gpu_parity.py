@@ -775,3 +775,41 @@ def test_color_render_matches_reference_golden(fixture_decoder):
     a = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=two[:1])[2]
     b = r.render(c('color_code'), c('latent'), c('R'), c('T'), no_grad=True, lighting_locations=two[1:])[2]
     assert np.abs((col3 - (a + b)).cpu().numpy()).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_cluster_tiles_bit_identical_to_single_workgroup_tiles(fixture_decoder):
+    """The deep tail of the march runs on cluster tiles (one 16-ray tile split over 8 / 4 workgroups on as many CUs,
+    slices exchanged through uncached memory, csrc/distr_mlp.hpp). Every output row is still one k-ordered chain, so a
+    render must be bit-identical with the cluster tiles switched off, forward and backward; no barrier may time out."""
+    import torch
+    from distr import binding, fixture, functions
+    Ws, bs, latent = fixture_decoder
+    outs = []
+    for env in ('8', '4', '0'):
+        os.environ['DISTR_CLUSTER'] = env
+        try:
+            eng = functions.engine_from_weights(Ws, bs, 0)       # the knob is read at distr_create
+        finally:
+            del os.environ['DISTR_CLUSTER']
+        H = W = 96
+        K = fixture.make_intrinsic(H, W)
+        R, T = fixture.make_camera(35.0, 25.0, 1.6, 10.0)
+        res = helpers.hip_render(eng, H, W, K, R, T, latent, march_step=60, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+        cfg = res['cfg']
+        fwd_bytes, _ = eng.ctx.workspace_bytes(cfg)
+        ws = torch.empty(fwd_bytes, dtype=torch.uint8, device='cuda')
+        o = [torch.empty(H * W, device='cuda'), torch.empty(H * W, dtype=torch.uint8, device='cuda'), torch.empty(H * W, device='cuda'),
+             torch.empty(H, W, device='cuda'), torch.empty(H, W, 3, device='cuda')]
+        import ctypes as C
+        p = binding.ptr
+        lat = torch.from_numpy(latent).cuda().reshape(-1)
+        eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(torch.from_numpy(R).cuda().reshape(-1)),
+                                                   p(torch.from_numpy(T).cuda()), p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(ws), ws.numel(),
+                                                   eng.ctx.stream()))
+        st = eng.ctx.render_stats(cfg, ws)
+        assert st['cluster_timeouts'] == 0 and st['num_valid'] > 300
+        outs.append(res)
+    for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
+        assert outs[0][k].tobytes() == outs[2][k].tobytes(), k
+        assert outs[1][k].tobytes() == outs[2][k].tobytes(), k
