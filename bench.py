@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
     ap.add_argument('--march-step', type=int, default=50)
+    ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU (c5 at N <= 4)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
@@ -131,20 +132,30 @@ def main():
         return torch.where(mb, depth * wd[r0:r1], torch.zeros_like(depth)).sum() + (q.reshape(r1 - r0, W) * wq[r0:r1]).sum() + \
             (normal * wn[r0:r1]).sum()
 
+    # several independent work items on one GPU (c5 at N <= 4): issue them on a small pool of HIP streams so that one item's
+    # latency-bound tail overlaps another item's dense steps (same mechanism as core.inv_optimizer.optimize_multi)
+    from core.inv_optimizer.optimize_multi import _StreamPool
+    pool = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev)
+
+    def render_item(shape, v, r0, r1):
+        Rt, Tt = cams[v]
+        if (r0, r1) == (0, H):
+            outs = functions.render_call(eng, cfg, lats[shape], Rt, Tt)
+        else:
+            outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
+        return image_loss(outs, r0, r1)
+
     def step():
         for l in lats:
             l.grad = None
-        total = None
-        for (shape, v, r0, r1) in items:
-            Rt, Tt = cams[v]
+        for (Rt, Tt) in cams.values():
             Rt.grad = None
             Tt.grad = None
-            if (r0, r1) == (0, H):
-                outs = functions.render_call(eng, cfg, lats[shape], Rt, Tt)
-            else:
-                outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
-            L = image_loss(outs, r0, r1)
-            total = L if total is None else total + L
+        losses = [pool.run(i, lambda it=it: render_item(*it)) for i, it in enumerate(items)]
+        pool.join(losses)
+        total = losses[0]
+        for L in losses[1:]:
+            total = total + L
         total.backward()
         loss_buf.copy_(total.detach().reshape(1))
         for l in lats:
