@@ -48,13 +48,14 @@ def load_decoder(experiment_directory, checkpoint_num=None, color_size=None, exp
 
 
 def decode_sdf(decoder, latent_vector, points, clamp_dist=0.1, MAX_POINTS=100000, no_grad=False):
-    """(n,3) points -> (n,1) SDF, optionally clamped. Forward-only: use SDFRenderer.render* for gradients."""
+    """(n,3) points -> (n,1) SDF, optionally clamped (decoder_utils.py:53-74). Differentiable w.r.t. the latent code and
+    the points unless `no_grad` (fused backward: distr_mlp_backward); the decoder weights are frozen."""
     if latent_vector is None:
         raise NotImplementedError('latent_vector=None (decoder_utils.py:58-59) is not supported')
+    eng = _engine(decoder, points)
     if (not no_grad) and torch.is_grad_enabled() and (latent_vector.requires_grad or points.requires_grad):
-        raise NotImplementedError('decode_sdf is forward-only here; gradients are produced by SDFRenderer.render / '
-                                  'render_depth (fused backward kernel). Pass no_grad=True or wrap in torch.no_grad().')
-    return functions.mlp_eval(_engine(decoder, points), latent_vector, points, clamp_dist)
+        return functions.mlp_eval_autograd(eng, latent_vector, points, clamp_dist)
+    return functions.mlp_eval(eng, latent_vector, points, clamp_dist)
 
 
 def decode_sdf_gradient(decoder, latent_vector, points, clamp_dist=0.1, MAX_POINTS=100000, no_grad=False):

@@ -702,6 +702,42 @@ int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   return DISTR_OK;
 }
 
+size_t distr_mlp_backward_workspace_bytes(int64_t n) {
+  const size_t tiles = (size_t)((n + 31) / 32);
+  return distr_mlp_workspace_bytes(n) + tiles * PSTRIDE * sizeof(float) + 256;
+}
+
+int distr_mlp_backward(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, const float* g_sdf, float clamp,
+                       float* g_xyz, float* g_latent, void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n < 0 || (n > 0 && (!xyz || !g_sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_backward_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (g_latent) HIP_TRY(hipMemsetAsync(g_latent, 0, LAT * sizeof(float), s));
+    return DISTR_OK;
+  }
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* partial = (float*)(((uintptr_t)(c0c4 + 2 * HID) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
+  LAUNCH_CHECK("k_latent_consts");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.n = n; B.xyz = xyz; B.c0c4 = c0c4; B.coef = g_sdf; B.clamp = clamp; B.partial = partial; B.out_g = g_xyz;
+  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
+  const int TILE = 32 * rb_dense;
+  const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
+  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, ctx->D);
+  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, ctx->D);
+  LAUNCH_CHECK("k_bwd<pointgrad+latent>");
+  if (g_latent) {
+    hipLaunchKernelGGL(k_points_latent_grad, dim3(1), dim3(256), 0, s, (const float*)partial, (int)tiles, ctx->D, g_latent);
+    LAUNCH_CHECK("k_points_latent_grad");
+  }
+  return DISTR_OK;
+}
+
 int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, int layer, float* out, void* ws,
                           size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;

@@ -798,7 +798,9 @@ struct BwdArgs {
   const float* zdepth;       // POINTGRAD from pixel list: depth along the level-0 ray
   const int32_t* pix_list;
   const float* c0c4;         // POINTGRAD explicit: latent constants; null -> V.C
-  float* partial;            // FULL: [tiles][PSTRIDE]
+  const float* coef;         // POINTGRAD explicit: upstream gradient per point (decode_sdf backward); null -> 1
+  float clamp;               // POINTGRAD explicit with coef: >= 0 -> zero the gradient where |f| > clamp (decode_sdf's clamp)
+  float* partial;            // FULL: [tiles][PSTRIDE]; POINTGRAD with coef: same (delta sums for the latent gradient)
   float* out_sdf;            // POINTGRAD: [n]
   float* out_g;              // POINTGRAD: [n][3]
 };
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
       if (valid) {
         if (MODE == BWD_POINTGRAD && A.xyz) {
           p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
-          sm.coef = 1.0f;
+          sm.coef = A.coef ? A.coef[r] : 1.0f;
         } else {
           if (MODE == BWD_POINTGRAD) { sm.src = A.pix_list[r]; sm.zb = A.zdepth[sm.src]; sm.coef = 1.0f; }
           else sm = A.samples[r];
@@ -879,11 +881,12 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     const float pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
     if (tid < TILE) {
       y = tanh_spec(pre);
+      if (MODE == BWD_POINTGRAD && A.coef && A.clamp >= 0.f && !(fabsf(y) <= A.clamp)) sm.coef = 0.f;
       S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
     }
     __syncthreads();
   }
-  float* part = (MODE != BWD_POINTGRAD) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
+  float* part = (MODE != BWD_POINTGRAD || A.partial) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
   mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
 
   if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
@@ -891,8 +894,8 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
   const float gp0 = S.aux[TILE + rl], gp1 = S.aux[2 * TILE + rl], gp2 = S.aux[3 * TILE + rl];
   if (MODE == BWD_POINTGRAD) {
     if (valid) {
-      A.out_sdf[r] = y;
-      A.out_g[r * 3] = gp0; A.out_g[r * 3 + 1] = gp1; A.out_g[r * 3 + 2] = gp2;
+      if (A.out_sdf) A.out_sdf[r] = y;
+      if (A.out_g) { A.out_g[r * 3] = gp0; A.out_g[r * 3 + 1] = gp1; A.out_g[r * 3 + 2] = gp2; }
     }
     return;
   }
@@ -1186,6 +1189,21 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial
   float s = 0.f;
   for (int t = t0; t < t1; ++t) s += partial[(size_t)t * PSTRIDE + col];
   chunk_part[(size_t)blockIdx.y * PSTRIDE + col] = s;
+}
+
+// decode_sdf backward (explicit points): ordered column sums of the tile partials, then g_latent as in k_bwd_final
+__global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial, int ntiles, DecoderDev D, float* g_latent) {
+  __shared__ float red[2 * HID];
+  const int k = threadIdx.x;
+  for (int col = k; col < 2 * HID; col += 256) {
+    float s = 0.f;
+    for (int t = 0; t < ntiles; ++t) s += partial[(size_t)t * PSTRIDE + col];
+    red[col] = s;
+  }
+  __syncthreads();
+  float a = 0.f;
+  for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * red[o] + D.W4lat[o * LAT + k] * red[HID + o];
+  g_latent[k] = a;
 }
 
 // g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)

@@ -21,7 +21,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
-           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts']
+           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward']
 
 
 class DistrError(RuntimeError):
@@ -136,6 +136,9 @@ def lib():
             L.distr_set_color_decoder.argtypes = [vp, C.POINTER(DecoderDesc), C.POINTER(C.c_float), C.c_size_t]
             L.distr_color_eval.argtypes = [vp, fp, fp, C.c_int64, fp, vp, C.c_size_t, vp]
             L.distr_debug_xchg_ts.argtypes = [vp, vp, C.POINTER(C.c_int64)]
+            L.distr_mlp_backward_workspace_bytes.argtypes = [C.c_int64]
+            L.distr_mlp_backward_workspace_bytes.restype = C.c_size_t
+            L.distr_mlp_backward.argtypes = [vp, fp, fp, C.c_int64, fp, C.c_float, fp, fp, vp, C.c_size_t, vp]
             _lib = L
     return _lib
 

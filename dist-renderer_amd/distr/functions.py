@@ -215,6 +215,40 @@ def mlp_eval(engine, latent, points, clamp_dist=None):
     return out
 
 
+class DecodeSdfFunction(torch.autograd.Function):
+    """decode_sdf with autograd (decoder_utils.py:53-74 called without no_grad): (latent (1,256), points (n,3)) -> (n,1);
+    backward = distr_mlp_backward (one fused forward-recompute + dX chain per point, latent gradient from the delta sums)."""
+
+    @staticmethod
+    def forward(ctx, latent, points, engine, clamp_dist):
+        out = mlp_eval(engine, latent, points, clamp_dist)
+        ctx.engine, ctx.clamp = engine, clamp_dist
+        ctx.save_for_backward(latent.detach(), points.detach())
+        ctx.need = (latent.requires_grad, points.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        engine = ctx.engine
+        dev = engine.device
+        latent, points = ctx.saved_tensors
+        lat = _f32c(latent, dev).reshape(-1)
+        x = _f32c(points, dev).reshape(-1, 3)
+        n = x.shape[0]
+        gs = _f32c(g, dev).reshape(-1)
+        g_x = torch.empty(n, 3, dtype=torch.float32, device=dev) if ctx.need[1] else None
+        g_l = torch.empty(256, dtype=torch.float32, device=dev) if ctx.need[0] else None
+        ws = torch.empty(engine.ctx.L.distr_mlp_backward_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_mlp_backward(engine.ctx.h, p(lat), p(x), n, p(gs), -1.0 if ctx.clamp is None else float(ctx.clamp),
+                                                        p(g_x), p(g_l), p(ws), ws.numel(), engine.ctx.stream()))
+        return (None if g_l is None else g_l.reshape(latent.shape)), (None if g_x is None else g_x.reshape(points.shape)), None, None
+
+
+def mlp_eval_autograd(engine, latent, points, clamp_dist=None):
+    return DecodeSdfFunction.apply(latent, points, engine, clamp_dist)
+
+
 def mlp_grad(engine, latent, points):
     """(sdf (n,), d sdf/d xyz (n,3)) of the unclamped decoder."""
     dev = engine.device

@@ -144,6 +144,12 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev
                    float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int distr_mlp_grad(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float* sdf_dev,
                    float* grad_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* Backward of decode_sdf for callers that differentiate through it (decoder_utils.py:53-74 without no_grad): g_sdf[n] is
+ * the upstream gradient of the (clamped) outputs; writes g_xyz[n][3] = g * df/dxyz (may be null) and
+ * g_latent[256] = sum_n g * df/dlatent (may be null). clamp >= 0: the gradient is zero where |f| > clamp (torch.clamp). */
+size_t distr_mlp_backward_workspace_bytes(int64_t n);
+int distr_mlp_backward(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, const float* g_sdf, float clamp,
+                       float* g_xyz, float* g_latent, void* ws, size_t ws_bytes, void* stream);
 
 /* Test aid: post-activation of hidden layer `layer` (0..7) for n points -> out_dev[n][512]. */
 int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, int layer,

@@ -11,6 +11,7 @@ G8: SDFRenderer_warp.get_valid_points + compute_loss_color (core/sdfrenderer/ren
 G9: two view pairs of the multi-view round (loss_multi.py:6-49 via optimize_multi.py:50-79) with a sim(3): summed loss
     and gradients w.r.t. the shape code and the sim(3) parameters.
 G10 (--g10): decode_color + SDFRenderer_color.render with a seed-defined colour decoder (row f4).
+G11 (--g11): decode_sdf differentiated by autograd w.r.t. latent and points.
 The goldens are data (inputs + reference outputs); no reference source is copied.
 """
 import os
@@ -193,7 +194,32 @@ def golden_g10():
           'shaded mean', float(c2.detach().abs().mean()))
 
 
+def golden_g11():
+    """G11: the reference's decode_sdf (decoder_utils.py:53-74) differentiated by autograd w.r.t. the latent code and
+    the points (clamped and unclamped), with seeded per-point upstream gradients."""
+    rh.install_shims()
+    decoder_utils = rh.reference_modules()[3]
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    rs = np.random.RandomState(31)
+    pts = (rs.rand(777, 3) * 1.4 - 0.7).astype(np.float32)
+    wts = rs.standard_normal((777, 1)).astype(np.float32)
+    out = {}
+    for name, clamp in (('clamped', 0.1), ('raw', None)):
+        lat = torch.from_numpy(latent).clone().requires_grad_(True)
+        x = torch.from_numpy(pts).clone().requires_grad_(True)
+        y = decoder_utils.decode_sdf(dec, lat, x, clamp_dist=clamp)
+        (y * torch.from_numpy(wts)).sum().backward()
+        out['sdf_' + name], out['g_latent_' + name], out['g_points_' + name] = y.detach().numpy(), lat.grad.numpy(), x.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g11_decode_sdf_grad.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent,
+                        points=pts, weights=wts, **out)
+    print('g11', {k: float(np.abs(v).max()) for k, v in out.items()}, 'clamped pts', int((np.abs(out['sdf_raw']) > 0.1).sum()))
+
+
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--g11']:
+        golden_g11()
+        sys.exit(0)
     if sys.argv[1:2] == ['--g10']:
         golden_g10()
         sys.exit(0)
