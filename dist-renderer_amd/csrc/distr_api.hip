@@ -140,6 +140,10 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   }
   if (!free_slot) return nullptr;
   constexpr size_t buf_bytes = (size_t)256 * 2 * 8192 * sizeof(float), flag_bytes = (size_t)256 * 128 * sizeof(uint32_t) + 64 * sizeof(long long);
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (cur != ctx->device) (void)hipSetDevice(ctx->device);       // the region must live on the context's device
+  struct Restore { int cur, dev; ~Restore() { if (cur >= 0 && cur != dev) (void)hipSetDevice(cur); } } restore{cur, ctx->device};
   if (hipExtMallocWithFlags((void**)&free_slot->buf, buf_bytes, hipDeviceMallocUncached) != hipSuccess ||
       hipExtMallocWithFlags((void**)&free_slot->flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess ||
       hipMemset(free_slot->flags, 0, flag_bytes) != hipSuccess) {
