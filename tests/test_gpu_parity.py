@@ -9,6 +9,7 @@ differs, so gradients are compared at 1e-4 relative.
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -857,3 +858,29 @@ def test_decode_sdf_autograd_matches_reference_golden(fixture_decoder):
         assert bad <= max(1, n // 100), bad
     with torch.no_grad():
         assert not decode_sdf(dec, torch.from_numpy(g['latent']).cuda().requires_grad_(True), x.detach()).requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['c3', 'c5'])
+def test_bench_two_ranks_on_one_gpu(workload):
+    """bench.py's multi-rank path end to end: two ranks (time-sharing this one GPU, gloo for the packed all-reduce since two
+    RCCL ranks cannot share a device) through torch.distributed.run; checks the contract fields of the JSON line. c5
+    exercises the shape / row-band partition (each rank renders two of the four shapes)."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    port = 29700 + (os.getpid() % 200) + (1 if workload == 'c5' else 0)
+    size = ['--size', '128', '--march-step', '30'] if workload == 'c5' else ['--size', '160', '--march-step', '30']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--workload', workload] + size
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    assert j['n_gpus'] == 2 and j['steps'] == 2 and j['unit'] == 'rays/s' and j['value'] > 0
+    assert j['scaling'] == ('strong' if workload == 'c5' else 'weak')
+    assert 'cpu_baseline' not in j and j['roofline']['achieved'] > 0
+    rays = (4 if workload == 'c5' else 2) * int(size[1]) ** 2 * 2
+    assert abs(j['value'] * j['ms_per_step'] * 1e-3 * 2 - rays) <= 1e-6 * rays
