@@ -1202,6 +1202,7 @@ __global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial
   }
   __syncthreads();
   float a = 0.f;
+#pragma unroll 16
   for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * red[o] + D.W4lat[o * LAT + k] * red[HID + o];
   g_latent[k] = a;
 }
@@ -1224,7 +1225,8 @@ __global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, const f
   const float* sd0 = C->red;
   const float* sd4 = C->red + HID;
   float a = 0.f;
-  for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * sd0[o] + D.W4lat[o * LAT + k] * sd4[o];
+#pragma unroll 16
+  for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * sd0[o] + D.W4lat[o * LAT + k] * sd4[o];   // loads batch 16 deep
   if (g_latent) g_latent[k] = a;
   if (k < 12) {
     float gc[3];
