@@ -1217,7 +1217,8 @@ __global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, const f
     const int nchunks = min(nchunks_max, (ntiles + chunk - 1) / chunk);
     for (int col = k; col < 2 * HID + 12; col += 256) {
       float s = 0.f;
-      for (int c = 0; c < nchunks; ++c) s += chunk_part[(size_t)c * PSTRIDE + col];
+#pragma unroll 8
+      for (int c = 0; c < nchunks; ++c) s += chunk_part[(size_t)c * PSTRIDE + col];   // ordered; the loads batch 8 deep
       C->red[col] = s;
     }
   }
