@@ -246,7 +246,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_note': 'fabric-side bytes per march step from a separate rocprofv3 PMC pass (profiles/r01_traffic.json)',
-                         'kernel': 'k_march (fused 9-layer decoder + march update), %d launches, %.3f ms total, avg %.1f us'
+                         'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one bracket per march step), %d steps, %.3f ms total, avg %.1f us'
                                    % (launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
         }

@@ -384,15 +384,16 @@ struct MarchArgs {
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
 // that the backward pass does not have to recompute the decoder forward (View::mstore).
+// Body of one 32*RB-ray tile; `tile` / `ntile_grid` = index and count of the tiles this launch (or this role of a merged
+// launch, k_step) provides, `which` = the tile size the split rule (fine_range) knows this role by.
 template <int MODE, int RB, bool KEEP>
-__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
+__device__ __forceinline__ void march_tile(const MarchArgs& A, const DecoderDev& D, Smem<RB>& S, int tile, int ntile_grid, int which,
+                                           int origin_tile) {
   constexpr int TILE = 32 * RB;
-  __shared__ Smem<RB> S;
   const View& V = A.V;
   const int tid = threadIdx.x;
-  int tile = blockIdx.x;
   bool origin = false;
-  if (MODE != MODE_EVAL && A.origin_tile && tile == (int)gridDim.x - 1) origin = true;
+  if (MODE != MODE_EVAL && origin_tile && tile == ntile_grid - 1) origin = true;
 
   int64_t count;
   const int32_t* list = nullptr;
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
     else { count = V.C->cnt_live[A.step]; list = V.live[A.step & 1]; }
   }
   int64_t lo = 0, hi = count;
-  if (MODE == MODE_FINE && V.cfg.marcher != DISTR_MARCH_TRIVIAL) fine_range(count, A.t16, A.t32, A.which, lo, hi);
+  if (MODE == MODE_FINE && V.cfg.marcher != DISTR_MARCH_TRIVIAL) fine_range(count, A.t16, A.t32, which, lo, hi);
   const int64_t base = lo + (int64_t)tile * TILE;
   if (!origin && base >= hi) return;
   count = hi;
@@ -499,12 +500,18 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
   }
 }
 
+template <int MODE, int RB, bool KEEP>
+__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
+  __shared__ Smem<RB> S;
+  march_tile<MODE, RB, KEEP>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
+}
+
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
 // MODE_FINE (recursive marchers), MODE_COARSE (pyramid levels of small images) and MODE_EVAL.
 template <int MODE, bool KEEP>
-__global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
+__device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, int bidx,
+                                             int origin_tile) {
   constexpr int TILE = 16;
-  __shared__ Smem16CL S;
   const View& V = A.V;
   const int tid = threadIdx.x;
   int64_t count;
@@ -527,16 +534,16 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
   // exchange cost what the whole layer costs on one CU), so larger remainders stay on single-workgroup tiles.
   int cl = 1;
   if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : 1;
-  int tile = blockIdx.x, member = 0;
-  if (cl > 1) {   // members of a cluster = workgroups with equal blockIdx mod 8 (same XCD)
-    const int g = blockIdx.x / (8 * cl), r = blockIdx.x % (8 * cl);
+  int tile = bidx, member = 0;
+  if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8)
+    const int g = bidx / (8 * cl), r = bidx % (8 * cl);
     tile = g * 8 + (r & 7);
     member = r >> 3;
   }
   // the tile after the last real one evaluates f(0,0,0) (sample point of padded rows) in the launch that carries
   // `origin_tile`: on a tail step it rides along for free instead of adding a 257th tile to a full round elsewhere
   const int64_t ntiles = (n + TILE - 1) / TILE;
-  const bool origin = (MODE == MODE_FINE) && A.origin_tile && tile == ntiles;
+  const bool origin = (MODE == MODE_FINE) && origin_tile && tile == ntiles;
   const int64_t base = lo + (int64_t)tile * TILE;
   if (!origin && base >= hi) return;
   count = hi;
@@ -631,6 +638,33 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
     } else {
       store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     }
+  }
+}
+
+template <int MODE, bool KEEP>
+__global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
+  __shared__ Smem16CL S;
+  march_tile16<MODE, KEEP>(A, D, D16, S, (int)blockIdx.x, A.origin_tile);
+}
+
+// One full-resolution march step of the recursive marchers in ONE launch: the three tile sizes of the split (fine_range)
+// are roles of the same grid -- workgroups [0, n64) run 64-ray tiles, [n64, n64 + n32) 32-ray tiles, the rest 16-ray /
+// cluster tiles (n64, n32 multiples of 8, so cluster members keep equal index mod 8 = the same XCD). Each role finds its
+// range from the device-side live count and exits if it is empty. Against three launches per step this saves two empty
+// launches (4-5 us each) on almost every step; the long tiles are dispatched first.
+struct StepGrid { int32_t n64, n32, n16; };
+
+template <bool KEEP>
+__global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, DecoderDev16 D16, StepGrid G) {
+  __shared__ __attribute__((aligned(16))) unsigned char raw[sizeof(Smem<2>)];
+  static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CL), "role shared memory");
+  const int b = blockIdx.x;
+  if (b < G.n64) {
+    march_tile<MODE_FINE, 2, KEEP>(A, D, *reinterpret_cast<Smem<2>*>(raw), b, G.n64, 64, 0);
+  } else if (b < G.n64 + G.n32) {
+    march_tile<MODE_FINE, 1, KEEP>(A, D, *reinterpret_cast<Smem<1>*>(raw), b - G.n64, G.n32, 32, 0);
+  } else {
+    march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n64 - G.n32, A.origin_tile);
   }
 }
 
