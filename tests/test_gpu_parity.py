@@ -884,3 +884,27 @@ def test_bench_two_ranks_on_one_gpu(workload):
     assert 'cpu_baseline' not in j and j['roofline']['achieved'] > 0
     rays = (4 if workload == 'c5' else 2) * int(size[1]) ** 2 * 2
     assert abs(j['value'] * j['ms_per_step'] * 1e-3 * 2 - rays) <= 1e-6 * rays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_random_configs_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
+    """Seeded random draws over image size (ragged), steps, buffer_size, ratio, marcher, normal mode and camera: HIP vs
+    oracle with zero mask flips. Long marches at small sizes spend most steps on cluster tiles / merged launches."""
+    from distr import fixture
+    rs = np.random.RandomState(1000 + seed)
+    H, W = int(rs.randint(17, 97)), int(rs.randint(17, 97))
+    marcher = ['recursive', 'pyramid_recursive', 'pyramid_recursive', 'trivial'][rs.randint(4)]
+    S = int(rs.randint(12, 70)) if marcher != 'trivial' else int(rs.randint(8, 20))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 6)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher,
+              use_depth2normal=bool(rs.randint(2)))
+    if marcher == 'pyramid_recursive':
+        kw['coarse_steps'] = (int(rs.randint(1, 4)), int(rs.randint(1, 4)))
+    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(1.3, 2.2)), float(rs.uniform(-30, 30)))
+    _, _, latent = fixture_decoder
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(*cam)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=3e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0, (res, H, W, kw, cam)
