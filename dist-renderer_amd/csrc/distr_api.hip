@@ -231,7 +231,7 @@ constexpr int BWD_CHUNK = 64;   // tiles per reduction chunk
 size_t bwd_bytes(const distr_render_cfg& c) {
   const size_t P = (size_t)band_rows(c) * c.W;
   const size_t smax = P * c.buffer_size + 1;
-  const size_t tiles = (smax + 31) / 32;
+  const size_t tiles = (smax + 31) / 32 + 256;
   const size_t nblk = (P + 255) / 256, nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
   return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + nchunks * PSTRIDE * sizeof(float) +
          nblk * (2 * sizeof(int32_t) + 16 * sizeof(float)) + 2048;
@@ -612,10 +612,11 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   Carver cv(ws_bwd);
   Sample* samples = cv.take<Sample>(smax);
   const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
-  float* partial = cv.take<float>((size_t)tiles * PSTRIDE);
+  const unsigned prows = tiles + 256;     // partial rows: a split list (bwd_range) has up to 256 32-sample tiles after the 64-sample ones
+  float* partial = cv.take<float>((size_t)prows * PSTRIDE);
 
   const int nblk = (P + 255) / 256;
-  const unsigned nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
+  const unsigned nchunks = (prows + BWD_CHUNK - 1) / BWD_CHUNK;
   float* chunk_part = cv.take<float>((size_t)nchunks * PSTRIDE);
   BwdBlocks BB;
   BB.cnt = cv.take<int32_t>(nblk); BB.off = cv.take<int32_t>(nblk); BB.acc = cv.take<float>((size_t)nblk * 16);
@@ -628,7 +629,13 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
-  if (V.save_masks) {
+  // tile-size split of the sample list (bwd_range): full rounds on 64-sample tiles, a small remainder on 32-sample tiles
+  const bool bsplit = V.save_masks && ctx->tile_rb == 0 && ctx->hybrid_threshold > 0;
+  if (bsplit) {
+    B.split = 1;
+    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3((unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3((unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+  } else if (V.save_masks) {
     if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
     else hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
   } else {
@@ -637,10 +644,10 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   }
   LAUNCH_CHECK("k_bwd<full>");
   hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, nchunks), dim3(256), 0, s, V, (const float*)partial, chunk_part,
-                     BWD_CHUNK, TILE);
+                     BWD_CHUNK, bsplit ? -1 : TILE);
   LAUNCH_CHECK("k_bwd_reduce");
-  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, (const float*)chunk_part, (int)nchunks, BWD_CHUNK, TILE, g_latent,
-                     g_R, g_T);
+  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, (const float*)chunk_part, (int)nchunks, BWD_CHUNK,
+                     bsplit ? -1 : TILE, g_latent, g_R, g_T);
   LAUNCH_CHECK("k_bwd_final");
   return DISTR_OK;
 }
