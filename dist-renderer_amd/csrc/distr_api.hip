@@ -41,6 +41,7 @@ struct distr_ctx {
   XRegion xr[NXR];
   bool cluster = true;          // DISTR_CLUSTER=0: single-workgroup 16-ray tiles only
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
+  bool persist64 = true;        // DISTR_PERSIST64=0: one workgroup per 64-ray tile in the merged launch
   bool merged_step = true;      // DISTR_MERGED_STEP=0: one launch per tile size and step instead of one merged launch per step
 };
 
@@ -275,6 +276,7 @@ int distr_create(distr_ctx** out, int hip_device) {
   if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
   if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
   if (const char* e = getenv("DISTR_MERGED_STEP")) ctx->merged_step = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_PERSIST64")) ctx->persist64 = atoi(e) != 0;
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
   int n = 0;
@@ -518,14 +520,14 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       // one launch per step: the three tile sizes are roles of the same grid (k_step)
       auto up8 = [](int64_t v) { return (int32_t)((v + 7) / 8 * 8); };
       StepGrid G;
-      G.n64 = skip64 ? 0 : up8((P + 63) / 64);
+      G.n64 = skip64 ? 0 : std::min(up8((P + 63) / 64), ctx->persist64 ? 256 : 0x7fffffff);   // persistent: at most one 64-ray workgroup per CU
       G.n32 = (A.t32 > A.t16 && !skip32) ? up8((std::min(P, A.t32) + 31) / 32) : 0;
       MarchArgs A2 = A;
       A2.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
       A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl);
       unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
       if (xr) n16 = std::max(n16, 256u);
-      G.n16 = (int32_t)n16;
+      G.n16 = up8(n16);
       const unsigned grid = (unsigned)(G.n64 + G.n32 + G.n16);
       if (V.save_masks) hipLaunchKernelGGL((k_step<true>), dim3(grid), dim3(NTHREADS), 0, s, A2, D, ctx->D16, G);
       else hipLaunchKernelGGL((k_step<false>), dim3(grid), dim3(NTHREADS), 0, s, A2, D, ctx->D16, G);

@@ -386,8 +386,9 @@ struct MarchArgs {
 // that the backward pass does not have to recompute the decoder forward (View::mstore).
 // Body of one 32*RB-ray tile; `tile` / `ntile_grid` = index and count of the tiles this launch (or this role of a merged
 // launch, k_step) provides, `which` = the tile size the split rule (fine_range) knows this role by.
+// Returns false when the tile lies beyond this role's range (nothing done).
 template <int MODE, int RB, bool KEEP>
-__device__ __forceinline__ void march_tile(const MarchArgs& A, const DecoderDev& D, Smem<RB>& S, int tile, int ntile_grid, int which,
+__device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev& D, Smem<RB>& S, int tile, int ntile_grid, int which,
                                            int origin_tile) {
   constexpr int TILE = 32 * RB;
   const View& V = A.V;
@@ -409,7 +410,7 @@ __device__ __forceinline__ void march_tile(const MarchArgs& A, const DecoderDev&
   int64_t lo = 0, hi = count;
   if (MODE == MODE_FINE && V.cfg.marcher != DISTR_MARCH_TRIVIAL) fine_range(count, A.t16, A.t32, which, lo, hi);
   const int64_t base = lo + (int64_t)tile * TILE;
-  if (!origin && base >= hi) return;
+  if (!origin && base >= hi) return false;
   count = hi;
 
   int32_t id = -1;
@@ -498,12 +499,13 @@ __device__ __forceinline__ void march_tile(const MarchArgs& A, const DecoderDev&
       if (b >= 0) store_mask_chunk<RB>(V.mstore + (size_t)b * 32, masks, rb, wave, lane >> 5);
     }
   }
+  return true;
 }
 
 template <int MODE, int RB, bool KEEP>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
   __shared__ Smem<RB> S;
-  march_tile<MODE, RB, KEEP>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
+  (void)march_tile<MODE, RB, KEEP>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
 }
 
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
@@ -648,23 +650,31 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
 }
 
 // One full-resolution march step of the recursive marchers in ONE launch: the three tile sizes of the split (fine_range)
-// are roles of the same grid -- workgroups [0, n64) run 64-ray tiles, [n64, n64 + n32) 32-ray tiles, the rest 16-ray /
-// cluster tiles (n64, n32 multiples of 8, so cluster members keep equal index mod 8 = the same XCD). Each role finds its
-// range from the device-side live count and exits if it is empty. Against three launches per step this saves two empty
-// launches (4-5 us each) on almost every step; the long tiles are dispatched first.
+// are roles of the same grid -- n32 workgroups for 32-ray tiles, n16 for 16-ray / cluster tiles, n64 for 64-ray tiles
+// (n32 a multiple of 8, so cluster members keep equal index mod 8 = the same XCD). Each role finds its
+// range from the device-side live count and exits if it is empty. The 64-ray role is PERSISTENT: at most one workgroup
+// per CU, each walking tiles b, b + n64, ... of the range (the tiles cost the same, so the static assignment loses
+// nothing, a full round needs no re-dispatch, and a tail step has 512 idle workgroups to retire instead of 4 352).
+// Against three launches per step this saves two empty launches (4-5 us each) on almost every step.
 struct StepGrid { int32_t n64, n32, n16; };
 
 template <bool KEEP>
 __global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, DecoderDev16 D16, StepGrid G) {
   __shared__ __attribute__((aligned(16))) unsigned char raw[sizeof(Smem<2>)];
   static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CL), "role shared memory");
+  // role order in the grid: 32-ray tiles, 16-ray / cluster tiles, 64-ray tiles. On a tail step the cluster tiles start
+  // after one wave of idle 32-ray workgroups and the idle 64-ray workgroups retire on the free CUs while the clusters
+  // run; on a dense step the remainder tiles start first and the persistent 64-ray workgroups follow as CUs free up.
   const int b = blockIdx.x;
-  if (b < G.n64) {
-    march_tile<MODE_FINE, 2, KEEP>(A, D, *reinterpret_cast<Smem<2>*>(raw), b, G.n64, 64, 0);
-  } else if (b < G.n64 + G.n32) {
-    march_tile<MODE_FINE, 1, KEEP>(A, D, *reinterpret_cast<Smem<1>*>(raw), b - G.n64, G.n32, 32, 0);
+  if (b < G.n32) {
+    (void)march_tile<MODE_FINE, 1, KEEP>(A, D, *reinterpret_cast<Smem<1>*>(raw), b, G.n32, 32, 0);
+  } else if (b < G.n32 + G.n16) {
+    march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n32, A.origin_tile);
   } else {
-    march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n64 - G.n32, A.origin_tile);
+    for (int t = b - G.n32 - G.n16;; t += G.n64) {
+      if (!march_tile<MODE_FINE, 2, KEEP>(A, D, *reinterpret_cast<Smem<2>*>(raw), t, 0x7fffffff, 64, 0)) break;
+      __syncthreads();       // the tile's last LDS reads (mask store) are done before the next tile's points are written
+    }
   }
 }
 
