@@ -297,6 +297,59 @@ __device__ __forceinline__ int topk_insert(const View& V, int px, float s, float
   return free_slot;
 }
 
+// Per-ray march state requested in a tile's PROLOGUE (before the decoder runs) so that the epilogue needs no dependent
+// global loads: with one workgroup per CU nothing else hides that latency (~5 us of a 380 us tile, more of a tail tile).
+struct RayPre {
+  float m, init_now, maxbound, minabs;
+  float ks[MAX_BS];      // selected rows' sdf, |.| ascending
+  int32_t sl[MAX_BS];    // their mask slots
+};
+
+__device__ __forceinline__ void raypre_load(const View& V, int px, RayPre& st) {
+  const size_t P = (size_t)V.P;
+  const int bs = V.cfg.buffer_size;
+  st.m = V.m[px]; st.init_now = V.init_now[px]; st.maxbound = V.maxbound[px]; st.minabs = V.minabs[px];
+#pragma unroll
+  for (int k = 0; k < MAX_BS; ++k) {
+    st.ks[k] = (k < bs) ? V.tk_s[k * P + px] : 0.f;
+    st.sl[k] = (k < bs) ? V.tk_slot[k * P + px] : 0;
+  }
+}
+
+// topk_insert with the keys / slots already in registers (same result, same memory image)
+__device__ __forceinline__ int topk_insert_pre(const View& V, const RayPre& st, int px, float s, float zb, float za, int32_t src) {
+  const int bs = V.cfg.buffer_size;
+  const size_t P = (size_t)V.P;
+  const float key = fabsf(s);
+  int pos = bs;
+  bool open = true;
+#pragma unroll
+  for (int k = MAX_BS - 1; k >= 0; --k) {
+    if (k < bs && open) { if (key < fabsf(st.ks[k])) pos = k; else open = false; }
+  }
+  if (pos >= bs) return -1;
+  int used = 0;
+#pragma unroll
+  for (int k = 0; k < MAX_BS; ++k) used += (k < bs) ? st.sl[k] : 0;
+  const int free_slot = bs * (bs + 1) / 2 - used;
+#pragma unroll
+  for (int k = MAX_BS - 1; k >= 1; --k) {
+    if (k < bs && k > pos) {
+      V.tk_s[k * P + px] = st.ks[k - 1];
+      V.tk_slot[k * P + px] = st.sl[k - 1];
+      V.tk_zb[k * P + px] = V.tk_zb[(k - 1) * P + px];
+      V.tk_za[k * P + px] = V.tk_za[(k - 1) * P + px];
+      V.tk_src[k * P + px] = V.tk_src[(k - 1) * P + px];
+    }
+  }
+  V.tk_s[pos * P + px] = s;
+  V.tk_zb[pos * P + px] = zb;
+  V.tk_za[pos * P + px] = za;
+  V.tk_src[pos * P + px] = src;
+  V.tk_slot[pos * P + px] = free_slot;
+  return free_slot;
+}
+
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
 __global__ void __launch_bounds__(256) k_fine_init(View V) {
   const LevelView& L0 = V.lv[0];
@@ -416,6 +469,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   int32_t id = -1;
   float zd = 0.f;
   bool valid = false;
+  RayPre st;
   if (tid < TILE) {
     float p[3] = {0.f, 0.f, 0.f};
     if (!origin) {
@@ -432,7 +486,8 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
           float cx, cy;
           level_center(L, id, cx, cy);
           const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-          zd = (MODE == MODE_COARSE) ? (L.cinit[id] + L.cm[id]) : (V.init_now[id] + V.m[id]);
+          if (MODE == MODE_FINE) { raypre_load(V, id, st); zd = st.init_now + st.m; }
+          else zd = L.cinit[id] + L.cm[id];
           make_point(V.cfg.M, cam.c, g.d, zd, p);
         }
       }
@@ -470,16 +525,15 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
       } else {  // MODE_FINE
         bool stay = false;
         if (valid) {
-          const float init_now = V.init_now[id];
-          const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
+          const float mn = st.m + clampf(s, -cd, cd) * ratio;
           V.m[id] = mn;
-          const float za = mn + init_now;
-          const int slot = topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
+          const float za = mn + st.init_now;
+          const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
           if (slot >= 0) mblock = (int64_t)id * (V.cfg.buffer_size + 1) + slot;
           const float a = fabsf(s);
-          if (a < V.minabs[id]) V.minabs[id] = a;
+          if (a < st.minabs) V.minabs[id] = a;
           if (A.step == 0) V.first_sdf[id] = s;
-          stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+          stay = (za < st.maxbound) && (a >= V.cfg.threshold);
         }
         if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
           wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
@@ -553,6 +607,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   int32_t id = -1;
   float zd = 0.f;
   bool valid = false;
+  RayPre st;
   if (tid < TILE) {
     float p[3] = {0.f, 0.f, 0.f};
     const int64_t r = base + tid;
@@ -568,7 +623,8 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
         float cx, cy;
         level_center(L, id, cx, cy);
         const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-        zd = (MODE == MODE_COARSE) ? (L.cinit[id] + L.cm[id]) : (V.init_now[id] + V.m[id]);
+        if (MODE == MODE_FINE) { raypre_load(V, id, st); zd = st.init_now + st.m; }
+        else zd = L.cinit[id] + L.cm[id];
         make_point(V.cfg.M, cam.c, g.d, zd, p);
       }
     }
@@ -611,16 +667,15 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
       bool stay = false;
       if (valid) {
-        const float init_now = V.init_now[id];
-        const float mn = V.m[id] + clampf(s, -cd, cd) * ratio;
+        const float mn = st.m + clampf(s, -cd, cd) * ratio;
         V.m[id] = mn;
-        const float za = mn + init_now;
-        const int slot = topk_insert(V, id, s, zd, V.pyramid ? za : mn, id);
+        const float za = mn + st.init_now;
+        const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);
         if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
         const float a = fabsf(s);
-        if (a < V.minabs[id]) V.minabs[id] = a;
+        if (a < st.minabs) V.minabs[id] = a;
         if (A.step == 0) V.first_sdf[id] = s;
-        stay = (za < V.maxbound[id]) && (a >= V.cfg.threshold);
+        stay = (za < st.maxbound) && (a >= V.cfg.threshold);
       }
       wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
     }
