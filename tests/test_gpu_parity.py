@@ -908,3 +908,51 @@ def test_random_configs_match_oracle(engine, cpu_oracle, orc, fixture_decoder, s
     b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
     res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=3e-4, normal_p99=1e-5, max_flip_frac=0.0)
     assert res['flips'] == 0, (res, H, W, kw, cam)
+
+
+@pytest.mark.gpu
+def test_c_abi_error_paths(engine, fixture_decoder):
+    """Error behaviour of the C ABI: non-zero return + distr_last_error text, nothing crashes: null pointers, too-small
+    workspaces, bad configurations, backward on an inference-only forward, calls before distr_set_decoder."""
+    import ctypes as C
+    import torch
+    from distr import binding, fixture
+    L, h = engine.ctx.L, engine.ctx.h
+    K = fixture.make_intrinsic(32, 32)
+    cfg = binding.make_cfg((32, 32), K, march_step=12, buffer_size=3)
+    fwd, bwd = engine.ctx.workspace_bytes(cfg)
+    ws = torch.empty(fwd, dtype=torch.uint8, device='cuda')
+    lat = torch.zeros(256, device='cuda'); R = torch.eye(3, device='cuda').reshape(-1); T = torch.tensor([0., 0., 1.6], device='cuda')
+    z = torch.empty(1024, device='cuda'); m = torch.empty(1024, dtype=torch.uint8, device='cuda'); q = torch.empty(1024, device='cuda')
+    p, s = binding.ptr, engine.ctx.stream()
+
+    def err():
+        return L.distr_last_error(h).decode()
+    assert L.distr_render_forward(h, C.byref(cfg), None, p(R), p(T), p(z), p(m), p(q), None, None, p(ws), ws.numel(), s) != 0 and 'null' in err()
+    assert L.distr_render_forward(h, C.byref(cfg), p(lat), p(R), p(T), p(z), p(m), p(q), None, None, p(ws), 1024, s) != 0 and 'workspace' in err()
+    for field, val in (('buffer_size', 0), ('buffer_size', 9), ('marcher', 7), ('march_step', 3), ('H', 0), ('radius', -1.0)):
+        bad = cfg.clone()
+        setattr(bad, field, val)
+        f, b = C.c_size_t(), C.c_size_t()
+        assert L.distr_workspace_bytes(h, C.byref(bad), C.byref(f), C.byref(b)) != 0, field
+        assert len(err()) > 0
+    # backward on a forward that did not save for backward
+    inf = cfg.clone()
+    inf.save_for_backward = 0
+    inf.want_normal = 0
+    assert L.distr_render_forward(h, C.byref(inf), p(lat), p(R), p(T), p(z), p(m), p(q), None, None, p(ws), ws.numel(), s) == 0
+    wsb = torch.empty(bwd, dtype=torch.uint8, device='cuda')
+    g = torch.empty(256, device='cuda'); gR = torch.empty(9, device='cuda'); gT = torch.empty(3, device='cuda')
+    rc = L.distr_render_backward(h, C.byref(inf), p(ws), ws.numel(), p(z), p(q), None, None, p(g), p(gR), p(gT), p(wsb), wsb.numel(), s)
+    assert rc != 0 and 'save_for_backward' in err()
+    # a context without a decoder
+    ctx2 = binding.Context(0)
+    out = torch.empty(4, 1, device='cuda'); x = torch.zeros(4, 3, device='cuda')
+    w2 = torch.empty(L.distr_mlp_workspace_bytes(4), dtype=torch.uint8, device='cuda')
+    assert L.distr_mlp_eval(ctx2.h, p(lat), p(x), 4, -1.0, p(out), p(w2), w2.numel(), s) != 0
+    assert 'distr_set_decoder' in L.distr_last_error(ctx2.h).decode()
+    assert L.distr_color_eval(ctx2.h, p(lat), p(x), 4, p(out), p(w2), w2.numel(), s) != 0
+    # wrong weight count
+    with pytest.raises(binding.DistrError):
+        ctx2.set_decoder(np.zeros(10, np.float32))
+    torch.cuda.synchronize()

@@ -155,3 +155,23 @@ def test_row_sharding_tiles_every_image_once():
         assert (cover == 1).all()
     assert parallel.shard_rows(4, 1024, 5, 8) == [(2, 512, 1024)]
     assert parallel.shard_rows(4, 1024, 1, 2) == [(2, 0, 1024), (3, 0, 1024)]
+
+
+def test_c_abi_from_plain_c(libdistr, tmp_path):
+    """include/distr.h compiles as C (gcc -std=c99 -pedantic) and a plain-C program resolves every entry point from the
+    shared library and runs the GPU-free calls."""
+    import shutil
+    import subprocess
+    from distr import binding
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    exe = str(tmp_path / 'abi_check')
+    src = os.path.join(ROOT, 'tests', 'c_abi', 'abi_check.c')
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-o', exe, src, '-ldl'])
+    out = subprocess.run([exe, binding.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert 'symbols=24' in out.stdout and 'version="distr' in out.stdout
+    assert ('sizeof(cfg)=%d' % C.sizeof(binding.RenderCfg)) in out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert 'create_rc=0' not in out.stdout and 'device' in out.stdout
