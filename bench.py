@@ -79,6 +79,10 @@ def main():
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
     ap.add_argument('--march-step', type=int, default=50)
+    ap.add_argument('--loss', default='dense', choices=['dense', 'reference'],
+                    help='dense (default): seeded per-pixel weights on depth, normal and min-sdf of EVERY pixel (the loss of the golden '
+                         'vectors; the heaviest backward: every in-sphere ray carries a gradient sample); reference: the single-view '
+                         'loss of run_single_shape.py:93-98 against a ground truth rendered once from a perturbed latent')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU (c5 at N <= 4)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
@@ -126,8 +130,24 @@ def main():
     loss_buf = torch.zeros(1, device=dev)
     zero_grad = torch.zeros(1, 256, device=dev)
 
-    def image_loss(outs, r0, r1):
+    gts = {}
+    if args.loss == 'reference':
+        # ground truth per (shape, view): rendered once (outside the timed region) from a perturbed latent
+        for (shape, v, _, _) in items:
+            if (shape, v) not in gts:
+                pert = torch.from_numpy(0.1 * np.random.RandomState(900 + shape).standard_normal((1, 256)).astype(np.float32)).to(dev)
+                with torch.no_grad():
+                    _, gm, _, gd, gn = functions.render_call(eng, cfg, lats[shape].detach() + pert, cams[v][0].detach(), cams[v][1].detach())
+                gts[(shape, v)] = (gd.clone(), gn.clone(), gm.reshape(H, W).clone())
+        lw = torch.tensor([1.0, 1.0, 10.0, 5.0], device=dev)      # mask_gt, mask_out, depth, normal (run_single_shape.py:93-98)
+
+    def image_loss(outs, r0, r1, key=None):
         z, mask, q, depth, normal = outs
+        if args.loss == 'reference':
+            gd, gn, gm = gts[key]
+            terms = functions.single_view_losses(eng, depth, normal, mask.reshape(r1 - r0, W), q.reshape(r1 - r0, W), gd[r0:r1], gn[r0:r1],
+                                                 gm[r0:r1], cfg.threshold)
+            return (terms * lw).sum()
         mb = mask.reshape(r1 - r0, W).bool()
         return torch.where(mb, depth * wd[r0:r1], torch.zeros_like(depth)).sum() + (q.reshape(r1 - r0, W) * wq[r0:r1]).sum() + \
             (normal * wn[r0:r1]).sum()
@@ -143,7 +163,7 @@ def main():
             outs = functions.render_call(eng, cfg, lats[shape], Rt, Tt)
         else:
             outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
-        return image_loss(outs, r0, r1)
+        return image_loss(outs, r0, r1, (shape, v))
 
     def step():
         for l in lats:
@@ -193,7 +213,7 @@ def main():
     one = (lambda: functions.render_call(eng, cfg, lats[shape0], Rt0, Tt0)) if (r00, r01) == (0, H) else \
         (lambda: functions.render_band_call(eng, cfg, lats[shape0], Rt0, Tt0, r00, r01))
     outs0, fwd_ms = timed(one)
-    Lsplit = image_loss(outs0, r00, r01)
+    Lsplit = image_loss(outs0, r00, r01, (shape0, v0))
     _, bwd_ms = timed(lambda: Lsplit.backward())
 
     # counters of one forward of every work item of this rank (identical every step: same inputs)
@@ -233,8 +253,9 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if c5 else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)',
             'config': {'workload': '%s%dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
-                                   'fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
+                                   '%s loss, fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
                                                          args.marcher, BUFFER_SIZE, RATIO,
+                                                         'dense per-pixel' if args.loss == 'dense' else 'reference single-view',
                                                          'fixed total work split shape-major then in row bands' if c5 else '1 view per GPU'),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + ' (RCCL all-reduce of packed latent grad)',
                        'rank0_items': [list(it) for it in items],
