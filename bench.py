@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--size', type=int, default=512, help='image side (default 512 = the headline config C3)')
     ap.add_argument('--march-step', type=int, default=50)
+    ap.add_argument('--view-offset', type=int, default=0, help='diagnostics: rank r renders view (r + offset) mod 8 of the C4 camera circle')
     ap.add_argument('--loss', default='dense', choices=['dense', 'reference'],
                     help='dense (default): seeded per-pixel weights on depth, normal and min-sdf of EVERY pixel (the loss of the golden '
                          'vectors; the heaviest backward: every in-sphere ray carries a gradient sample); reference: the single-view '
@@ -116,7 +117,7 @@ def main():
         lats_np = [latent_np] + [fixture.make_latent(1234 + i) for i in range(1, n_shapes)]
     else:
         n_shapes = 1
-        items = [(0, v, 0, H) for v in parallel.shard_views(args.gpus, rank, world)]          # one view per GPU
+        items = [(0, (v + args.view_offset) % 8, 0, H) for v in parallel.shard_views(args.gpus, rank, world)]     # one view per GPU
         lats_np = [latent_np]
     cams = {}
     for (_, v, _, _) in items:
