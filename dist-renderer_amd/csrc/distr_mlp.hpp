@@ -52,14 +52,41 @@ struct DecoderDev {
 
 // A tile = RB blocks of 32 rays. RB=2: 64 rays, 133 KiB LDS, one workgroup per CU. RB=1: 32 rays, 67 KiB LDS, two
 // workgroups per CU (each hides the other's prologue / epilogue / barrier stalls; half the tile latency).
+// 64-ray tiles also stage the eight layers' accumulator start values (c0, b1, b2, b3, c4, b5, b6, b7: 16 KiB) in LDS once
+// per tile, so that a layer does not begin with an exposed L2 round trip for its biases (the 32-ray tile has no LDS
+// left for this: two of them share a CU).
+template <int RB> struct SmemBias { };
+template <> struct SmemBias<2> { float bias[8 * HID]; };
+
 template <int RB>
-struct Smem {
+struct Smem : SmemBias<RB> {
   static constexpr int TILE = 32 * RB;
   float X[HID * TILE];   // activations / deltas [feature][ray]
   float xyz[4 * TILE];   // rows 0..2: sample points of the tile
   float part[12 * TILE]; // lin8 partial chains [4][TILE]; backward: xyz-gradient partials [3][4][TILE]
   float aux[4 * TILE];   // backward: row 0 = d8, rows 1..3 = d/dxyz through lin4's xyz columns
 };
+
+template <int RB>
+__device__ __forceinline__ void stage_bias(const DecoderDev& D, const float* __restrict__ c0, const float* __restrict__ c4, Smem<RB>& S) {
+  if constexpr (RB == 2) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const float* src = (l == 0) ? c0 : (l == 4) ? c4 : D.bias[l];
+      const int n = (l == 3) ? 256 : HID;
+#pragma unroll
+      for (int i = tid; i < HID; i += NTHREADS) S.bias[l * HID + i] = (i < n) ? src[i] : 0.f;
+    }
+  }
+}
+
+// start values of layer l for this tile: LDS copy (RB == 2, after stage_bias + barrier) or the global arrays
+template <int RB>
+__device__ __forceinline__ const float* layer_init(const DecoderDev& D, const float* c0, const float* c4, const Smem<RB>& S, int l) {
+  if constexpr (RB == 2) return S.bias + l * HID;
+  else return (l == 0) ? c0 : (l == 4) ? c4 : D.bias[l];
+}
 
 // ---------------------------------------------------------------------------------------- scalar math
 // tanh in explicit IEEE operations so that host (oracle) and device agree bit for bit.
@@ -182,6 +209,63 @@ __device__ __forceinline__ void dense(const float* __restrict__ Wp, const float*
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) b[s][rb] = bn[s][rb];
   }
+}
+
+// dense() with (part of) the layer's first weight group already in registers -- requested during the previous layer --
+// and the look-ahead slot of the last iteration, which would otherwise re-fetch the last group, pointed at the NEXT
+// layer's first group: no layer starts with an exposed L2 round trip for its weights. pre[0..NIN) = this wave's first NIN
+// fragments of group 0 (NIN <= NOB); on return pre[0..NOUT) = the first NOUT (<= NOB) fragments of the next layer's group 0
+// (WpNext, whose waves own NOBN row blocks each); WpNext == nullptr: nothing is fetched.
+template <int K, int NOB, int RB, int NIN, int NOUT, int NOBN>
+__device__ __forceinline__ void dense_pf(const float* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][RB], int wave, int lane,
+                                         f32x4 (&pre)[4], const float* __restrict__ WpNext) {
+  constexpr int NG = K / 8;
+  constexpr int TILE = 32 * RB;
+  static_assert(NIN <= NOB && NOUT <= NOB && NOUT <= NOBN, "prefetch slots");
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)wave * NOB * 64 + lane;
+  const f32x4* wnext = WpNext ? reinterpret_cast<const f32x4*>(WpNext) + (size_t)wave * NOBN * 64 + lane : wp + (size_t)(NG - 1) * (4 * NOB * 64);
+  const float* xb = X + (lane >> 5) * TILE + (lane & 31);
+  f32x4 a[NOB];
+  float b[4][RB];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) a[ob] = (ob < NIN) ? pre[ob] : wp[ob * 64];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) b[s][rb] = xb[2 * s * TILE + 32 * rb];
+#pragma unroll 2
+  for (int g = 0; g < NG; ++g) {
+    f32x4 an[NOB];
+    float bn[4][RB];
+    const bool last = (g + 1 == NG);
+    const int gn = last ? g : g + 1;
+    const f32x4* wn = last ? wnext : wp + (size_t)gn * (4 * NOB * 64);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) an[ob] = wn[((last && ob >= NOUT) ? 0 : ob) * 64];
+    const float* xg = xb + (size_t)gn * 8 * TILE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) bn[s][rb] = xg[2 * s * TILE + 32 * rb];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][s], b[s][rb], acc[ob][rb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) a[ob] = an[ob];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) b[s][rb] = bn[s][rb];
+  }
+#pragma unroll
+  for (int ob = 0; ob < NOUT; ++ob) pre[ob] = a[ob];
 }
 
 // Write a layer's accumulators back to X (in place). RELU: max(x,0); mask out: bit (rb*16+r) of mask[ob] = x>0.
@@ -308,14 +392,22 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
   const int h = lane >> 5;
   const int ray = tid & (TILE - 1);
   float* X = S.X;
+  // first weight group of every layer travels while the previous layer finishes (dense_pf)
+  f32x4 wpre[4];
+  {
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(D.Wf[0]) + (size_t)wave * 4 * 64 + lane;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) wpre[ob] = w0[ob * 64];
+  }
+  stage_bias<RB>(D, c0, c4, S);
   // layer-0 input rows: xyz + zero padding to K=8
 #pragma unroll
   for (int i = tid; i < 8 * TILE; i += NTHREADS) X[i] = (i < 3 * TILE) ? S.xyz[i] : 0.f;
   __syncthreads();
   {
     f32x16 acc[4][RB];
-    acc_init<4, RB>(acc, c0, wave * 128, h);
-    dense<8, 4, RB>(D.Wf[0], X, acc, wave, lane);
+    acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, 0), wave * 128, h);
+    dense_pf<8, 4, RB, 4, 4, 4>(D.Wf[0], X, acc, wave, lane, wpre, D.Wf[1]);
     DISTR_TS(1);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[0]);
@@ -323,22 +415,32 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     DISTR_TS(2);
   }
   if (DEBUG_STOP && stop == 0) return 0.f;
-#pragma unroll
-  for (int l = 1; l <= 2; ++l) {
+  {
     f32x16 acc[4][RB];
-    acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
-    dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
-    DISTR_TS(2 * l + 1);
+    acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, 1), wave * 128, h);
+    dense_pf<512, 4, RB, 4, 4, 4>(D.Wf[1], X, acc, wave, lane, wpre, D.Wf[2]);
+    DISTR_TS(3);
     __syncthreads();
-    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[1]);
     __syncthreads();
-    DISTR_TS(2 * l + 2);
-    if (DEBUG_STOP && stop == l) return 0.f;
+    DISTR_TS(4);
+    if (DEBUG_STOP && stop == 1) return 0.f;
+  }
+  {
+    f32x16 acc[4][RB];
+    acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, 2), wave * 128, h);
+    dense_pf<512, 4, RB, 4, 2, 2>(D.Wf[2], X, acc, wave, lane, wpre, D.Wf[3]);
+    DISTR_TS(5);
+    __syncthreads();
+    writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[2]);
+    __syncthreads();
+    DISTR_TS(6);
+    if (DEBUG_STOP && stop == 2) return 0.f;
   }
   {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
     f32x16 acc[2][RB];
-    acc_init<2, RB>(acc, D.bias[3], wave * 64, h);
-    dense<512, 2, RB>(D.Wf[3], X, acc, wave, lane);
+    acc_init<2, RB>(acc, layer_init<RB>(D, c0, c4, S, 3), wave * 64, h);
+    dense_pf<512, 2, RB, 2, 2, 4>(D.Wf[3], X, acc, wave, lane, wpre, D.Wf[4]);
     DISTR_TS(7);
     __syncthreads();
     masks[3][2] = 0; masks[3][3] = 0;
@@ -351,8 +453,8 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
   if (DEBUG_STOP && stop == 3) return 0.f;
   {  // lin4: [x3(253) | xyz(3)] -> 512, latent part folded into c4
     f32x16 acc[4][RB];
-    acc_init<4, RB>(acc, c4, wave * 128, h);
-    dense<256, 4, RB>(D.Wf[4], X, acc, wave, lane);
+    acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, 4), wave * 128, h);
+    dense_pf<256, 4, RB, 2, 4, 4>(D.Wf[4], X, acc, wave, lane, wpre, D.Wf[5]);
     DISTR_TS(9);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
@@ -363,8 +465,8 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
 #pragma unroll
   for (int l = 5; l <= 7; ++l) {
     f32x16 acc[4][RB];
-    acc_init<4, RB>(acc, D.bias[l], wave * 128, h);
-    dense<512, 4, RB>(D.Wf[l], X, acc, wave, lane);
+    acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, l), wave * 128, h);
+    dense_pf<512, 4, RB, 4, 4, 4>(D.Wf[l], X, acc, wave, lane, wpre, (l < 7) ? D.Wf[l + 1] : nullptr);
     DISTR_TS(2 * l + 1);
     __syncthreads();
     writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
