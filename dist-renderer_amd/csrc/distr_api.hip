@@ -35,7 +35,8 @@ struct distr_ctx {
   size_t ev_used = 0;
   // exchange regions of the cluster tiles (distr_mlp.hpp, "Cluster tile"): uncached device memory, one region per stream
   // that renders through this context (concurrent renders on different streams must not share barrier words)
-  struct XRegion { float* buf = nullptr; uint32_t* flags = nullptr; uint32_t epoch = 0; hipStream_t stream = nullptr; bool used = false; };
+  struct XRegion { float* buf = nullptr; uint32_t* flags = nullptr; uint32_t epoch = 0; hipStream_t stream = nullptr; bool used = false; uint64_t last_use = 0; };
+  uint64_t xr_clock = 0;
   bool xchg_ts = false;         // DISTR_XCHG_TS=1: cluster 0 / member 0 writes phase stamps behind the flag words (distr_debug_xchg_ts)
   static constexpr int NXR = 8;
   XRegion xr[NXR];
@@ -137,10 +138,23 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   if (!ctx->cluster) return nullptr;
   distr_ctx::XRegion* free_slot = nullptr;
   for (auto& r : ctx->xr) {
-    if (r.used && r.stream == stream) return &r;
+    if (r.used && r.stream == stream) { r.last_use = ++ctx->xr_clock; return &r; }
     if (!r.used && !free_slot) free_slot = &r;
   }
-  if (!free_slot) return nullptr;
+  if (!free_slot) {
+    // all regions taken: hand the least recently used one whose stream has nothing in flight to the new stream
+    distr_ctx::XRegion* lru = nullptr;
+    for (auto& r : ctx->xr) {
+      if (lru && r.last_use >= lru->last_use) continue;
+      const hipError_t q = hipStreamQuery(r.stream);
+      if (q == hipErrorNotReady) continue;            // still working: its barrier words are live
+      if (q != hipSuccess) (void)hipGetLastError();   // stale handle of a destroyed stream
+      lru = &r;
+    }
+    if (!lru) return nullptr;
+    lru->stream = stream; lru->last_use = ++ctx->xr_clock;
+    return lru;
+  }
   constexpr size_t buf_bytes = (size_t)256 * 2 * 8192 * sizeof(float), flag_bytes = (size_t)256 * 128 * sizeof(uint32_t) + 64 * sizeof(long long);
   int cur = -1;
   (void)hipGetDevice(&cur);
@@ -155,7 +169,7 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
     ctx->cluster = false;
     return nullptr;
   }
-  free_slot->used = true; free_slot->stream = stream; free_slot->epoch = 0;
+  free_slot->used = true; free_slot->stream = stream; free_slot->epoch = 0; free_slot->last_use = ++ctx->xr_clock;
   return free_slot;
 }
 

@@ -987,15 +987,16 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
     main = torch.cuda.current_stream()
     ref = [render(i, main) for i in range(16)]
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(8)]
+    streams = [torch.cuda.Stream() for _ in range(12)]       # more streams than exchange regions (8): idle regions are recycled
     for s in streams:
         s.wait_stream(main)
     got = []
     for rep in range(3):                      # several waves of concurrent launches
         got = []
         for i in range(16):
-            with torch.cuda.stream(streams[i % 8]):
-                got.append(render(i, streams[i % 8]))
+            st_ = streams[(i + 4 * rep) % (8 if rep < 2 else 12)]
+            with torch.cuda.stream(st_):
+                got.append(render(i, st_))
     torch.cuda.synchronize()
     for i in range(16):
         for a, b in zip(got[i][0], ref[i][0]):
