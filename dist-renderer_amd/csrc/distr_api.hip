@@ -136,6 +136,12 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
 // state never allocates). Null (-> single-workgroup tiles) when disabled, out of regions, or the allocation fails.
 distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   if (!ctx->cluster) return nullptr;
+  {  // a launch sequence that is being captured into a graph would replay with the epochs of the capture (the barrier words
+     // would already match) and must not allocate or query streams: single-workgroup tiles for captured renders
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) return nullptr;
+  }
   distr_ctx::XRegion* free_slot = nullptr;
   for (auto& r : ctx->xr) {
     if (r.used && r.stream == stream) { r.last_use = ++ctx->xr_clock; return &r; }

@@ -1003,3 +1003,54 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
             assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes(), i
         st = engine.ctx.render_stats(cfg, got[i][1])
         assert st['cluster_timeouts'] == 0 and st['num_in_sphere'] > 0
+
+
+@pytest.mark.gpu
+def test_forward_is_graph_capturable(engine, fixture_decoder):
+    """The forward is a fixed launch sequence with device-side control flow only, so it can be captured into a HIP graph
+    and replayed with new inputs written into the same buffers (cluster tiles are left out of captured renders: their
+    barrier epochs are launch-time values)."""
+    import ctypes as C
+    import torch
+    from distr import binding, fixture
+    _, _, latent = fixture_decoder
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    cfg = binding.make_cfg((H, W), K, march_step=30, buffer_size=3, use_depth2normal=True)
+    cfg.save_for_backward = 0
+    fwd, _ = engine.ctx.workspace_bytes(cfg)
+    p = binding.ptr
+    lat = torch.from_numpy(latent).cuda().reshape(-1).clone()
+    R0, T0 = fixture.make_camera(10.0, 5.0, 1.6, 0.0)
+    R1, T1 = fixture.make_camera(-40.0, 30.0, 1.8, 12.0)
+    Rt, Tt = torch.from_numpy(R0).cuda().reshape(-1).clone(), torch.from_numpy(T0).cuda().clone()
+    ws = torch.empty(fwd, dtype=torch.uint8, device='cuda')
+    o = [torch.empty(H * W, device='cuda'), torch.empty(H * W, dtype=torch.uint8, device='cuda'), torch.empty(H * W, device='cuda'),
+         torch.empty(H, W, device='cuda'), torch.empty(H, W, 3, device='cuda')]
+
+    def launch():
+        engine.ctx.check(engine.ctx.L.distr_render_forward(engine.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt), p(o[0]), p(o[1]), p(o[2]), p(o[3]),
+                                                          p(o[4]), p(ws), ws.numel(), engine.ctx.stream()))
+    launch()
+    torch.cuda.synchronize()
+    want0 = [t.clone() for t in o]
+    Rt.copy_(torch.from_numpy(R1).reshape(-1)); Tt.copy_(torch.from_numpy(T1))
+    launch()
+    torch.cuda.synchronize()
+    want1 = [t.clone() for t in o]
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            launch()
+    torch.cuda.synchronize()
+    for (R, T, want) in ((R0, T0, want0), (R1, T1, want1), (R0, T0, want0)):
+        Rt.copy_(torch.from_numpy(R).reshape(-1)); Tt.copy_(torch.from_numpy(T))
+        for t in o:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(o, want):
+            assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+    assert want0[1].sum() > 50 and (want0[3] != want1[3]).any()
