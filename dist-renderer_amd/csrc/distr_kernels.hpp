@@ -465,6 +465,9 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   const int64_t base = lo + (int64_t)tile * TILE;
   if (!origin && base >= hi) return false;
   count = hi;
+  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
+  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
+  stage_bias<RB>(D, c0, c4, S);      // first thing: these loads travel under the prologue's dependent state loads
 
   int32_t id = -1;
   float zd = 0.f;
@@ -497,9 +500,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   __syncthreads();
 
   uint32_t masks[8][4];
-  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
-  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  const float pre = mlp_forward<RB, KEEP>(D, c0, c4, S, masks);
+  const float pre = mlp_forward<RB, KEEP, false, true>(D, c0, c4, S, masks);
 
   // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
   int64_t mblock = -1;   // mask block this ray's row goes to (KEEP), -1: row not kept

@@ -378,7 +378,8 @@ __device__ __forceinline__ float lin8_row(const float* __restrict__ w8row, float
 
 // Returns (every thread, for ray = tid & (TILE-1)) the pre-tanh output. masks[l] = ReLU bitmasks of layer l
 // (bit rb*16+r of masks[l][ob]). DEBUG_STOP: (test builds only) return right after layer `stop` is in X.
-template <int RB, bool KEEP, bool DEBUG_STOP = false>
+// STAGED: the caller already ran stage_bias (early, so that its loads overlap the tile's prologue).
+template <int RB, bool KEEP, bool DEBUG_STOP = false, bool STAGED = false>
 __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* __restrict__ c0,
                                              const float* __restrict__ c4, Smem<RB>& S, uint32_t (&masks)[8][4],
                                              int stop = 8, long long* ts = nullptr) {
@@ -399,7 +400,7 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) wpre[ob] = w0[ob * 64];
   }
-  stage_bias<RB>(D, c0, c4, S);
+  if (!STAGED) stage_bias<RB>(D, c0, c4, S);
   // layer-0 input rows: xyz + zero padding to K=8
 #pragma unroll
   for (int i = tid; i < 8 * TILE; i += NTHREADS) X[i] = (i < 3 * TILE) ? S.xyz[i] : 0.f;
