@@ -12,6 +12,7 @@ G9: two view pairs of the multi-view round (loss_multi.py:6-49 via optimize_mult
     and gradients w.r.t. the shape code and the sim(3) parameters.
 G10 (--g10): decode_color + SDFRenderer_color.render with a seed-defined colour decoder (row f4).
 G11 (--g11): decode_sdf differentiated by autograd w.r.t. latent and points.
+G6 (--g6): per-call point counts of the reference's decoder calls during render_depth (live rays per march step).
 The goldens are data (inputs + reference outputs); no reference source is copied.
 """
 import os
@@ -216,7 +217,49 @@ def golden_g11():
     print('g11', {k: float(np.abs(v).max()) for k, v in out.items()}, 'clamped pts', int((np.abs(out['sdf_raw']) > 0.1).sum()))
 
 
+def golden_g6():
+    """G6: structure of the reference's march, recorded by wrapping its decode_sdf (core/utils/decoder_utils.py:53): the
+    number of points of every decoder call of render_depth in call order (= live rays per march step, then the
+    re-evaluation calls), plus init_zdepth / valid_mask of the unit-sphere test, for the three marchers at C1 size."""
+    rh.install_shims()
+    mods = rh.reference_modules()
+    SDFRenderer = mods[0]
+    import core.sdfrenderer.renderer as ref_renderer
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(30, 20, 1.6, 10)
+    out = dict(weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent, K=K, R=R, T=T, H=H, W=W, march_step=20, buffer_size=3)
+    orig = ref_renderer.decode_sdf
+    for marcher in ('trivial', 'recursive', 'pyramid_recursive'):
+        sizes = []
+
+        def counting(decoder, latent_vector, points, *a, **k):
+            sizes.append(int(points.shape[0]))
+            return orig(decoder, latent_vector, points, *a, **k)
+        ref_renderer.decode_sdf = counting
+        try:
+            r = SDFRenderer(dec, K, img_hw=(H, W), march_step=20, buffer_size=3, use_gpu=False)
+            with torch.no_grad():
+                z, m, q = r.render_depth(torch.from_numpy(latent), torch.from_numpy(R), torch.from_numpy(T), ray_marching_type=marcher, no_grad=True)
+                cam_pos = r.get_camera_location(torch.from_numpy(R), torch.from_numpy(T))
+                cam_rays = r.get_camera_rays(torch.from_numpy(R))
+                init_z, valid = r.get_intersections_with_unit_spheres(cam_pos, cam_rays)
+        finally:
+            ref_renderer.decode_sdf = orig
+        out['calls_' + marcher] = np.array(sizes, np.int64)
+        out['valid_final_' + marcher] = m.numpy()
+        print('g6', marcher, sizes)
+    out['init_zdepth'] = init_z.numpy()
+    out['in_sphere'] = valid.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g6_march_structure.npz'), **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--g6']:
+        golden_g6()
+        sys.exit(0)
     if sys.argv[1:2] == ['--g11']:
         golden_g11()
         sys.exit(0)

@@ -806,8 +806,9 @@ def test_cluster_tiles_bit_identical_to_single_workgroup_tiles(fixture_decoder):
         import ctypes as C
         p = binding.ptr
         lat = torch.from_numpy(latent).cuda().reshape(-1)
-        eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(torch.from_numpy(R).cuda().reshape(-1)),
-                                                   p(torch.from_numpy(T).cuda()), p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(ws), ws.numel(),
+        Rt_, Tt_ = torch.from_numpy(R).cuda().reshape(-1), torch.from_numpy(T).cuda()      # kept alive across the call
+        eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(Rt_),
+                                                   p(Tt_), p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(ws), ws.numel(),
                                                    eng.ctx.stream()))
         st = eng.ctx.render_stats(cfg, ws)
         assert st['cluster_timeouts'] == 0 and st['num_valid'] > 300
@@ -1054,3 +1055,29 @@ def test_forward_is_graph_capturable(engine, fixture_decoder):
         for a, b in zip(o, want):
             assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
     assert want0[1].sum() > 50 and (want0[3] != want1[3]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('marcher', ['trivial', 'recursive', 'pyramid_recursive'])
+def test_march_structure_matches_reference_golden(engine, marcher):
+    """G6: the number of decoder evaluations the march executes (sum of the live-ray counts of all steps) and the number of
+    rays that hit the unit sphere, against the reference's own decoder-call sizes."""
+    import ctypes as C
+    import torch
+    from distr import binding
+    g = dict(np.load(os.path.join(GOLDEN, 'g6_march_structure.npz')))
+    H, W = int(g['H']), int(g['W'])
+    cfg = binding.make_cfg((H, W), g['K'], march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), marcher=marcher, want_normal=False)
+    cfg.save_for_backward = 0
+    fwd, _ = engine.ctx.workspace_bytes(cfg)
+    ws = torch.empty(fwd, dtype=torch.uint8, device='cuda')
+    p = binding.ptr
+    o = [torch.empty(H * W, device='cuda'), torch.empty(H * W, dtype=torch.uint8, device='cuda'), torch.empty(H * W, device='cuda')]
+    lat, Rt, Tt = (torch.from_numpy(g[k]).cuda().reshape(-1) for k in ('latent', 'R', 'T'))      # keep the inputs alive across the call
+    engine.ctx.check(engine.ctx.L.distr_render_forward(engine.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt),
+                                                      p(o[0]), p(o[1]), p(o[2]), None, None, p(ws), ws.numel(), engine.ctx.stream()))
+    st = engine.ctx.render_stats(cfg, ws)
+    ref = g['calls_' + marcher][:int(g['march_step'])]
+    assert st['num_in_sphere'] == int(g['in_sphere'].sum())
+    assert abs(st['num_point_evals'] - int(ref.sum())) <= 3, (st, int(ref.sum()))
+    assert (o[1].cpu().numpy().astype(bool) != g['valid_final_' + marcher].astype(bool)).sum() <= 1

@@ -196,3 +196,22 @@ def test_color_oracle_vs_reference_golden():
     orc.build()
     rgb = orc.ColorOracle(Wc, bc).decode_color(g['color_code'], g['latent'], g['points'])
     assert np.abs(rgb - g['rgb']).max() <= 2e-6
+
+
+def test_march_structure_vs_reference_golden():
+    """G6: live rays per march step (sizes of the reference's decoder calls, in call order) for the three marchers, the
+    unit-sphere mask and start depths. One ray may stop a step earlier / later (|sdf| within float noise of the threshold)."""
+    g = dict(np.load(os.path.join(GOLDEN, 'g6_march_structure.npz')))
+    Ws, bs, latent = fixture.make_decoder_weights()
+    orc.build()
+    O = orc.Oracle(Ws, bs)
+    for marcher in ('trivial', 'recursive', 'pyramid_recursive'):
+        cfg = orc.make_cfg(int(g['H']), int(g['W']), g['K'], march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), marcher=marcher)
+        st = O.render(cfg, latent, g['R'], g['T'])['state']
+        ref = g['calls_' + marcher][:int(g['march_step'])]
+        got = st.live_counts
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1, (marcher, got, ref)
+        assert st.num_inside == int(g['in_sphere'].sum())
+        iz = st.init_z.reshape(-1)
+        m = g['in_sphere'].reshape(-1).astype(bool)
+        assert np.abs(iz[m] - g['init_zdepth'].reshape(-1)[m]).max() <= 1e-6
