@@ -149,6 +149,31 @@ __device__ __forceinline__ void wave_append(bool flag, int32_t id, int32_t* list
   if (flag) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = id;
 }
 
+// block-level stream compaction for the full-image setup kernels (256 threads): one atomic per BLOCK -- with one per
+// wavefront the 4096 atomics of a 512x512 level on a single counter cost more than the rest of the kernel
+__device__ __forceinline__ void block_append(bool flag, int32_t id, int32_t* list, int32_t* counter) {
+  __shared__ int32_t s_n[4], s_base;
+  const unsigned long long ball = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_n[wave] = __popcll(ball);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    s_base = tot ? atomicAdd(counter, tot) : 0;
+  }
+  __syncthreads();
+  int base = s_base;
+  for (int w = 0; w < wave; ++w) base += s_n[w];
+  if (flag) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = id;
+}
+
+// wave-level max, then one atomicMax per wavefront (skipped when the wave has nothing to contribute)
+__device__ __forceinline__ void wave_atomic_max(uint32_t* dst, uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0 && v != 0u) atomicMax(dst, v);
+}
+
 // ------------------------------------------------------------------------------------------ k_prep
 __global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const float* __restrict__ latent,
                                               const float* __restrict__ R, const float* __restrict__ T) {
@@ -206,6 +231,7 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
   const CamRegs cam = load_cam(C);
   const bool inside = cam.cdist < V.cfg.radius;
   bool valid = false;
+  uint32_t mx = 0u;
   if (i < L.n) {
     float px, py;
     level_center(L, i, px, py);
@@ -225,9 +251,10 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
         }
     }
     L.valid[i] = valid ? 1 : 0;
-    if (!V.band && s.in && !inside) atomicMax(&C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
+    if (!V.band && s.in && !inside) mx = __float_as_uint(s.init_raw);
   }
-  wave_append(valid, i, L.list, &C->cnt_level[lvl]);
+  wave_atomic_max(&C->maxinit_bits[lvl], mx);      // positive floats order like their bit patterns; one atomic per wavefront
+  block_append(valid, i, L.list, &C->cnt_level[lvl]);
 }
 
 // row band: the fill depth of rays that miss the sphere is the maximum over the FULL image's level grid
@@ -235,13 +262,15 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
 __global__ void __launch_bounds__(256) k_maxinit_full(View V, int lvl) {
   const LevelView& L = V.lv[lvl];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= L.full_h * L.w) return;
   const CamRegs cam = load_cam(V.C);
-  if (cam.cdist < V.cfg.radius) return;
-  const float px = L.scale * (float)(i % L.w) + L.off, py = L.scale * (float)(i / L.w) + L.off;
-  const RayGeo g = make_ray(V.cfg.K_inv, cam.R, px, py);
-  const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
-  if (s.in) atomicMax(&V.C->maxinit_bits[lvl], __float_as_uint(s.init_raw));
+  uint32_t mx = 0u;
+  if (i < L.full_h * L.w && !(cam.cdist < V.cfg.radius)) {
+    const float px = L.scale * (float)(i % L.w) + L.off, py = L.scale * (float)(i / L.w) + L.off;
+    const RayGeo g = make_ray(V.cfg.K_inv, cam.R, px, py);
+    const Sph s = intersect(V.cfg.radius, cam.c, cam.cdist, g.d);
+    if (s.in) mx = __float_as_uint(s.init_raw);
+  }
+  wave_atomic_max(&V.C->maxinit_bits[lvl], mx);
 }
 
 // start depth of a coarse level: unit-sphere entry (coarsest) or the parent's last marched depth (renderer.py:766-769)
@@ -397,7 +426,7 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
     V.first_sdf[px] = 1.0f;
     live = (V.cfg.marcher == DISTR_MARCH_TRIVIAL) ? true : ((0.f + init_now) < maxbound);
   }
-  if (V.cfg.marcher != DISTR_MARCH_TRIVIAL) wave_append(live, px, V.live[0], &C->cnt_live[0]);
+  if (V.cfg.marcher != DISTR_MARCH_TRIVIAL) block_append(live, px, V.live[0], &C->cnt_live[0]);
 }
 
 // ------------------------------------------------------------------------------------------ the march kernel
