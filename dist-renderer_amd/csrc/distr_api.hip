@@ -877,6 +877,36 @@ int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void
   return DISTR_OK;
 }
 
+int distr_profile_read_list(distr_ctx* ctx, float* ms_out, int64_t cap, int64_t* n, void* stream) {
+  if (!ctx || !n) return DISTR_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *n = (int64_t)ctx->ev_used;
+  for (size_t i = 0; i < ctx->ev_used && (int64_t)i < cap && ms_out; ++i)
+    HIP_TRY(hipEventElapsedTime(&ms_out[i], ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+  return DISTR_OK;
+}
+
+int distr_get_live_counts(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, int32_t* out, int32_t cap, int32_t* n,
+                          void* stream) {
+  if (!ctx || !ws || !out || !n) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  View V;
+  make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks);
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local std::vector<char> hostbuf;
+  hostbuf.resize(sizeof(Consts));
+  HIP_TRY(hipMemcpyAsync(hostbuf.data(), V.C, sizeof(Consts), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const Consts* C = (const Consts*)hostbuf.data();
+  int k = 0;
+  for (int l = V.nlev - 1; l >= 1; --l)
+    for (int st = 0; st < V.lv[l].steps; ++st) { if (k < cap) out[k] = C->cnt_level[l]; ++k; }
+  for (int t = 0; t < V.fine_steps; ++t) { if (k < cap) out[k] = (cfg->marcher == DISTR_MARCH_TRIVIAL) ? C->cnt_level[0] : C->cnt_live[t]; ++k; }
+  *n = k;
+  return DISTR_OK;
+}
+
 int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64) {
   if (!ctx || !out64) return DISTR_ERR_INVALID_ARG;
   for (auto& r : ctx->xr)

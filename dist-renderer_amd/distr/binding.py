@@ -21,7 +21,8 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
-           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward']
+           'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward',
+           'distr_profile_read_list', 'distr_get_live_counts']
 
 
 class DistrError(RuntimeError):
@@ -127,6 +128,8 @@ def lib():
             L.distr_get_render_stats.argtypes = [vp, C.POINTER(RenderCfg), vp, C.POINTER(RenderStats), vp]
             L.distr_profile_enable.argtypes = [vp, C.c_int]
             L.distr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), vp]
+            L.distr_profile_read_list.argtypes = [vp, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), vp]
+            L.distr_get_live_counts.argtypes = [vp, C.POINTER(RenderCfg), vp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), vp]
             L.distr_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
             L.distr_loss_workspace_bytes.restype = C.c_size_t
             L.distr_single_loss_forward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, u8p, fp, fp, fp, u8p, C.c_float, fp, vp, C.c_size_t, vp]
@@ -232,6 +235,18 @@ class Context(object):
         n, ms = C.c_int64(), C.c_double()
         self.check(self.L.distr_profile_read(self.h, C.byref(n), C.byref(ms), self.stream()))
         return n.value, ms.value
+
+    def profile_read_list(self, cap=8192):
+        """Per-launch kernel ms of the bracketed march launches since the last profile_read (launch order)."""
+        buf, n = (C.c_float * cap)(), C.c_int64()
+        self.check(self.L.distr_profile_read_list(self.h, buf, cap, C.byref(n), self.stream()))
+        return [buf[i] for i in range(min(cap, n.value))]
+
+    def live_counts(self, cfg, ws, cap=4096):
+        """Rays evaluated by every march launch of the forward that used `ws` (launch order)."""
+        buf, n = (C.c_int32 * cap)(), C.c_int32()
+        self.check(self.L.distr_get_live_counts(self.h, C.byref(cfg), C.c_void_p(ws.data_ptr()), buf, cap, C.byref(n), self.stream()))
+        return [buf[i] for i in range(min(cap, n.value))]
 
     def render_stats(self, cfg, ws):
         st = RenderStats()

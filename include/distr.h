@@ -170,6 +170,13 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
                        void* stream);
 int distr_profile_enable(distr_ctx* ctx, int enable);
 int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
+/* Per-launch view of the same brackets (does not reset): ms_out[i] = kernel time of the i-th bracketed march launch since the
+ * last distr_profile_read, in launch order (coarse-level steps first, then the full-resolution steps of each forward). */
+int distr_profile_read_list(distr_ctx* ctx, float* ms_out, int64_t cap, int64_t* n, void* stream);
+/* Rays evaluated by every march launch of the forward that used `ws_dev`, in launch order (the live-ray profile of
+ * ray_marching_recursive, renderer.py:528-567: what the reference learns from torch.nonzero on the host every step). */
+int distr_get_live_counts(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws_dev, int32_t* out, int32_t cap, int32_t* n,
+                          void* stream);
 /* Test aid (DISTR_XCHG_TS=1): 64 wall-clock stamps (100 MHz) of the last cluster-tile launch on `stream`: phase boundaries of
  * cluster 0 / member 0 (csrc/distr_mlp.hpp, DISTR_XTS). */
 int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64);

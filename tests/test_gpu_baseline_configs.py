@@ -1,0 +1,312 @@
+"""GPU parity tests AT BASELINE.json's configurations (C2..C5), not at reduced sizes:
+
+  C2  256x256 / 50 steps, single view          HIP vs the reference's own goldens (G3: crop + whole-image summaries +
+                                               gradients) and HIP vs the CPU oracle on the FULL image
+  C3  512x512 / 50 steps, depth2normal         HIP vs the CPU oracle on the FULL image (the bench workload itself)
+  C4  8 views x 512x512                        the eight bench cameras: HIP vs oracle at 128x128, properties at 512x512,
+                                               and two ranks (gloo, sharing this GPU) whose all-reduced gradients must equal
+                                               the serial HIP gradient over all views
+  C5  4 shapes x 1024x1024 / 100 steps         8-way shard_rows partition through render_band_call: every band bit-identical
+                                               to the same rows of the full render, band gradients sum to the full gradient
+
+Bars: HIP vs oracle = 0 mask flips, depth / zdepth / min-sdf <= 1e-6, gradients <= 1e-4 relative (same IEEE op sequence in
+the forward; only the reduction order of the backward differs). HIP vs reference goldens = north_star's 1e-4.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, PKG
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine(fixture_decoder):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from distr import binding, functions
+    assert os.path.exists(binding.LIB_PATH), 'libdistr.so missing: run __graft_entry__.build()'
+    Ws, bs, _ = fixture_decoder
+    return functions.engine_from_weights(Ws, bs, 0)
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def _bench_camera(view):
+    """The C4 camera circle exactly as bench.py builds it (view 0 = the C3 camera)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from distr import fixture
+    return bench.view_camera(fixture, view)
+
+
+# ------------------------------------------------------------------------------------------------------------------ C2
+@pytest.mark.parametrize('name', ['g3_c2_recursive_d2n.npz', 'g3_c2_pyramid_recursive_d2n.npz'])
+def test_c2_hip_matches_reference_golden(engine, name):
+    """C2 through the HIP path against what the reference itself produced at 256x256/50 (G3): the 32x32 crop pixel by pixel,
+    the whole-image summaries, and the latent / camera gradients (bar = 2x the reference's own noise floor for this config,
+    tests/golden/noise_floor_c2_pyramid_d2n.npz, printed next to the residual)."""
+    g = dict(np.load(os.path.join(GOLDEN, name)))
+    floor = dict(np.load(os.path.join(GOLDEN, 'noise_floor_c2_pyramid_d2n.npz')))
+    H, W = int(g['H']), int(g['W'])
+    a = helpers.hip_render(engine, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']),
+                           march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']),
+                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']))
+    y0, x0 = int(g['crop_y0']), int(g['crop_x0'])
+    sl = (slice(y0, y0 + 32), slice(x0, x0 + 32))
+    m = a['mask'].reshape(H, W).astype(bool)
+    mc, rc = m[sl], g['mask'].astype(bool)
+    assert int((mc != rc).sum()) <= 1
+    both = mc & rc
+    assert np.abs(a['depth'][sl] - g['depth'])[both].max() <= 1e-4
+    assert np.abs(a['zdepth'].reshape(H, W)[sl] - g['zdepth'])[both].max() <= 1e-4
+    assert np.abs(a['min_sdf'].reshape(H, W)[sl] - g['min_abs_query']).max() <= 1e-4
+    nb = ~(mc | rc)
+    assert np.array_equal(a['depth'][sl][nb], g['depth'][nb])            # depth2normal's background convention (0)
+    fx = float(g['K'][0, 0])
+    dn = np.abs(a['normal'][sl] - g['normal'])[both]
+    assert np.percentile(dn, 99) <= max(1e-4, 1e-5 * fx)                 # finite differences amplify depth noise by fx/2
+    # whole-image summaries
+    assert abs(int(m.sum()) - int(g['valid_count'])) <= max(1, int(0.001 * int(g['valid_count'])))
+    assert abs(a['depth'][m].sum(dtype=np.float64) / m.sum() - float(g['sum_depth']) / int(g['valid_count'])) <= 1e-4
+    assert abs(a['min_sdf'].sum(dtype=np.float64) - float(g['sum_q'])) / (H * W) <= 1e-5
+    for k, fk in (('g_latent', 'g_latent_rel'), ('g_R', 'g_R_rel'), ('g_T', 'g_T_rel')):
+        rel = np.abs(a[k].reshape(-1) - g[k].reshape(-1)).max() / np.abs(g[k]).max()
+        fl = float(floor[fk])
+        print('%s %s: residual %.3e, reference noise floor %.3e' % (name, k, rel, fl))
+        assert rel <= 2.0 * fl, (k, rel, fl)
+
+
+@pytest.mark.parametrize('marcher', ['recursive', 'pyramid_recursive'])
+def test_c2_hip_matches_oracle_full_image(engine, cpu_oracle, orc, fixture_decoder, marcher):
+    """C2, every one of the 65 536 pixels: HIP vs oracle, zero flips, depth <= 1e-6."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 256
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(0, 0, 1.6, 0)
+    kw = dict(march_step=50, buffer_size=3, marcher=marcher, use_depth2normal=True)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=1e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0, res
+    assert int(a['mask'].sum()) > 10000
+
+
+# ------------------------------------------------------------------------------------------------------------------ C3
+def test_c3_hip_matches_oracle_full_image(engine, cpu_oracle, orc, fixture_decoder):
+    """C3 = the bench workload (512x512, 50 steps, pyramid_recursive, depth2normal, dense loss): HIP vs oracle on all 262 144
+    pixels, zero flips, depth <= 1e-6, gradients <= 1e-4 relative, and the number of decoder evaluations / gradient samples
+    the two sides executed are identical."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 512
+    K = fixture.make_intrinsic(H, W)
+    R, T = _bench_camera(0)
+    kw = dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=1e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0, res
+    import test_gpu_parity as tg
+    st = engine.ctx.render_stats(a['cfg'], tg._last_ws(engine, a['cfg'], latent, R, T))
+    # the oracle pads finished rays' history rows instead of compacting: it counts the same live evaluations + f(origin)
+    assert abs(int(st['num_point_evals']) - int(b['num_evals'])) <= 3, (st['num_point_evals'], b['num_evals'])
+    assert st['num_valid'] == int(b['mask'].sum()) and st['cluster_timeouts'] == 0
+    print('C3 residuals vs oracle:', res)
+
+
+# ------------------------------------------------------------------------------------------------------------------ C4
+@pytest.mark.parametrize('view', range(8))
+def test_c4_cameras_match_oracle_128(engine, cpu_oracle, orc, fixture_decoder, view):
+    """Each of the eight C4 cameras (azimuth 45 deg * view, elevation 25 deg; bench.view_camera) at 128x128/50: HIP vs oracle."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 128
+    K = fixture.make_intrinsic(H, W)
+    R, T = _bench_camera(view)
+    kw = dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=2e-4, normal_p99=1e-5, max_flip_frac=0.0)
+    assert res['flips'] == 0 and int(a['mask'].sum()) > 1500, res
+
+
+def test_c4_cameras_full_size_properties(engine, fixture_decoder):
+    """The eight C4 views at 512x512/50 (what each of the 8 GPUs renders): reproducible bits, plausible silhouettes, converged
+    surface samples, unit normals, finite gradients; the per-view latent gradients are summed in the order the all-reduce
+    would and compared with one backward() through the sum of the eight losses (the serial form of optimize_multi.py:62-81)."""
+    import torch
+    from distr import binding, fixture, functions
+    _, _, latent = fixture_decoder
+    H = W = 512
+    K = fixture.make_intrinsic(H, W)
+    kw = dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    g_sum = np.zeros((1, 256), np.float64)
+    for v in range(8):
+        R, T = _bench_camera(v)
+        a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+        if v in (0, 7):
+            b = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+            for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
+                assert np.array_equal(a[k], b[k]), (v, k)
+        m = a['mask'].reshape(H, W).astype(bool)
+        assert 0.15 * H * W < m.sum() < 0.40 * H * W, (v, m.sum())
+        assert np.all(np.abs(a['min_sdf'][a['mask'].astype(bool)]) <= 5e-5)
+        assert np.abs(np.linalg.norm(a['normal'][m], axis=-1) - 1).max() < 1e-5
+        d = a['depth'][m]
+        assert d.min() > 0.5 and d.max() < 2.7
+        for k in ('g_latent', 'g_R', 'g_T'):
+            assert np.isfinite(a[k]).all() and np.abs(a[k]).max() > 0
+        g_sum += a['g_latent'].astype(np.float64)
+    # serial form: one backward through the sum of the eight view losses
+    dev = engine.device
+    cfg = binding.make_cfg((H, W), K, **kw)
+    lat = torch.from_numpy(latent).to(dev).requires_grad_(True)
+    wd, wq, wn = (torch.from_numpy(x).to(dev) for x in helpers.loss_weights(H, W, 5))
+    total = 0
+    for v in range(8):
+        R, T = _bench_camera(v)
+        z, mk, q, dep, nrm = functions.render_call(engine, cfg, lat, torch.from_numpy(R).to(dev), torch.from_numpy(T).to(dev))
+        total = total + (dep * wd)[mk.reshape(H, W).bool()].sum() + (q.reshape(H, W) * wq).sum() + (nrm * wn).sum()
+    total.backward()
+    rel = np.abs(lat.grad.double().cpu().numpy() - g_sum).max() / np.abs(g_sum).max()
+    assert rel <= 2e-5, rel
+
+
+def _two_rank_worker(rank, world, port, q):
+    for p_ in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      DISTR_DIST_BACKEND='gloo')
+    import torch
+    from distr import fixture, functions, parallel
+    import helpers as hp
+    r, w, local = parallel.init_from_env()            # gloo: two RCCL ranks cannot share one device
+    assert (r, w) == (rank, world)
+    Ws, bs, latent = fixture.make_decoder_weights()
+    eng = functions.engine_from_weights(Ws, bs, local)
+    H = W = 128
+    K = fixture.make_intrinsic(H, W)
+    kw = dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    import bench
+    g_lat = torch.zeros(1, 256, dtype=torch.float32, device=eng.device)
+    g_cam = torch.zeros(8, 12, dtype=torch.float32, device=eng.device)     # per-view camera gradients (zero for other ranks' views)
+    loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+    for v in parallel.shard_views(8, rank, world):
+        R, T = bench.view_camera(fixture, v)
+        a = hp.hip_render(eng, H, W, K, R, T, latent, **kw)
+        g_lat += torch.from_numpy(a['g_latent']).to(eng.device)
+        g_cam[v, :9] = torch.from_numpy(a['g_R'].reshape(-1)).to(eng.device)
+        g_cam[v, 9:] = torch.from_numpy(a['g_T'].reshape(-1)).to(eng.device)
+        loss += a['loss']
+    parallel.allreduce_packed([g_lat, g_cam, loss])                       # ONE packed all-reduce: [g_latent | g_cam | loss]
+    parallel.barrier()
+    q.put((rank, g_lat.cpu().numpy(), g_cam.cpu().numpy(), float(loss)))
+    torch.distributed.destroy_process_group()
+
+
+def test_c4_two_ranks_gradient_sum_equals_serial(engine, fixture_decoder):
+    """The HIP path and the collective TOGETHER (two ranks time-sharing this GPU, gloo): rank r renders views r, r+2, ... of
+    the eight C4 cameras through libdistr, one packed all-reduce, and every rank must end up with the gradient (latent, all
+    eight cameras, loss) that a single process gets by rendering the eight views itself: <= 2e-5 relative."""
+    import torch.multiprocessing as mp
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H = W = 128
+    K = fixture.make_intrinsic(H, W)
+    kw = dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    g_lat = np.zeros((1, 256), np.float64)
+    g_cam = np.zeros((8, 12), np.float64)
+    loss = 0.0
+    for v in range(8):
+        R, T = _bench_camera(v)
+        a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+        g_lat += a['g_latent']
+        g_cam[v, :9] = a['g_R'].reshape(-1)
+        g_cam[v, 9:] = a['g_T'].reshape(-1)
+        loss += a['loss']
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    for rank, gl, gc, ls in res:
+        assert np.abs(gl - g_lat).max() <= 2e-5 * np.abs(g_lat).max(), rank
+        assert np.abs(gc - g_cam).max() <= 2e-5 * np.abs(g_cam).max(), rank
+        assert abs(ls - loss) <= 2e-5 * abs(loss), rank
+
+
+# ------------------------------------------------------------------------------------------------------------------ C5
+def test_c5_four_shapes_row_bands_full_size(engine, fixture_decoder):
+    """C5 at its full size: 4 shapes (latent seeds 1234..1237) x 1024x1024 x 100 steps, cut 8 ways by shard_rows exactly as
+    bench.py --workload c5 --gpus 8 does. Every band (rendered on its own through render_band_call, as its rank would) is
+    bit-identical to the same rows of the full render of that shape, the pieces tile every image exactly once, and the bands'
+    latent / camera gradients sum to the full render's (<= 2e-5 relative: summation order only)."""
+    import torch
+    from distr import binding, fixture, functions, parallel
+    _, _, latent0 = fixture_decoder
+    H = W = 1024
+    n_shapes, world = 4, 8
+    K = fixture.make_intrinsic(H, W)
+    R, T = _bench_camera(0)
+    dev = engine.device
+    cfg = binding.make_cfg((H, W), K, march_step=100, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+    lats = [latent0] + [fixture.make_latent(1234 + i) for i in range(1, n_shapes)]
+    wd, wq, wn = (torch.from_numpy(a).to(dev) for a in helpers.loss_weights(H, W, 5))
+
+    def run(shape, r0, r1):
+        lat = torch.from_numpy(lats[shape]).to(dev).requires_grad_(True)
+        Rt = torch.from_numpy(R).to(dev).requires_grad_(True)
+        Tt = torch.from_numpy(T).to(dev).requires_grad_(True)
+        if (r0, r1) == (0, H):
+            z, m, q, d, n = functions.render_call(engine, cfg, lat, Rt, Tt)
+        else:
+            z, m, q, d, n = functions.render_band_call(engine, cfg, lat, Rt, Tt, r0, r1)
+        rows = r1 - r0
+        mb = m.reshape(rows, W).bool()
+        L = torch.where(mb, d * wd[r0:r1], torch.zeros_like(d)).sum() + (q.reshape(rows, W) * wq[r0:r1]).sum() + (n * wn[r0:r1]).sum()
+        L.backward()
+        out = [t.detach().reshape(rows, -1).cpu().numpy() for t in (z, m, q, d, n)]
+        return out, [g.grad.double().cpu().numpy() for g in (lat, Rt, Tt)]
+
+    pieces = {s: [] for s in range(n_shapes)}
+    cover = np.zeros((n_shapes, H), np.int32)
+    for rank in range(world):
+        items = parallel.shard_rows(n_shapes, H, rank, world)
+        assert len(items) == 1 and items[0][2] - items[0][1] == H // 2          # 8 ranks, 4 images: half an image each
+        for (s, r0, r1) in items:
+            pieces[s].append((r0, r1))
+            cover[s, r0:r1] += 1
+    assert (cover == 1).all()
+    for s in range(n_shapes):
+        full, gfull = run(s, 0, H)
+        valid = int(full[1].sum())
+        assert 0.10 * H * W < valid < 0.45 * H * W, (s, valid)
+        parts = [run(s, r0, r1) for (r0, r1) in sorted(pieces[s])]
+        for k, name in enumerate(('zdepth', 'mask', 'min_sdf', 'depth', 'normal')):
+            cat = np.concatenate([p_[0][k] for p_ in parts], axis=0)
+            assert cat.shape == full[k].shape
+            assert cat.tobytes() == full[k].tobytes(), (s, name)
+        for k, name in enumerate(('g_latent', 'g_R', 'g_T')):
+            tot = sum(p_[1][k] for p_ in parts)
+            rel = np.abs(tot - gfull[k]).max() / np.abs(gfull[k]).max()
+            assert rel < 2e-5, (s, name, rel)
+        del full, parts
+        torch.cuda.empty_cache()
