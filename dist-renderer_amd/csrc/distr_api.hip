@@ -398,6 +398,9 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   D.b8 = b[8][0];
   D.b8x[0] = nout > 1 ? b[8][1] : 0.f; D.b8x[1] = nout > 2 ? b[8][2] : 0.f;
   D.nlat = nlat;
+  if (getenv("DISTR_DEBUG_ALIAS_WEIGHTS")) {   // timing experiment only (wrong values): every 512x512 layer streams lin1's fragments
+    for (int l : {2, 5, 6, 7}) { D.Wf[l] = D.Wf[1]; D.Wb[l] = D.Wb[1]; }
+  }
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
   return DISTR_OK;
 }

@@ -24,14 +24,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "distr_dense_asm.hpp"
+
 namespace distr {
 
 constexpr int HID = 512;
 constexpr int LAT = 256;
 constexpr int NTHREADS = 256;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// (f32x16 / f32x4 / rsrc_t: distr_dense_asm.hpp)
+
+// LDS byte offset of a __shared__ object (low half of its flat address) -- the address operand of the hand-written ds_* ops
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)p; }
+// raw buffer descriptor over a fragment stream (stride 0, 1 GiB range, gfx9 dword-3 flags): lets the dense loop walk the
+// stream with an SGPR offset instead of 64-bit VGPR address arithmetic
+__device__ __forceinline__ rsrc_t weight_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x40000000, 0x00020000);
+}
 
 struct DecoderDev {
   const float* Wf[8];   // forward A-fragments of lin0..lin7 (lin0: K padded to 8; lin3: O padded to 256; lin4: K=256)
@@ -56,10 +65,10 @@ struct DecoderDev {
 // per tile, so that a layer does not begin with an exposed L2 round trip for its biases (the 32-ray tile has no LDS
 // left for this: two of them share a CU).
 template <int RB> struct SmemBias { };
-template <> struct SmemBias<2> { float bias[8 * HID]; };
+template <> struct alignas(16) SmemBias<2> { float bias[8 * HID]; };
 
 template <int RB>
-struct Smem : SmemBias<RB> {
+struct alignas(16) Smem : SmemBias<RB> {
   static constexpr int TILE = 32 * RB;
   float X[HID * TILE];   // activations / deltas [feature][ray]
   float xyz[4 * TILE];   // rows 0..2: sample points of the tile
@@ -416,6 +425,78 @@ __device__ __forceinline__ float mlp_forward(const DecoderDev& D, const float* _
     DISTR_TS(2);
   }
   if (DEBUG_STOP && stop == 0) return 0.f;
+  if constexpr (RB == 2) {
+    // 64-ray tile: layers 1..7 on the hand-scheduled loop (distr_dense_asm.hpp). Every layer's accumulators start from the
+    // LDS copy of its bias (srcC of the first MFMAs); the next layer's first weight group travels in `wpre` across the
+    // write-back; S.part..S.aux (4 KiB, idle during the layers) is the scratch of the tuple -> register move.
+    const uint32_t xaddr = lds_off(X) + (uint32_t)h * (TILE * 4) + (uint32_t)(lane & 31) * 4;
+    const uint32_t voff = (uint32_t)lane * 16;
+    const uint32_t scratch = lds_off(S.part) + (uint32_t)wave * 1024 + (uint32_t)lane * 16;
+    const uint32_t bias4 = lds_off(S.bias) + (uint32_t)wave * 512 + (uint32_t)h * 16;   // + l * 2048: rows wave*128 .. of layer l
+    const uint32_t bias2 = lds_off(S.bias) + 3 * 2048 + (uint32_t)wave * 256 + (uint32_t)h * 16;   // lin3: rows wave*64 ..
+    const uint32_t soff4 = (uint32_t)wave * 4096, soff2 = (uint32_t)wave * 2048;
+    rsrc_t rs[8];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) rs[l] = weight_rsrc(D.Wf[l]);
+    {
+      f32x16 acc[4][2];
+      dense_asm_k512_n4_o4_bias(acc, wpre, xaddr, voff, rs[1], rs[2], soff4, soff4, bias4 + 1 * 2048, scratch);
+      DISTR_TS(3);
+      __syncthreads();
+      writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[1]);
+      __syncthreads();
+      DISTR_TS(4);
+      if (DEBUG_STOP && stop == 1) return 0.f;
+    }
+    {
+      f32x16 acc[4][2];
+      dense_asm_k512_n4_o2_bias(acc, wpre, xaddr, voff, rs[2], rs[3], soff4, soff2, bias4 + 2 * 2048, scratch);
+      DISTR_TS(5);
+      __syncthreads();
+      writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[2]);
+      __syncthreads();
+      DISTR_TS(6);
+      if (DEBUG_STOP && stop == 2) return 0.f;
+    }
+    {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
+      f32x16 acc[2][2];
+      dense_asm_k512_n2_o4_bias(acc, wpre, xaddr, voff, rs[3], rs[4], soff2, soff4, bias2, scratch);
+      DISTR_TS(7);
+      __syncthreads();
+      masks[3][2] = 0; masks[3][3] = 0;
+      writeback<2, RB, true, false, KEEP>(X, acc, wave * 64, lane, masks[3]);
+      __syncthreads();
+      if (tid < 3 * TILE) X[253 * TILE + tid] = S.xyz[tid];
+      __syncthreads();
+      DISTR_TS(8);
+      if (DEBUG_STOP && stop == 3) return 0.f;
+    }
+    {  // lin4: [x3(253) | xyz(3)] -> 512, latent part folded into c4
+      f32x16 acc[4][2];
+      dense_asm_k256_n4_o4_bias(acc, wpre, xaddr, voff, rs[4], rs[5], soff4, soff4, bias4 + 4 * 2048, scratch);
+      DISTR_TS(9);
+      __syncthreads();
+      writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[4]);
+      __syncthreads();
+      DISTR_TS(10);
+      if (DEBUG_STOP && stop == 4) return 0.f;
+    }
+#pragma unroll
+    for (int l = 5; l <= 7; ++l) {
+      f32x16 acc[4][2];
+      if (l < 7) dense_asm_k512_n4_o4_bias(acc, wpre, xaddr, voff, rs[l], rs[l < 7 ? l + 1 : l], soff4, soff4, bias4 + l * 2048, scratch);
+      else dense_asm_k512_n4_o0_bias(acc, wpre, xaddr, voff, rs[l], rs[l], soff4, soff4, bias4 + l * 2048, scratch);
+      DISTR_TS(2 * l + 1);
+      __syncthreads();
+      writeback<4, RB, true, false, KEEP>(X, acc, wave * 128, lane, masks[l]);
+      __syncthreads();
+      DISTR_TS(2 * l + 2);
+      if (DEBUG_STOP && stop == l) return 0.f;
+    }
+    const float pre_asm = lin8_row<RB>(D.w8, D.b8, S);
+    DISTR_TS(17);
+    return pre_asm;
+  }
   {
     f32x16 acc[4][RB];
     acc_init<4, RB>(acc, layer_init<RB>(D, c0, c4, S, 1), wave * 128, h);
@@ -527,6 +608,62 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, u
     }
   }
   __syncthreads();
+  if constexpr (RB == 2) {
+    // 64-sample tile: the dX chain on the hand-scheduled loop (distr_dense_asm.hpp), accumulators starting from zero, the next
+    // layer's first transposed weight group travelling in `t` across each write-back; scratch = S.xyz..S.part (4 KiB, idle here)
+    const uint32_t xaddr = lds_off(X) + (uint32_t)h * (TILE * 4) + (uint32_t)j * 4;
+    const uint32_t voff = (uint32_t)lane * 16;
+    const uint32_t scratch = lds_off(S.xyz) + (uint32_t)wave * 1024 + (uint32_t)lane * 16;
+    const uint32_t soff4 = (uint32_t)wave * 4096, soff2 = (uint32_t)wave * 2048;
+    rsrc_t rs[8];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) rs[l] = weight_rsrc(D.Wb[l]);
+    f32x4 t[4];
+    {
+      const f32x4* w7 = reinterpret_cast<const f32x4*>(D.Wb[7]) + (size_t)wave * 4 * 64 + lane;
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) t[ob] = w7[ob * 64];
+    }
+#pragma unroll
+    for (int l = 7; l >= 5; --l) {  // delta_l (512) -> delta_{l-1} (512)
+      f32x16 acc[4][2];
+      if (l > 5) dense_asm_k512_n4_o4_zero(acc, t, xaddr, voff, rs[l], rs[l > 5 ? l - 1 : l], soff4, soff4, 0u, scratch);
+      else dense_asm_k512_n4_o2_zero(acc, t, xaddr, voff, rs[5], rs[4], soff4, soff2, 0u, scratch);
+      __syncthreads();
+      writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+      __syncthreads();
+    }
+    if (sd4) row_sums<RB>(X, sd4, tid);  // X = delta4
+    {  // lin4^T: delta4 (512) -> [delta3 (253) | d xyz (3)]
+      f32x16 acc[2][2];
+      dense_asm_k512_n2_o4_zero(acc, t, xaddr, voff, rs[4], rs[3], soff2, soff4, 0u, scratch);
+      __syncthreads();
+      writeback<2, RB, false, true>(X, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
+      if (wave == 3 && h == 1) {
+#pragma unroll
+        for (int r = 13; r < 16; ++r)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) S.aux[(1 + r - 13) * TILE + 32 * rb + j] = acc[1][rb][r];
+      }
+      __syncthreads();
+    }
+    {  // lin3^T: delta3 (256 rows, 253 real) -> delta2 (512)
+      f32x16 acc[4][2];
+      dense_asm_k256_n4_o4_zero(acc, t, xaddr, voff, rs[3], rs[2], soff4, soff4, 0u, scratch);
+      __syncthreads();
+      writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[2]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+      f32x16 acc[4][2];
+      if (l > 1) dense_asm_k512_n4_o4_zero(acc, t, xaddr, voff, rs[2], rs[1], soff4, soff4, 0u, scratch);
+      else dense_asm_k512_n4_o0_zero(acc, t, xaddr, voff, rs[1], rs[1], soff4, soff4, 0u, scratch);
+      __syncthreads();
+      writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
+      __syncthreads();
+    }
+  } else {
 #pragma unroll
   for (int l = 7; l >= 5; --l) {  // delta_l (512) -> delta_{l-1} (512)
     f32x16 acc[4][RB];
@@ -567,6 +704,7 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, u
     __syncthreads();
     writeback<4, RB, false, true>(X, acc, wave * 128, lane, masks[l - 1]);
     __syncthreads();
+  }
   }
   if (sd0) row_sums<RB>(X, sd0, tid);  // X = delta0
   // d xyz through lin0's xyz columns: 3 x four 128-long chains per ray

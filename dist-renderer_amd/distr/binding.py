@@ -81,7 +81,7 @@ class RenderStats(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
-    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_losses.hpp')]
+    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
