@@ -263,7 +263,7 @@ def main():
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
                        'decoder_evals_per_step_rank0': stats['num_point_evals'],
                        'march_launches_per_step_rank0': stats['num_march_launches'],
-                       'forward_ms_one_item': fwd_ms, 'backward_ms_one_item': bwd_ms, 'cluster_timeouts': stats['cluster_timeouts'],
+                       'forward_ms_one_item': fwd_ms, 'backward_ms_one_item': bwd_ms, 'cluster_fallbacks': stats['cluster_fallbacks'],
                        'decoder_evals_per_s_march': evals / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,

@@ -24,7 +24,7 @@ struct Consts {
   float latent[LAT];
   float R[9], T[3], c[3];
   float cdist;
-  int32_t xchg_err;       // a cluster barrier timed out (should never happen; results of that render are invalid)
+  int32_t xchg_err;       // cluster tiles that fell back to the single-workgroup path (not assembled in time / barrier timeout); results stay exact
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
   uint32_t maxinit_bits[3];
   int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
@@ -666,11 +666,19 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
   float pre;
+  bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
   if (MODE != MODE_EVAL && cl > 1) {
-    int* err = &V.C->xchg_err;
-    if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member, err);
-    else pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member, err);
+    if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+    else pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
     if (member != 0) return;            // only the lead member runs the epilogue
+    clustered = S.fail == 0;
+    if (!clustered) {
+      // the cluster did not assemble (compute units held by other streams / ranks) or a barrier timed out: the lead member
+      // evaluates the tile on its own -- identical values; counted in the render stats (cluster_fallbacks)
+      if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
+      __syncthreads();
+      pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+    }
   } else {
     pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
   }
@@ -713,7 +721,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
-    if (cl > 1) {   // the lead member assembled the rays' mask blocks in LDS (masks_from_lds)
+    if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (masks_from_lds)
       const int j = tid >> 4, q = tid & 15;
       const long long b = S.mb[j];
       if (b >= 0) {

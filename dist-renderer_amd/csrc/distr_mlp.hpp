@@ -923,12 +923,23 @@ struct Xchg {
   uint32_t* flags;     // [256 clusters][16 barriers][8 members]
   uint32_t epoch;      // unique per launch (per region)
   int32_t max_cl;      // largest cluster size to use (8 or 4)
+  int32_t test_abort;  // tests (DISTR_CLUSTER_TEST_ABORT=1): every lead member behaves as if its cluster had not assembled
   long long* ts;       // debug (DISTR_XCHG_TS=1): wall-clock stamps of cluster 0 / member 0 at phase boundaries, else null
 };
+// Wall-clock budgets (100 MHz ticks) of the cluster protocol. Co-residency of a cluster's workgroups is NOT guaranteed by the
+// hardware (other streams / ranks may hold the compute units), so a cluster first ASSEMBLES: every member posts an arrival
+// word, the lead member waits at most CL_T_ARRIVE (after its own lin0) for all of them and then publishes `go` or `abort`. After `go` all members
+// are resident and the per-layer barriers can only be delayed by compute skew; they are still bounded (CL_T_BARRIER). Whenever
+// the lead member gives up -- at assembly or at any barrier -- it evaluates the tile on its own (mlp_forward16: same values,
+// bit for bit), so a scheduling surprise costs time, never correctness. Members that give up just leave.
+constexpr long long CL_T_ARRIVE = 30 * 100;      // 30 us (members of a cluster are dispatched within ~1 us of each other when CUs are free)
+constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for the lead's verdict
+constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per layer barrier
 #define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) xc.ts[(i)] = (long long)wall_clock64(); } while (0)
 
 struct Smem16CL : Smem16 {
   uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
+  int32_t fail;           // != 0: this member gave up on the cluster (assembly or barrier timed out / aborted)
 };
 
 // Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
@@ -954,17 +965,53 @@ __device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, f32x
   }
 }
 
+// slot layout of a cluster's flag words ([16][8] uint32): slot 0 = arrival words, slots 1..7 = the layers' barriers,
+// slot 8 = { go, abort } published by the lead member
 template <int CL>
-__device__ __forceinline__ void cl_barrier(uint32_t* flags /*this cluster: [16][8]*/, int j, int member, uint32_t epoch, int tid, int* err) {
+__device__ __forceinline__ void cl_barrier(uint32_t* flags /*this cluster: [16][8]*/, int j, int member, uint32_t epoch, int tid, int32_t* fail /*LDS*/) {
   // precondition: every wave has drained its global stores (s_waitcnt 0) and passed a __syncthreads()
   if (tid == 0) __hip_atomic_store(flags + j * 8 + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < 64) {
-    int spins = 0;
+    const long long t0 = (long long)wall_clock64();
     for (;;) {
       const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + j * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__ballot(v != epoch) == 0ull) break;
-      if (++spins > (1 << 21)) { if (tid == 0) *err = 1; break; }
+      if ((long long)wall_clock64() - t0 > CL_T_BARRIER) { if (tid == 0) *fail = 1; break; }
       __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+// Assembly of a cluster (see CL_T_*). Returns with *fail set (all threads see it after the barrier) when this member must not
+// take part: the lead then evaluates the tile alone, the others leave.
+template <int CL>
+__device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int test_abort) {
+  if (tid < 64) {
+    const long long t0 = (long long)wall_clock64();
+    if (member == 0) {
+      bool ok = false;
+      for (;;) {
+        const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__ballot(v != epoch) == 0ull) { ok = !test_abort; break; }
+        if ((long long)wall_clock64() - t0 > CL_T_ARRIVE) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (tid == 0) {
+        __hip_atomic_store(flags + 8 * 8 + (ok ? 0 : 1), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) *fail = 1;
+      }
+    } else {
+      for (;;) {
+        const uint32_t v = (tid < 2) ? __hip_atomic_load(flags + 8 * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned long long hit = __ballot(v == epoch);
+        if (hit & 1ull) break;                                  // go
+        if ((hit & 2ull) || (long long)wall_clock64() - t0 > CL_T_GO) {   // abort, or no verdict: withdraw the arrival word and leave
+          if (tid == 0) { *fail = 1; __hip_atomic_store(flags + member, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
   }
   __syncthreads();
@@ -976,7 +1023,7 @@ __device__ __forceinline__ void cl_barrier(uint32_t* flags /*this cluster: [16][
 template <int K, int O, int CL, int START, int KN, int ON>
 __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const float* __restrict__ init, const float* __restrict__ WfNext,
                                          f32x4 (&w)[2][16], Smem16CL& S, const Xchg& xc, float* xbase, uint32_t* flags, int layer,
-                                         int member, int* err) {
+                                         int member) {
   using Ge = ClGeom<K, O, CL>;
   constexpr int RBT = Ge::RBT, PER = Ge::PER, NBL = Ge::NBL, ACT = Ge::ACT, G = Ge::G, NCH = Ge::NCH, NG = Ge::NG;
   const int tid = threadIdx.x;
@@ -1041,7 +1088,8 @@ __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const flo
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   DISTR_XTS(4 * layer + 1);
-  cl_barrier<CL>(flags, layer, member, xc.epoch, tid, err);
+  cl_barrier<CL>(flags, layer, member, xc.epoch, tid, &S.fail);
+  if (S.fail) return;                      // (uniform: written before the barrier's __syncthreads)
   DISTR_XTS(4 * layer + 2);
   // other members' slices: float4 index i over the row blocks not owned by this member
   constexpr int OTHER = (RBT - PER) * 64;
@@ -1079,11 +1127,12 @@ __device__ __forceinline__ void masks_from_lds(Smem16CL& S, int layer, int rows,
 }
 
 // Cluster forward. Every member returns after its last contribution; member 0 returns the pre-tanh value (ray = tid & 15)
-// and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0.
+// and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0. On return S.fail != 0 (uniform over the
+// workgroup) means this member gave up (cluster not assembled in time / a barrier timed out): the lead member's caller then
+// evaluates the tile with mlp_forward16 (S.xyz is untouched), the other members simply leave.
 template <int CL, bool KEEP>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
-                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member,
-                                                  int* err) {
+                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -1095,6 +1144,10 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   const bool lead = (member == 0);
   f32x4 w[2][16];
   DISTR_XTS(0);
+  if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
+    S.fail = 0;
+    __hip_atomic_store(flags + member, xc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   cl_load_chunk<512, 512, CL>(D16.Wf[1], w[0], 0, member, wave, lane);      // lin1's first weights travel while lin0 runs
   X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;
   __syncthreads();
@@ -1108,25 +1161,34 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     if (KEEP && lead) masks_from_lds(S, 0, 512, tid);
   }
   DISTR_XTS(1);
+  cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, xc.test_abort);
+  if (S.fail) return 0.f;
   // buffer parity of every layer's chunk 0 (see layer_cl)
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
   constexpr int S1 = 0, S2 = (S1 + N1) & 1, S3 = (S2 + N1) & 1, S4 = (S3 + N3) & 1, S5 = (S4 + N4) & 1, S6 = (S5 + N1) & 1, S7 = (S6 + N1) & 1;
-  layer_cl<512, 512, CL, S1, 512, 512>(D16.Wf[1], D.bias[1], D16.Wf[2], w, S, xc, xbase, flags, 1, member, err);
+  layer_cl<512, 512, CL, S1, 512, 512>(D16.Wf[1], D.bias[1], D16.Wf[2], w, S, xc, xbase, flags, 1, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 1, 512, tid);
-  layer_cl<512, 512, CL, S2, 512, 256>(D16.Wf[2], D.bias[2], D16.Wf[3], w, S, xc, xbase, flags, 2, member, err);
+  layer_cl<512, 512, CL, S2, 512, 256>(D16.Wf[2], D.bias[2], D16.Wf[3], w, S, xc, xbase, flags, 2, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 2, 512, tid);
-  layer_cl<512, 256, CL, S3, 256, 512>(D16.Wf[3], D.bias[3], D16.Wf[4], w, S, xc, xbase, flags, 3, member, err);
+  layer_cl<512, 256, CL, S3, 256, 512>(D16.Wf[3], D.bias[3], D16.Wf[4], w, S, xc, xbase, flags, 3, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 3, 253, tid, 64);     // rows 253..255 are padding (bias 0 -> relu 0 -> bit 0), as in the other tiles
   __syncthreads();
   if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
   __syncthreads();
-  layer_cl<256, 512, CL, S4, 512, 512>(D16.Wf[4], c4, D16.Wf[5], w, S, xc, xbase, flags, 4, member, err);
+  layer_cl<256, 512, CL, S4, 512, 512>(D16.Wf[4], c4, D16.Wf[5], w, S, xc, xbase, flags, 4, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 4, 512, tid);
-  layer_cl<512, 512, CL, S5, 512, 512>(D16.Wf[5], D.bias[5], D16.Wf[6], w, S, xc, xbase, flags, 5, member, err);
+  layer_cl<512, 512, CL, S5, 512, 512>(D16.Wf[5], D.bias[5], D16.Wf[6], w, S, xc, xbase, flags, 5, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 5, 512, tid);
-  layer_cl<512, 512, CL, S6, 512, 512>(D16.Wf[6], D.bias[6], D16.Wf[7], w, S, xc, xbase, flags, 6, member, err);
+  layer_cl<512, 512, CL, S6, 512, 512>(D16.Wf[6], D.bias[6], D16.Wf[7], w, S, xc, xbase, flags, 6, member);
+  if (S.fail) return 0.f;
   if (KEEP && lead) masks_from_lds(S, 6, 512, tid);
-  layer_cl<512, 512, CL, S7, 0, 0>(D16.Wf[7], D.bias[7], nullptr, w, S, xc, xbase, flags, 7, member, err);
+  layer_cl<512, 512, CL, S7, 0, 0>(D16.Wf[7], D.bias[7], nullptr, w, S, xc, xbase, flags, 7, member);
+  if (S.fail) return 0.f;
   if (!lead) return 0.f;
   if (KEEP) masks_from_lds(S, 7, 512, tid);
   DISTR_XTS(32);

@@ -76,7 +76,7 @@ def make_warp_cfg(img_hw, intrinsic, thres_depth):
 
 class RenderStats(C.Structure):
     _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
-                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_timeouts', C.c_int64)]
+                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64)]
 
 
 def build_library(force=False, verbose=False):

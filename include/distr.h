@@ -91,8 +91,9 @@ typedef struct distr_render_stats {
   int64_t num_point_evals;    /* decoder evaluations executed by the march kernel      */
   int64_t num_valid;          /* final valid pixels                                    */
   int64_t num_grad_samples;   /* (backward) gradient-carrying samples of the last backward on this workspace */
-  int64_t cluster_timeouts;   /* != 0: a cross-workgroup barrier of the cluster tiles timed out -> this render is invalid
-                                 (never observed; the bounded wait exists so that a scheduling surprise cannot hang the GPU) */
+  int64_t cluster_fallbacks;  /* cluster tiles (16 rays split over 8 / 4 compute units) whose workgroups were not co-resident in time
+                                 (compute units held by other streams / ranks) or whose barrier timed out: the tile's lead workgroup
+                                 evaluated it alone instead -- same values bit for bit, only slower. 0 on an otherwise idle GPU. */
 } distr_render_stats;
 
 int distr_create(distr_ctx** out, int hip_device);

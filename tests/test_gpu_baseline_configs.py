@@ -122,7 +122,7 @@ def test_c3_hip_matches_oracle_full_image(engine, cpu_oracle, orc, fixture_decod
     st = engine.ctx.render_stats(a['cfg'], tg._last_ws(engine, a['cfg'], latent, R, T))
     # the oracle pads finished rays' history rows instead of compacting: it counts the same live evaluations + f(origin)
     assert abs(int(st['num_point_evals']) - int(b['num_evals'])) <= 3, (st['num_point_evals'], b['num_evals'])
-    assert st['num_valid'] == int(b['mask'].sum()) and st['cluster_timeouts'] == 0
+    assert st['num_valid'] == int(b['mask'].sum()) and st['cluster_fallbacks'] == 0
     print('C3 residuals vs oracle:', res)
 
 

@@ -811,7 +811,7 @@ def test_cluster_tiles_bit_identical_to_single_workgroup_tiles(fixture_decoder):
                                                    p(Tt_), p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(ws), ws.numel(),
                                                    eng.ctx.stream()))
         st = eng.ctx.render_stats(cfg, ws)
-        assert st['cluster_timeouts'] == 0 and st['num_valid'] > 300
+        assert st['cluster_fallbacks'] == 0 and st['num_valid'] > 300
         outs.append(res)
     for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
         assert outs[0][k].tobytes() == outs[2][k].tobytes(), k
@@ -962,8 +962,8 @@ def test_c_abi_error_paths(engine, fixture_decoder):
 @pytest.mark.gpu
 def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
     """Sixteen small renders (tail steps on cluster tiles) issued round-robin on eight HIP streams through ONE context: every
-    stream has its own exchange region, no barrier times out, and each render is bit-identical to the same render issued
-    alone on the default stream."""
+    stream has its own exchange region, clusters that cannot assemble fall back to their lead workgroup, and each render is
+    bit-identical to the same render issued alone on the default stream."""
     import ctypes as C
     import torch
     from distr import binding, fixture
@@ -1003,7 +1003,51 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
         for a, b in zip(got[i][0], ref[i][0]):
             assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes(), i
         st = engine.ctx.render_stats(cfg, got[i][1])
-        assert st['cluster_timeouts'] == 0 and st['num_in_sphere'] > 0
+        assert st['num_in_sphere'] > 0     # (cluster_fallbacks may be > 0 here: clusters of concurrent launches compete for CUs)
+
+
+@pytest.mark.gpu
+def test_cluster_fallback_is_bit_identical(engine, fixture_decoder):
+    """A cluster whose workgroups do not become co-resident in time is evaluated by its lead workgroup alone. Forced here for
+    EVERY cluster (DISTR_CLUSTER_TEST_ABORT=1 on a second context): outputs and gradients equal the normal run bit for bit and
+    the render stats count the fallbacks."""
+    from distr import fixture, functions
+    Ws, bs, latent = fixture_decoder
+    os.environ['DISTR_CLUSTER_TEST_ABORT'] = '1'
+    try:
+        eng2 = functions.engine_from_weights(Ws, bs, 0)
+    finally:
+        del os.environ['DISTR_CLUSTER_TEST_ABORT']
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(33, 12, 1.6, 0)
+    for marcher, d2n in (('recursive', False), ('pyramid_recursive', True)):
+        kw = dict(march_step=60, buffer_size=3, marcher=marcher, use_depth2normal=d2n)
+        a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+        b = helpers.hip_render(eng2, H, W, K, R, T, latent, **kw)
+        for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
+            assert np.array_equal(a[k], b[k]), (marcher, k)
+        sa = engine.ctx.render_stats(a['cfg'], _last_ws(engine, a['cfg'], latent, R, T))
+        sb = eng2.ctx.render_stats(b['cfg'], _last_ws(eng2, b['cfg'], latent, R, T))
+        assert sa['cluster_fallbacks'] == 0 and sb['cluster_fallbacks'] > 20, (sa, sb)
+        assert sa['num_point_evals'] == sb['num_point_evals']
+
+
+@pytest.mark.gpu
+def test_cluster_tiles_under_oversubscription():
+    """ADVICE r1 (medium) / VERDICT r1 item 2: eight streams, 512x512 dense renders mixed with small tail-dominated renders,
+    GPU_MAX_HW_QUEUES=8, 200 iterations -- clusters that cannot assemble fall back on the device; every one of the 1600 renders
+    is bit-identical to its stand-alone result (tests/gpu_stress_clusters.py)."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='8')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'gpu_stress_clusters.py'), '--iters', '200', '--streams', '8'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    print('oversubscription stress:', j)
+    assert j['mismatching_renders'] == 0 and j['renders'] == 1600
 
 
 @pytest.mark.gpu
