@@ -32,6 +32,8 @@ def compute_all_loss(sdf_renderer, latent_tensor, extrinsic, gt_pack, threshold=
     sil = gt.get('silhouette')
 
     pack = dict(mask_gt=0.0, mask_out=0.0, depth=0.0, normal=0.0)
+    if visualizer is not None:
+        visualizer.reset_data()                     # loss_single.py:27-28: one set of images per call
     engine = getattr(sdf_renderer, '_engine', None)
     if sil is not None and engine is not None and visualizer is None and depth.is_cuda:
         # fused path (row f3): all four terms in two element-wise kernels, no host synchronisation
@@ -53,4 +55,6 @@ def compute_all_loss(sdf_renderer, latent_tensor, extrinsic, gt_pack, threshold=
             value, visualizer = LU.compute_loss_normal(normal, mask, gt['normal'], sil, visualizer=visualizer)
             pack['normal'] = _maybe_detach(value, on['normal'])
     pack['l2reg'] = latent_tensor.pow(2).mean()
+    if visualizer is not None:
+        visualizer.add_loss_from_pack(pack)         # loss_single.py:62-63: the loss curves
     return pack, visualizer

@@ -1,32 +1,84 @@
 """optimize_single_view: the Adam loop over the shape code or the camera (reference:
-core/inv_optimizer/optimize_single.py:35-110), without the visualiser / mesh-evaluation hooks (out of scope).
-`on_iteration(i, loss_pack, loss)` replaces the reference's printing / plotting callbacks."""
+core/inv_optimizer/optimize_single.py:35-110). Same signature and the same hooks: per-iteration printing unless `silent`,
+the Visualizer's loss curves / image dumps when one is passed, and every `test_step` iterations the evaluator's mesh
+extraction + chamfer distance against `points_gt` (those objects are the reference's own CPU tooling; this loop only calls
+them). `on_iteration(i, loss_pack, loss)` is an extra callback for callers that want the numbers without printing.
+"""
+import os
+
 from core.utils.render_utils import get_camera_from_tensor
 
 from .loss_single import compute_all_loss
 
 
+def print_loss_pack(loss_pack, name):
+    """One line with the five loss terms (same content as the reference's core/visualize/visualizer.py:16-20)."""
+    def val(x):
+        return float(x.detach().mean()) if hasattr(x, 'detach') else float(x)
+    print('NAME = [{0}] -- loss_depth: {1:.4f}, loss_mask_gt: {2:.4f}, loss_mask_out: {3:.4f}, loss_normal: {4:.4f}, '
+          'loss_l2reg: {5:.4f}'.format(name, val(loss_pack['depth']), val(loss_pack['mask_gt']), val(loss_pack['mask_out']),
+                                       val(loss_pack['normal']), val(loss_pack['l2reg'])))
+
+
+def _progress(n, silent):
+    if not silent:
+        try:
+            from tqdm import tqdm
+            return tqdm(range(n))
+        except ImportError:
+            pass
+    return range(n)
+
+
 def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, camera_tensor, gt_pack, weight_dict,
                          optimizer_type='shape', num_iters=200, renderer_weights=None, grad_settings=None, points_gt=None,
-                         test_step=50, profile=False, visualizer=None, silent=True, vis_folder=None,
+                         test_step=50, profile=False, visualizer=None, silent=False, vis_folder=None,
                          ray_marching_type='pyramid_recursive', on_iteration=None):
     if optimizer_type not in ('shape', 'camera'):
         raise NotImplementedError
     weights = list(renderer_weights) if renderer_weights else [1.0] * len(sdfrenderer_list)
     if grad_settings is None:
         grad_settings = {'depth': True, 'normal': True, 'silhouette': True}
-    for i in range(num_iters):
+    visualize = (visualizer is not None) and (not silent)
+    if (visualize or (points_gt is not None and not silent)) and vis_folder is not None and not os.path.exists(vis_folder):
+        os.mkdir(vis_folder)
+    for i in _progress(num_iters, silent):
         optimizer.zero_grad()
         extrinsics = camera_tensor if optimizer_type == 'shape' else get_camera_from_tensor(camera_tensor)
         loss = 0
-        for renderer, rw in zip(sdfrenderer_list, weights):
-            pack, _ = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(),
-                                       profile=profile, ray_marching_type=ray_marching_type, grad_settings=dict(grad_settings))
+        for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights)):
+            # only the first (full-resolution) renderer of a multi-scale list feeds the visualiser (optimize_single.py:63-74)
+            pack, vis_out = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(),
+                                             profile=profile, visualizer=visualizer if idx == 0 else None,
+                                             ray_marching_type=ray_marching_type, grad_settings=dict(grad_settings))
+            if idx == 0:
+                visualizer = vis_out
+                if not silent:
+                    print_loss_pack(pack, '{0}/s224'.format(i))
+                if visualize:
+                    visualizer.show_loss_curve(os.path.join(vis_folder, 'vis_loss_curve_{}.png'.format(i)))
+                    visualizer.show_all_data(os.path.join(vis_folder, 'vis_all_data_{}.png'.format(i)))
             loss = loss + rw * (weight_dict['w_depth'] * pack['depth'] + weight_dict['w_normal'] * pack['normal'] +
                                 weight_dict['w_mask_gt'] * pack['mask_gt'] + weight_dict['w_mask_out'] * pack['mask_out'] +
                                 weight_dict['w_l2reg'] * pack['l2reg'])
-            if on_iteration is not None and renderer is sdfrenderer_list[0]:
+            if on_iteration is not None and idx == 0:
                 on_iteration(i, pack, loss)
+        if visualize:
+            visualizer.add_loss(loss)
         loss.backward()
         optimizer.step()
+        # evaluation every test_step iterations (optimize_single.py:87-98): mesh of the current code + chamfer distance
+        if points_gt is not None and (i + 1) % test_step == 0 and not silent and evaluator is not None:
+            fname = os.path.join(vis_folder, 'output_{}.ply'.format(i)) if vis_folder is not None else None
+            points_tmp = evaluator.latent_vec_to_points(shape_code, fname=fname, silent=True)
+            if points_tmp is None:
+                print('The current latent code does not correspond to a valid shape.')
+                dist = 1e11
+            else:
+                dist = evaluator.compute_chamfer_distance(points_gt, points_tmp)
+                print('CHAMFER DISTANCE: {0:.3f}'.format(dist * 1000))
+            if visualize:
+                visualizer.add_chamfer(dist)
+        if visualize:
+            visualizer.dump_all_data(os.path.join(vis_folder, 'vis_all_data_{}.pkl'.format(i)))
     return (shape_code if optimizer_type == 'shape' else camera_tensor), optimizer

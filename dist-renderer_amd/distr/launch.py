@@ -1,0 +1,30 @@
+"""Runs one of the reference's drivers UNCHANGED on this build:
+
+    PYTHONPATH=/path/to/repo/dist-renderer_amd python -m distr.launch /path/to/DIST-Renderer/run_single_shape.py --gpu 0 ...
+
+A script started as `python run_single_shape.py` gets its own directory as sys.path[0], in front of PYTHONPATH, so the
+reference's `core` would win. This launcher starts the script with runpy instead: sys.path[0] is this build's package root, the
+script's directory follows (the drivers append it themselves, run_single_shape.py:5), and `core.*` resolves as described in
+core/_dropin.py -- mirrored modules here, everything else in the reference checkout.
+"""
+import os
+import runpy
+import sys
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit('usage: python -m distr.launch <driver.py> [driver arguments]')
+    script = os.path.abspath(argv[0])
+    pkg_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:] = [pkg_root] + [p for p in sys.path if os.path.abspath(p or os.getcwd()) != pkg_root]
+    script_dir = os.path.dirname(script)
+    if script_dir not in sys.path:
+        sys.path.append(script_dir)
+    sys.argv = [script] + argv[1:]
+    runpy.run_path(script, run_name='__main__')
+
+
+if __name__ == '__main__':
+    main()

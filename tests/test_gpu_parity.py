@@ -373,7 +373,7 @@ def test_adam_single_view_matches_reference_golden(fixture_decoder):
 
     def record(i, pack, loss):
         hist.append([float(pack[k].detach()) for k in ('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg')] + [float(loss.detach())])
-    optimize_single_view([r], None, opt, lat, RT, gt_pack, wd, optimizer_type='shape', num_iters=5, on_iteration=record)
+    optimize_single_view([r], None, opt, lat, RT, gt_pack, wd, optimizer_type='shape', num_iters=5, on_iteration=record, silent=True)
     hist, ref = np.array(hist), g['history']
     print('ours\n', hist, '\nreference\n', ref[:, :6])
     # Observed agreement: 3-6 significant digits. The first iteration is exact to ~1e-7; later ones depend on Adam, whose
