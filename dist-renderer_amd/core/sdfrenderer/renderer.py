@@ -61,8 +61,14 @@ class SDFRenderer(object):
         self.imgmap_init = torch.zeros(h, w, device=tdev)
         self.transform_matrix = torch.from_numpy(self._M_np).float().to(tdev)
         self.calib_map = self.normalize_vectors(self.homo_calib)[2, :]
-        self._engine = functions.get_engine(decoder, self.device)
+        functions.get_engine(decoder, self.device)          # packs + uploads the weights now (fails early on an unsupported decoder)
         self.last_stats = None
+
+    @property
+    def _engine(self):
+        """Packed decoder of this renderer's module; follows later parameter updates of the live module (load_state_dict,
+        fine-tuning steps, .to()) like the reference, which evaluates the module itself on every call."""
+        return functions.get_engine(self.decoder, self.device)
 
     # ---- small accessors (renderer.py:61-68)
     def get_intrinsic(self):

@@ -20,7 +20,11 @@ class SDFRenderer_color(SDFRenderer):
                                                 ray_marching_ratio=ray_marching_ratio, max_sample_dist=max_sample_dist,
                                                 threshold=threshold, use_gpu=use_gpu, is_eval=is_eval)
         self.decoder_color = decoder_color.eval() if is_eval else decoder_color
-        self._color_engine = functions.get_color_engine(self.decoder_color, self.device)
+        functions.get_color_engine(self.decoder_color, self.device)
+
+    @property
+    def _color_engine(self):
+        return functions.get_color_engine(self.decoder_color, self.device)
 
     # reference: renderer_rgb.py:20
     def render_color(self, latent_color, latent, cam_pos, cam_rays, Zdepth, valid_mask, no_grad=False):

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,7 @@ using namespace distr;
 
 struct distr_ctx {
   int device = 0;
+  std::mutex mu;             // entry points serialise per context (exchange regions, event pool, error text); launches stay async
   std::string err;
   float* dec_buf = nullptr;  // one device allocation holding every packed array
   float* dec_buf_color = nullptr;   // same for the colour decoder (distr_set_color_decoder)
@@ -58,6 +60,18 @@ int fail(distr_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) ctx->err = buf;
   return code;
 }
+
+// Every entry point that launches or allocates runs with the CONTEXT's device current and restores the caller's device on exit
+// (a context for a GPU other than the caller's current one must not depend on, or leave behind, a changed current device).
+struct EntryGuard {
+  std::lock_guard<std::mutex> lock;
+  int prev = -1, dev;
+  explicit EntryGuard(distr_ctx* ctx) : lock(ctx->mu), dev(ctx->device) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~EntryGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
@@ -389,8 +403,7 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   memcpy(host.data() + o_w8, W[8], sizeof(float) * nout * HID);
   for (int o = 0; o < HID; ++o) for (int k = 0; k < 3; ++k) host[o_W0x + (size_t)k * HID + o] = W[0][(size_t)o * in0 + nlat + k];
 
-  HIP_TRY(hipSetDevice(ctx->device));
-  if (*dev_buf) { HIP_TRY(hipFree(*dev_buf)); *dev_buf = nullptr; }
+  if (*dev_buf) { HIP_TRY(hipFree(*dev_buf)); *dev_buf = nullptr; }       // (the entry point's guard made ctx->device current)
   HIP_TRY(hipMalloc((void**)dev_buf, host.size() * sizeof(float)));
   HIP_TRY(hipMemcpy(*dev_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   const float* d = *dev_buf;
@@ -409,6 +422,7 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
 
 int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
   if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  EntryGuard guard_(ctx);
   if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
                 "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
@@ -420,6 +434,7 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
 
 int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
   if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  EntryGuard guard_(ctx);
   if (desc->latent_size <= LAT || desc->latent_size > 4096 || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "colour decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: expected the "
                 "DeepSDF 8x512 shape with latent = 256 + color_size and last_dim = 3", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
@@ -432,6 +447,7 @@ int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, cons
 int distr_color_eval(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, float* rgb, void* ws, size_t ws_bytes,
                      void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_color) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_color_decoder has not been called");
   if (n < 0 || !latent_cat || (n > 0 && (!xyz || !rgb)) || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
   if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "colour workspace too small");
@@ -460,6 +476,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
                          float* zdepth, uint8_t* mask, float* min_sdf, float* depth, float* normal, void* ws, size_t ws_bytes,
                          void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
@@ -621,6 +638,7 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
                           const float* g_min_sdf, const float* g_depth, const float* g_normal, float* g_latent, float* g_R,
                           float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
@@ -682,6 +700,7 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
 int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
                         const float* zdepth, const uint8_t* mask, float* normal3xP, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
@@ -716,6 +735,7 @@ size_t distr_mlp_workspace_bytes(int64_t n) { (void)n; return 2 * HID * sizeof(f
 int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float clamp, float* sdf, void* ws,
                    size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   if (n < 0 || (n > 0 && (!xyz || !sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
   if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
@@ -742,6 +762,7 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
 int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float* sdf, float* grad, void* ws,
                    size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   if (n < 0 || (n > 0 && (!xyz || !sdf || !grad)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
   if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
@@ -769,6 +790,7 @@ size_t distr_mlp_backward_workspace_bytes(int64_t n) {
 int distr_mlp_backward(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, const float* g_sdf, float clamp,
                        float* g_xyz, float* g_latent, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   if (n < 0 || (n > 0 && (!xyz || !g_sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
   if (ws_bytes < distr_mlp_backward_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
@@ -800,6 +822,7 @@ int distr_mlp_backward(distr_ctx* ctx, const float* latent, const float* xyz, in
 int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, int layer, float* out, void* ws,
                           size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   if (n <= 0 || !xyz || !out || !latent || !ws || layer < 0 || layer > 7) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
   if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
@@ -818,6 +841,7 @@ int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz,
 int distr_debug_tile_timing(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float* sdf_out, long long* ts_out,
                             void* ws, size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   if (n <= 0 || !xyz || !sdf_out || !ts_out || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
   if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
@@ -835,6 +859,7 @@ int distr_debug_tile_timing(distr_ctx* ctx, const float* latent, const float* xy
 
 int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, distr_render_stats* out, void* stream) {
   if (!ctx || !ws || !out) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  EntryGuard guard_(ctx);
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
   View V;
@@ -862,6 +887,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
 
 int distr_profile_enable(distr_ctx* ctx, int enable) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   ctx->profiling = enable != 0;
   ctx->ev_used = 0;
   return DISTR_OK;
@@ -869,6 +895,7 @@ int distr_profile_enable(distr_ctx* ctx, int enable) {
 
 int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   double tot = 0.0;
   for (size_t i = 0; i < ctx->ev_used; ++i) {
@@ -884,6 +911,7 @@ int distr_profile_read(distr_ctx* ctx, int64_t* launches, double* total_ms, void
 
 int distr_profile_read_list(distr_ctx* ctx, float* ms_out, int64_t cap, int64_t* n, void* stream) {
   if (!ctx || !n) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   *n = (int64_t)ctx->ev_used;
   for (size_t i = 0; i < ctx->ev_used && (int64_t)i < cap && ms_out; ++i)
@@ -894,6 +922,7 @@ int distr_profile_read_list(distr_ctx* ctx, float* ms_out, int64_t cap, int64_t*
 int distr_get_live_counts(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, int32_t* out, int32_t cap, int32_t* n,
                           void* stream) {
   if (!ctx || !ws || !out || !n) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
+  EntryGuard guard_(ctx);
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
   View V;
@@ -914,6 +943,7 @@ int distr_get_live_counts(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
 
 int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64) {
   if (!ctx || !out64) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   for (auto& r : ctx->xr)
     if (r.used && r.stream == (hipStream_t)stream) {
       HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -941,6 +971,7 @@ int distr_single_loss_forward(distr_ctx* ctx, int32_t H, int32_t W, const float*
                               float threshold, float* out8, void* ws, size_t ws_bytes, void* stream) {
   int rc = loss_args(ctx, H, W, ws, ws_bytes);
   if (rc) return rc;
+  EntryGuard guard_(ctx);
   if (!mask || !min_sdf || !gt_mask || !out8 || (gt_depth && !depth) || (gt_normal && !normal))
     return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -958,6 +989,7 @@ int distr_single_loss_backward(distr_ctx* ctx, int32_t H, int32_t W, const float
                                float threshold, const float* out8, const float* g4, float* g_depth, float* g_normal,
                                float* g_min_sdf, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   if (H < 1 || W < 1 || (int64_t)H * W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", H, W);
   if (!mask || !min_sdf || !gt_mask || !out8 || !g4 || (gt_depth && !depth) || (gt_normal && !normal))
     return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
@@ -985,6 +1017,7 @@ int distr_warp_loss_forward(distr_ctx* ctx, const distr_warp_cfg* cfg, const flo
                             const float* R2, const float* T2, float* out3, uint8_t* keep, float* color1, float* color2,
                             void* ws, size_t ws_bytes, void* stream) {
   if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
   if (rc) return rc;
   if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3)
@@ -1004,6 +1037,7 @@ int distr_warp_loss_backward(distr_ctx* ctx, const distr_warp_cfg* cfg, const fl
                              const float* R2, const float* T2, const float* out3, const float* g_loss, float* g_zdepth1,
                              float* g_cam, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
   int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
   if (rc) return rc;
   if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3 || !g_loss || !g_cam)

@@ -13,18 +13,38 @@ import torch
 from . import binding, decoder_pack
 
 
+def _param_key(module):
+    """Identity + in-place version of every parameter: changes after load_state_dict / an optimiser step / .to()."""
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _check_eval(module):
+    if module.training and getattr(module, 'dropout', None) and float(getattr(module, 'dropout_prob', 0.0) or 0.0) > 0.0:
+        raise decoder_pack.UnsupportedDecoder('decoder is in training mode with dropout: the fused kernels evaluate the deterministic '
+                                              '(eval) network only -- call decoder.eval() (SDFRenderer(is_eval=True) does)')
+
+
 class DecoderEngine(object):
     """Packed decoder on one device (distr_ctx). One per (decoder module, device)."""
 
     def __init__(self, decoder, device_index):
         self.ctx = binding.Context(device_index)
         self.device = torch.device('cuda', device_index)
+        self._key = None
         self.refresh(decoder)
 
     def refresh(self, decoder):
-        """(Re)uploads the weights; call after changing decoder parameters (they are frozen in every reference driver:
-        run_single_shape.py:88 optimises the latent only)."""
+        """(Re)uploads the weights."""
         self.ctx.set_decoder(decoder_pack.pack_module(decoder))
+        self._key = _param_key(decoder)
+
+    def sync(self, decoder):
+        """The reference reads the live module on every call (decoder_utils.py:53-74); the packed copy follows it: re-packed
+        when any parameter was modified in place, replaced or moved since the last upload (a few microseconds to check)."""
+        _check_eval(decoder)
+        if _param_key(decoder) != self._key:
+            self.refresh(decoder)
+        return self
 
 
 _engines = weakref.WeakKeyDictionary()
@@ -33,8 +53,9 @@ _engines = weakref.WeakKeyDictionary()
 def get_engine(decoder, device_index):
     per_dec = _engines.setdefault(decoder, {})
     if device_index not in per_dec:
+        _check_eval(decoder)
         per_dec[device_index] = DecoderEngine(decoder, device_index)
-    return per_dec[device_index]
+    return per_dec[device_index].sync(decoder)
 
 
 def engine_from_weights(Ws, bs, device_index=0):
@@ -52,9 +73,25 @@ class ColorEngine(object):
     def __init__(self, decoder_color=None, device_index=0, weights=None):
         self.ctx = binding.Context(device_index)
         self.device = torch.device('cuda', device_index)
-        flat, nlat = decoder_pack.pack_color_module(decoder_color) if weights is None else decoder_pack.flatten_color(*weights)
+        self._key = None
+        if weights is None:
+            self.refresh(decoder_color)
+        else:
+            flat, nlat = decoder_pack.flatten_color(*weights)
+            self.latent_size = nlat
+            self.ctx.set_color_decoder(flat, nlat)
+
+    def refresh(self, decoder_color):
+        flat, nlat = decoder_pack.pack_color_module(decoder_color)
         self.latent_size = nlat
         self.ctx.set_color_decoder(flat, nlat)
+        self._key = _param_key(decoder_color)
+
+    def sync(self, decoder_color):
+        _check_eval(decoder_color)
+        if _param_key(decoder_color) != self._key:
+            self.refresh(decoder_color)
+        return self
 
 
 _color_engines = weakref.WeakKeyDictionary()
@@ -63,8 +100,9 @@ _color_engines = weakref.WeakKeyDictionary()
 def get_color_engine(decoder_color, device_index):
     per_dec = _color_engines.setdefault(decoder_color, {})
     if device_index not in per_dec:
+        _check_eval(decoder_color)
         per_dec[device_index] = ColorEngine(decoder_color, device_index)
-    return per_dec[device_index]
+    return per_dec[device_index].sync(decoder_color)
 
 
 def color_eval(engine, color_code, shape_code, points):
@@ -147,7 +185,8 @@ class RenderFunction(torch.autograd.Function):
 def render_call(engine, cfg, latent, R, T):
     # inference (torch.no_grad() or no input requires grad): skip saving the ReLU masks for the backward pass
     need_bwd = torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (latent, R, T))
-    cfg.save_for_backward = 1 if need_bwd else 0
+    cfg = cfg.clone()          # the autograd node keeps ITS cfg: a caller reusing one cfg object for a later no-grad render must
+    cfg.save_for_backward = 1 if need_bwd else 0      # not flip save_for_backward under a pending backward
     return RenderFunction.apply(latent, R, T, engine, cfg)
 
 

@@ -1007,6 +1007,44 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
 
 
 @pytest.mark.gpu
+def test_engine_follows_live_decoder_parameters(fixture_decoder):
+    """the packed weights follow the live module (load_state_dict / in-place updates after SDFRenderer.__init__), as
+    the reference does by evaluating the module itself; a training-mode decoder with dropout is rejected."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.utils.decoder_utils import decode_sdf
+    from distr import decoder_pack, fixture
+    Ws, bs, latent = fixture_decoder
+    mk = lambda: Decoder(256, [512] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4], weight_norm=True)
+    dec = mk().cuda()
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in decoder_pack.fixture_state_dict(Ws, bs, True).items()})
+    K = fixture.make_intrinsic(32, 32)
+    R, T = (torch.from_numpy(a).cuda() for a in fixture.make_camera(10, 5, 1.6, 0))
+    r = SDFRenderer(dec, K, march_step=20, buffer_size=2)
+    lat = torch.from_numpy(latent).cuda()
+    pts = torch.from_numpy(_points(200)).cuda()
+    d0 = r.render(lat, R, T, no_grad=True)[0].clone()
+    s0 = decode_sdf(dec, lat, pts, no_grad=True).clone()
+    Ws2, bs2, _ = fixture.make_decoder_weights(77)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in decoder_pack.fixture_state_dict(Ws2, bs2, True).items()})
+    d1 = r.render(lat, R, T, no_grad=True)[0]
+    s1 = decode_sdf(dec, lat, pts, no_grad=True)
+    with torch.no_grad():
+        ref = dec.inference(torch.cat([lat.expand(200, -1), pts], 1)).clamp(-0.1, 0.1)
+    assert (s1 - ref).abs().max() < 5e-6 and (s1 - s0).abs().max() > 1e-3 and not torch.equal(d0, d1)
+    with torch.no_grad():
+        dec.lin8.bias.add_(0.05)                       # in-place edit of one parameter
+        ref2 = dec.inference(torch.cat([lat.expand(200, -1), pts], 1)).clamp(-0.1, 0.1)
+    assert (decode_sdf(dec, lat, pts, no_grad=True) - ref2).abs().max() < 5e-6
+    dec.train()
+    with pytest.raises(decoder_pack.UnsupportedDecoder):
+        r.render(lat, R, T, no_grad=True)
+    dec.eval()
+    r.render(lat, R, T, no_grad=True)
+
+
+@pytest.mark.gpu
 def test_cluster_fallback_is_bit_identical(engine, fixture_decoder):
     """A cluster whose workgroups do not become co-resident in time is evaluated by its lead workgroup alone. Forced here for
     EVERY cluster (DISTR_CLUSTER_TEST_ABORT=1 on a second context): outputs and gradients equal the normal run bit for bit and
