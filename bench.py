@@ -18,7 +18,8 @@ Extra objects on the JSON line:
   roofline     the dominant kernel (fused march/MLP kernel k_march): algorithmic FLOP (3 146 752 per decoder
                evaluation, latent hoisted) / summed hipEvent kernel time on the launch stream, vs the 157.3 TFLOP/s
                f32-MFMA peak (the instruction the kernel uses: v_mfma_f32_32x32x2_f32)
-  cpu_baseline the CPU oracle (oracle/, "port") timed on this host's cores on a bounded sample of the same workload
+  cpu_baseline the CPU oracle (oracle/, "port": C++, OpenMP) timed on this host's cores on one fwd+bwd of the same workload;
+               cpu_baseline_torch: the PyTorch-CPU restatement (baseline 2) on a bounded sample + config C1
 """
 import argparse
 import json
@@ -46,28 +47,71 @@ def view_camera(fixture, view):
     return fixture.make_camera(45.0 * view, 25.0 if view else 0.0, 1.6, 0.0) if view else fixture.make_camera(0, 0, 1.6, 0)
 
 
-def cpu_baseline(fixture, Ws, bs, latent, budget_s=20.0):
-    """Times the CPU oracle (fwd+bwd, all host cores) on the same view at the largest resolution that fits the budget."""
+def cpu_baseline(fixture, Ws, bs, latent, size, march_step, marcher):
+    """Times the CPU oracle (C++ restatement, OpenMP over rays, all host cores) on ONE fwd+bwd of the bench workload itself (same
+    image size, camera, decoder, marcher, loss): ~30 s of CPU work at 512x512 on a 128-core host."""
     from oracle import oracle as orc
     import helpers
     orc.build()
     O = orc.Oracle(Ws, bs)
     cores = orc.lib().orc_num_threads()
     R, T = view_camera(fixture, 0)
-    size, rate, t = 64, None, None
-    while True:
+    K = fixture.make_intrinsic(size, size)
+    t0 = time.perf_counter()
+    helpers.oracle_render(O, orc, size, size, K, R, T, latent, march_step=march_step, buffer_size=BUFFER_SIZE, ratio=RATIO, marcher=marcher,
+                          use_depth2normal=True)
+    t = time.perf_counter() - t0
+    return {'value': size * size / t, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
+            'sample': 'one fwd+bwd of the bench workload itself: %dx%d image of view 0, %d steps, %s, dense loss; %.1f s wall, OpenMP over rays'
+                      % (size, size, march_step, marcher, t),
+            'host': host_description()}
+
+
+def host_description():
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'cpu_model': model, 'nproc': os.cpu_count()}
+
+
+def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=25.0):
+    """BASELINE.md section 3, baseline (2): the build's own PyTorch-CPU restatement (oracle/torch_restatement.py: batched ATen ops, one
+    decoder evaluation per march step over the live rays, autograd backward -- how the reference itself executes) on the host's cores.
+    Config C1 (64x64, 20 steps: BASELINE.json configs[0], 'PyTorch CPU reference path') plus the largest power-of-two size of the bench
+    configuration that fits the time budget."""
+    import torch as th
+    from oracle import torch_restatement as tr
+    import helpers
+    # ATen's CPU kernels on these shapes (a few thousand rows x 512) stop scaling long before a 256-thread host is full and collapse
+    # under oversubscription (64x64/20 steps: ~1 s on 4..32 threads, ~2 minutes on 256): a bounded pool, like a user would set
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    R, T = view_camera(fixture, 0)
+
+    def run(size, steps, mar):
         K = fixture.make_intrinsic(size, size)
         t0 = time.perf_counter()
-        helpers.oracle_render(O, orc, size, size, K, R, T, latent, march_step=MARCH_STEP, buffer_size=BUFFER_SIZE,
-                              ratio=RATIO, marcher='pyramid_recursive', use_depth2normal=True)
-        t = time.perf_counter() - t0
-        rate = size * size / t
-        if size >= H or t * 4.2 > budget_s:
+        tr.render_fwd_bwd(Ws, bs, latent, size, size, K, R, T, helpers.loss_weights(size, size, 5), marcher=mar, march_step=steps,
+                          buffer_size=BUFFER_SIZE, ratio=RATIO, use_depth2normal=True, threads=threads)
+        return time.perf_counter() - t0
+    run(32, 12, marcher)                                            # warm-up (thread pool, allocator)
+    t_c1 = run(64, 20, marcher)
+    if t_c1 < 5.0:
+        t_c1 = min(t_c1, run(64, 20, marcher))
+    size, t, spent = 64, None, 0.0
+    while True:
+        t = run(size, march_step, marcher)
+        spent += t
+        if size >= H or t * 4.5 > budget_s - spent:
             break
         size *= 2
-    return {'value': rate, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-            'sample': '%dx%d image of view 0 (same camera/decoder/marcher, %d steps), fwd+bwd, %.1f s wall, OpenMP over rays'
-                      % (size, size, MARCH_STEP, t)}
+    return {'value': size * size / t, 'unit': 'rays/s', 'cores': int(th.get_num_threads()), 'kind': 'port',
+            'sample': 'PyTorch-CPU restatement, %dx%d image of view 0, %d steps, %s, fwd+bwd, %.1f s wall' % (size, size, march_step, marcher, t),
+            'c1_64x64_20steps': {'rays_per_s': 64 * 64 / t_c1, 'seconds': t_c1}}
 
 
 def main():
@@ -187,19 +231,35 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # ---- the timed region: exactly K steps between barrier + synchronize on both sides; nothing is recorded inside it
     torch.cuda.synchronize()
     parallel.barrier()
-    eng.ctx.profile_enable(True)
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     parallel.barrier()
+    elapsed = parallel.allreduce_max_scalar(elapsed, device=dev)
+
+    # ---- second pass (not part of `value`): per-step wall times -> median (SURVEY.md 8d asks for the median of >= 20 iterations)
+    per_step = []
+    for _ in range(max(args.steps, 1)):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        per_step.append(time.perf_counter() - ts)
+    median_s = parallel.allreduce_max_scalar(float(np.median(per_step)), device=dev)
+
+    # ---- third pass: roofline of the march kernels. Every march launch is bracketed by hipEvents on the launch stream (the
+    # brackets serialise a little, which is why they are not in the timed region); algorithmic FLOP / summed kernel time
+    ROOF_STEPS = min(5, max(args.steps, 1))
+    eng.ctx.profile_enable(True)
+    for _ in range(ROOF_STEPS):
+        step()
     launches, kernel_ms = eng.ctx.profile_read()
     eng.ctx.profile_enable(False)
-    elapsed = parallel.allreduce_max_scalar(elapsed, device=dev)
 
     # forward / backward split of one step (outside the timed region; hipEvents on the current stream)
     def timed(fn):
@@ -237,21 +297,24 @@ def main():
         stats = st if stats is None else {k: stats[k] + st[k] for k in st}
 
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see file
+    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see file
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath))['bytes_per_launch']
         except Exception:
             traffic = None
     if rank == 0:
-        evals = stats['num_point_evals'] * args.steps
+        evals = stats['num_point_evals'] * ROOF_STEPS
         flops = FLOP_PER_EVAL * evals
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         rays = (4.0 if c5 else float(args.gpus)) * H * W * args.steps     # c5: fixed total work (4 images); c3: one view per GPU
         out = {
             'metric': 'rays/sec (fwd+bwd) at %dx%d, %d march steps, DeepSDF 8x512' % (H, W, MARCH_STEP),
             'value': rays / elapsed, 'unit': 'rays/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong' if c5 else 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'median_ms_per_step': 1e3 * median_s,
+            'value_at_median': rays / args.steps / median_s, 'higher_is_better': True, 'scaling': 'strong' if c5 else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)',
             'config': {'workload': '%s%dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
                                    '%s loss, fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
@@ -267,13 +330,14 @@ def main():
                        'decoder_evals_per_s_march': evals / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'traffic_note': 'fabric-side bytes per march step from a separate rocprofv3 PMC pass (profiles/r01_traffic.json)',
-                         'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one bracket per march step), %d steps, %.3f ms total, avg %.1f us'
-                                   % (launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
+                         'traffic_note': 'fabric-side bytes per march launch from a separate rocprofv3 PMC pass (%s)' % os.path.relpath(tpath, ROOT),
+                         'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
+                                   % (ROOF_STEPS, launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
         }
-        if not args.no_cpu_baseline and args.gpus == 1:      # reported baseline, rank 0 at N=1 only
-            out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np)
+        if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)
+            out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np, H, MARCH_STEP, args.marcher)
+            out['cpu_baseline_torch'] = cpu_baseline_torch(fixture, Ws, bs, latent_np, MARCH_STEP, args.marcher)
         print(json.dumps(out))
     parallel.barrier()
 

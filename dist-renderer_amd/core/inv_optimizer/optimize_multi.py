@@ -9,6 +9,12 @@ stream and never synchronises, PyTorch replays each pair's backward on the strea
 backward of different pairs overlap on the idle CUs. The loss sum and every gradient are accumulated in the same order
 as in the sequential loop (the per-pair losses are added on the main stream in pair order), so results do not depend on
 the number of streams.
+
+Multi-GPU (`distributed=`): with torch.distributed initialised (one process per GPU, backend nccl = RCCL), the view
+pairs of a round are sharded over the ranks (rank r takes pairs r, r + world, ...: the 8 pairs of the reference's round on 8 GPUs =
+one pair each), every rank back-propagates its partial loss, and ONE packed all-reduce of [g_shape_code | g_sim3 (rot 3, scale 1,
+trans 3) | loss] (distr.parallel.allreduce_grads) gives every rank the gradient of the whole round; the optimiser step is then
+identical everywhere -- no parameter broadcast, no other collective.
 """
 import os
 
@@ -18,6 +24,18 @@ import torch
 from core.utils.train_utils import params_to_mtrx
 
 from .loss_multi import compute_loss_color_warp
+
+
+def _dist_state(distributed):
+    """(rank, world) the loop shards over; (0, 1) when not distributed. distributed=None: follow torch.distributed."""
+    from distr import parallel
+    if distributed is False:
+        return 0, 1
+    rank, world = parallel.rank_world()
+    if distributed and world == 1:
+        raise RuntimeError('distributed=True but torch.distributed is not initialised with more than one rank '
+                           '(distr.parallel.init_from_env() under torch.distributed.run)')
+    return rank, world
 
 
 class _StreamPool(object):
@@ -75,11 +93,14 @@ def multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, 
 def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images, cameras, weight_list,
                         num_views_per_round=8, num_iters=20, num_sample_points=30000, sep_dist=1, test_step=5, points_gt=None,
                         sim3=None, sim3_init=None, visualizer=None, vis_dir=None, vis_flag=None, full_flag=True, streams=4,
-                        on_round=None):
+                        on_round=None, distributed=None):
+    from distr import parallel
+    rank, world = _dist_state(distributed)
+    lead = rank == 0                         # printing / mesh extraction / evaluation happen once, on rank 0
     num_images = len(images)
     rot_freq = num_images / num_views_per_round
     pool = _StreamPool(streams if visualizer is None else 0, shape_code.device)
-    if evaluator is not None and vis_dir is not None:
+    if evaluator is not None and vis_dir is not None and lead:
         evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points, fname=os.path.join(vis_dir, 'mesh_initial.ply'), silent=True)
     best_chamfer, best_epoch = 100, 0
     loss_pack = None
@@ -94,16 +115,23 @@ def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images
                 sim_mtrx = torch.cat([rot, trans[:, None]], dim=1)
                 sim3_scale = torch.norm(rot) / np.sqrt(3)
             pairs = [pair_indices(idx, i, rot_freq, sep_dist, num_images) for i in range(num_views_per_round)]
-            loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, sim3=sim_mtrx,
-                                                     sim3_scale=sim3_scale, visualizer=visualizer, pool=pool)
-            loss_total.backward()
+            mine = pairs[rank::world]                  # view-parallel: this rank's share of the round (all of it when world == 1)
+            if mine:
+                loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, mine, weight_list, sim3=sim_mtrx,
+                                                         sim3_scale=sim3_scale, visualizer=visualizer, pool=pool)
+                loss_total.backward()
+            else:
+                loss_total = torch.zeros((), device=shape_code.device)
+            if world > 1:                              # ONE collective per step: [g_shape_code | g_sim3 | loss]
+                sim_params = [sim3[k] for k in ('rot', 'scale', 'trans')] if sim3 is not None else []
+                loss_total, = parallel.allreduce_grads([shape_code] + sim_params, [loss_total])
             shape_optimizer.step()
             if on_round is not None:
                 on_round(epoch, idx, loss_total.detach(), loss_pack)
-        if vis_flag and visualizer is not None:
+        if vis_flag and visualizer is not None and lead and loss_pack is not None:
             print('[{0}] loss_color: {1:.4f}, loss_l2reg: {2:.4f}\n'.format(epoch, loss_pack['color'], loss_pack['l2reg']))
             visualizer.show_all_data_color_warp(os.path.join(vis_dir, 'vis_{}.png'.format(epoch)))
-        if evaluator is not None and vis_dir is not None and epoch % test_step == 0:
+        if evaluator is not None and vis_dir is not None and epoch % test_step == 0 and lead:
             points_pred = evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points,
                                                          fname=os.path.join(vis_dir, 'mesh_{}.ply'.format(epoch)), silent=True)
             if points_pred is None:

@@ -3,8 +3,15 @@ core/inv_optimizer/optimize_single.py:35-110). Same signature and the same hooks
 the Visualizer's loss curves / image dumps when one is passed, and every `test_step` iterations the evaluator's mesh
 extraction + chamfer distance against `points_gt` (those objects are the reference's own CPU tooling; this loop only calls
 them). `on_iteration(i, loss_pack, loss)` is an extra callback for callers that want the numbers without printing.
+
+Multi-GPU (`distributed=`): with torch.distributed initialised the renderers of a multi-scale list
+(run_single_shape.py:110-117: full, 1/2 and 1/4 resolution) are sharded over the ranks (renderer i on rank i mod world); every rank
+back-propagates its weighted partial loss and ONE packed all-reduce of [g_shape_code or g_camera_tensor (7) | loss] makes the
+optimiser step identical on all ranks. (One large view is split further by row bands: distr.functions.render_band_call.)
 """
 import os
+
+import torch
 
 from core.utils.render_utils import get_camera_from_tensor
 
@@ -33,9 +40,13 @@ def _progress(n, silent):
 def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, camera_tensor, gt_pack, weight_dict,
                          optimizer_type='shape', num_iters=200, renderer_weights=None, grad_settings=None, points_gt=None,
                          test_step=50, profile=False, visualizer=None, silent=False, vis_folder=None,
-                         ray_marching_type='pyramid_recursive', on_iteration=None):
+                         ray_marching_type='pyramid_recursive', on_iteration=None, distributed=None):
     if optimizer_type not in ('shape', 'camera'):
         raise NotImplementedError
+    from distr import parallel
+    from .optimize_multi import _dist_state
+    rank, world = _dist_state(distributed)
+    silent = silent or rank != 0             # printing / plots / evaluation once, on rank 0
     weights = list(renderer_weights) if renderer_weights else [1.0] * len(sdfrenderer_list)
     if grad_settings is None:
         grad_settings = {'depth': True, 'normal': True, 'silhouette': True}
@@ -47,6 +58,8 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
         extrinsics = camera_tensor if optimizer_type == 'shape' else get_camera_from_tensor(camera_tensor)
         loss = 0
         for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights)):
+            if idx % world != rank:          # renderer-parallel: another rank renders this scale
+                continue
             # only the first (full-resolution) renderer of a multi-scale list feeds the visualiser (optimize_single.py:63-74)
             pack, vis_out = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(),
                                              profile=profile, visualizer=visualizer if idx == 0 else None,
@@ -63,9 +76,13 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
                                 weight_dict['w_l2reg'] * pack['l2reg'])
             if on_iteration is not None and idx == 0:
                 on_iteration(i, pack, loss)
+        if torch.is_tensor(loss):
+            loss.backward()
+        if world > 1:                        # ONE collective per step: [gradient of the optimised tensor | loss]
+            target = shape_code if optimizer_type == 'shape' else camera_tensor
+            loss, = parallel.allreduce_grads([target], [loss if torch.is_tensor(loss) else torch.zeros((), device=target.device)])
         if visualize:
             visualizer.add_loss(loss)
-        loss.backward()
         optimizer.step()
         # evaluation every test_step iterations (optimize_single.py:87-98): mesh of the current code + chamfer distance
         if points_gt is not None and (i + 1) % test_step == 0 and not silent and evaluator is not None:

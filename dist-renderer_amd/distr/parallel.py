@@ -54,6 +54,48 @@ def shard_rows(num_images, H, rank, world_size, align=4):
     return out
 
 
+def is_distributed(group=None):
+    """True when torch.distributed is up with more than one rank (the optimisation loops then shard their work items)."""
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def rank_world(group=None):
+    if not is_distributed(group):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def allreduce_grads(params, scalars=(), group=None):
+    """The one collective of an optimisation step: the gradients of `params` (shape code, sim(3) parameters, camera
+    tensor ...) and the detached loss `scalars` are packed into ONE flat f32 buffer [g_latent | g_sim3 / g_cam | loss ...] and summed
+    over the ranks with a single all-reduce (RCCL on GPUs, gloo on CPU); every rank then holds identical gradients and applies the
+    identical optimiser step -- no parameter broadcast. A parameter whose .grad is None on this rank (it rendered nothing that
+    depends on it) contributes zeros and receives the sum. Returns the reduced scalars as a list of 0-d tensors."""
+    params = [p for p in params if p is not None]
+    if not is_distributed(group):
+        return [s.detach() if torch.is_tensor(s) else torch.tensor(float(s)) for s in scalars]
+    dev = params[0].device if params else torch.device('cpu')
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    sc = [(s.detach().to(dev, torch.float32).reshape(1) if torch.is_tensor(s) else torch.tensor([float(s)], dtype=torch.float32, device=dev))
+          for s in scalars]
+    flat = torch.cat([g.detach().reshape(-1).to(torch.float32) for g in grads] + sc) if (grads or sc) else torch.zeros(0, device=dev)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        red = flat[off:off + n].reshape(g.shape).to(g.dtype)
+        if p.grad is None:
+            p.grad = red.clone()
+        else:
+            p.grad.copy_(red)
+        off += n
+    out = []
+    for _ in sc:
+        out.append(flat[off].clone())
+        off += 1
+    return out
+
+
 def allreduce_packed(tensors, group=None):
     """Sums every tensor of `tensors` over all ranks with ONE all-reduce of a packed flat f32 buffer (in place)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

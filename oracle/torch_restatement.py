@@ -64,7 +64,7 @@ class TorchRenderer(object):
         inside = dist <= self.radius
         chord = torch.where(inside, 2.0 * torch.sqrt(torch.clamp(self.radius ** 2 - dist ** 2, min=0.0)), torch.zeros_like(dist))
         cdist = torch.norm(cam_pos)
-        if float(cdist) < self.radius:
+        if float(cdist.detach()) < self.radius:
             init = torch.zeros_like(dist)
         else:
             init = torch.sqrt(torch.clamp(cdist ** 2 - dist ** 2, min=0.0)) - chord / 2.0

@@ -310,3 +310,65 @@ def test_c5_four_shapes_row_bands_full_size(engine, fixture_decoder):
             assert rel < 2e-5, (s, name, rel)
         del full, parts
         torch.cuda.empty_cache()
+
+
+# -------------------------------------------------------------------------- the product's distributed loop on the HIP path
+def _g9_round_hip(distributed):
+    import torch
+    from core.inv_optimizer import optimize_multi_view
+    import test_gpu_parity as tg
+    g = dict(np.load(os.path.join(GOLDEN, 'g9_multi_view_round.npz')))
+    r, cams, imgs = tg._multi_view_setup(g)
+    lat = torch.from_numpy(g['latent']).cuda().requires_grad_(True)
+    sim3 = {'rot': torch.from_numpy(g['sim3_rot']).cuda().requires_grad_(True),
+            'scale': torch.tensor(float(g['sim3_scale']), device='cuda', requires_grad=True),
+            'trans': torch.from_numpy(g['sim3_trans']).cuda().requires_grad_(True)}
+    opt = torch.optim.SGD([lat] + list(sim3.values()), lr=0.0)
+    got = []
+
+    def on_round(epoch, idx, loss, pack):
+        if not got:
+            got.append([float(loss)] + [t.grad.detach().cpu().numpy().copy() for t in (lat, sim3['rot'], sim3['scale'], sim3['trans'])])
+    optimize_multi_view(r, None, lat, opt, imgs, cams, {'color': float(g['w_color']), 'l2reg': float(g['w_l2reg'])}, num_views_per_round=2,
+                        num_iters=1, sep_dist=1, sim3=sim3, sim3_init=torch.cat([torch.eye(3), torch.zeros(3, 1)], 1).cuda(), on_round=on_round,
+                        distributed=distributed)
+    return got[0], g
+
+
+def _g9_worker(rank, world, port, q):
+    for p_ in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      DISTR_DIST_BACKEND='gloo')
+    import torch
+    from distr import parallel
+    parallel.init_from_env()
+    res, _ = _g9_round_hip(True)
+    q.put((rank, res))
+    torch.distributed.destroy_process_group()
+
+
+def test_optimize_multi_view_distributed_on_hip_path():
+    """core.inv_optimizer.optimize_multi_view(distributed=True) with the real SDFRenderer_warp on two ranks sharing this GPU (gloo):
+    the round's two view pairs go one to each rank, ONE packed all-reduce of [g_shape | g_sim3 | loss]; every rank ends with the
+    serial round's loss and gradients (<= 2e-5), which in turn match the reference's golden G9 round."""
+    import torch.multiprocessing as mp
+    serial, g = _g9_round_hip(False)
+    assert abs(serial[0] - float(g['loss_total'])) <= 2e-4 * abs(float(g['loss_total']))
+    for a, name in zip(serial[1:], ('g_latent', 'g_rot', 'g_scale', 'g_trans')):
+        assert np.abs(a - g[name]).max() <= 1e-2 * np.abs(g[name]).max(), name
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_g9_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    for rank, r in res:
+        assert abs(r[0] - serial[0]) <= 2e-5 * abs(serial[0]), rank
+        for a, b in zip(r[1:], serial[1:]):
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), rank
