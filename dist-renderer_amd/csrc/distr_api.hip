@@ -44,6 +44,7 @@ struct distr_ctx {
   XRegion xr[NXR];
   bool cluster = true;          // DISTR_CLUSTER=0: single-workgroup 16-ray tiles only
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
+  int min_cl = 4;               // DISTR_CLUSTER_MIN=2: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
   bool persist64 = true;        // DISTR_PERSIST64=0: one workgroup per 64-ray tile in the merged launch
   bool merged_step = true;      // DISTR_MERGED_STEP=0: one launch per tile size and step instead of one merged launch per step
@@ -194,8 +195,8 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   return free_slot;
 }
 
-inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8, int test_abort = 0) {
-  Xchg x{nullptr, nullptr, 0, max_cl, test_abort, nullptr};
+inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8, int test_abort = 0, int min_cl = 4) {
+  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
   if (r) { if (++r->epoch == 0) ++r->epoch; x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch; }
   return x;
@@ -309,6 +310,7 @@ int distr_create(distr_ctx** out, int hip_device) {
   if (ctx->tile_rb < -1 || ctx->tile_rb > 2) ctx->tile_rb = 0;   // -1: force 16-ray tiles wherever they exist (tests)
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
   if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
+  if (const char* e = getenv("DISTR_CLUSTER_MIN")) ctx->min_cl = atoi(e);
   if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
   if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e) != 0;
   if (const char* e = getenv("DISTR_MERGED_STEP")) ctx->merged_step = atoi(e) != 0;
@@ -523,7 +525,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       const int crb = (split_cfg && ln <= ctx->hybrid_threshold) ? 1 : rb_dense;
       const int ctile = c16 ? 16 : 32 * crb;
       unsigned tiles = (unsigned)((ln + ctile - 1) / ctile) + (A.origin_tile ? 1u : 0u);
-      A.xc = next_xchg(c16 ? xr : nullptr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort);
+      A.xc = next_xchg(c16 ? xr : nullptr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
       if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
       if (c16) {
@@ -555,7 +557,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
     if (force16) { A.t16 = 0x7fffffff; A.t32 = 0x7fffffff; }       // tests: whole step on 16-ray tiles (rem = count when < 16384...)
     // the live count never exceeds P: with P <= t32 the 64-ray range of the split is provably empty (and with P <= t16 the
     // 32-ray range too), so those launches are skipped on the host
-    const bool skip64 = split && !A.origin_tile && P <= A.t32 && A.t16 > 0;
+    const bool skip64 = split && !A.origin_tile && P <= A.t32 + A.t16 && A.t16 > 0;   // (up to t32 + t16 rays: 32- then 16-ray tiles)
     const bool skip32 = split && P <= A.t16;
     timer.begin();
     if (split_cfg && ctx->merged_step && !A.origin_tile) {
@@ -566,7 +568,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       G.n32 = (A.t32 > A.t16 && !skip32) ? up8((std::min(P, A.t32) + 31) / 32) : 0;
       MarchArgs A2 = A;
       A2.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
-      A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort);
+      A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
       unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
       if (xr) n16 = std::max(n16, 256u);
       G.n16 = up8(n16);
@@ -598,7 +600,7 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       if (A.t16 > 0) {
         A2.which = 16;
         A2.origin_tile = (split_cfg && st == V.fine_steps - 1) ? 1 : 0;
-        A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort);
+        A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
         // grid: one workgroup per 16-ray tile of the largest possible remainder (+1 for f(origin) in the launch that
         // carries it); cluster tiles (8 / 4 workgroups per tile of at most 31 / 63 tiles + the origin tile) need 256
         unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);

@@ -436,17 +436,30 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
 // workgroups beyond the device-side count exit immediately, so the host never synchronises inside the loop.
 enum { MODE_EVAL = 0, MODE_COARSE = 1, MODE_FINE = 2 };
 
-// A march step over `count` live rays is split by tile size so that no launch pays a full 64-ray tile latency for a
-// small remainder: rays [0, full) with full = floor(count / 16384) * 16384 (whole rounds of 256 CUs x 64 rays) go to
-// the 64-ray kernel; the remainder goes to 16-ray tiles if <= t16, to 32-ray tiles if <= t32, else also to 64-ray tiles.
-// Every kernel of the step evaluates this on the device-side count; the host never needs to know it.
+// A march step over `count` live rays is split by tile size so that no launch pays a full 64-ray tile latency for a small
+// remainder: rays [0, full) with full = floor(count / 16384) * 16384 (whole rounds of 256 CUs x 64 rays) go to the 64-ray
+// role; the remainder `rem` goes, by size, to
+//     rem <= t16 (4096)          16-ray tiles          (one wave of 111 us tiles; clusters below 1008 rays)
+//     rem <= t32 (8192)          32-ray tiles          (203 us)
+//     rem <= t32 + t16 (12288)   32-ray tiles for the first t32 rays + 16-ray tiles for the rest (203 + 111 us on the same CUs:
+//                                the work is MFMA-bound, so 48 rays per CU cost 48/64 of a round whether the two tiles share
+//                                the CU or follow each other)
+//     else                       one more round of 64-ray tiles (362 us).
+// Every role of the step evaluates this on the device-side count; the host never needs to know it.
 __device__ __forceinline__ void fine_range(int64_t count, int t16, int t32, int which, int64_t& lo, int64_t& hi) {
   if (t32 <= 0) { lo = 0; hi = count; return; }                                   // single kernel per step
   if (t16 == 0x7fffffff) { lo = 0; hi = (which == 16) ? count : 0; return; }      // tests: everything on 16-ray tiles
   const int64_t full = (count / 16384) * 16384, rem = count - full;
-  const int small = (rem == 0) ? 64 : (rem <= t16 ? 16 : (rem <= t32 ? 32 : 64));
-  if (which == 64) { lo = 0; hi = (small == 64) ? count : full; }
-  else { lo = full; hi = (small == which) ? count : full; }
+  // remainder split point: rays [full, cut) on 32-ray tiles, [cut, count) on 16-ray tiles (either part may be empty)
+  int64_t cut;
+  bool big = false;
+  if (rem <= t16) cut = full;
+  else if (rem <= t32) cut = count;
+  else if (t16 < t32 && rem <= (int64_t)t32 + t16) cut = full + t32;
+  else { cut = full; big = true; }                                                 // whole remainder on 64-ray tiles
+  if (which == 64) { lo = 0; hi = big ? count : full; }
+  else if (which == 32) { lo = full; hi = big ? full : cut; }
+  else { lo = big ? count : cut; hi = count; }
 }
 
 struct MarchArgs {
@@ -619,7 +632,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   // time: 68 us (8), 80 us (4), 111 us (single workgroup); 2 per tile gains nothing (the two halves of a layer plus the
   // exchange cost what the whole layer costs on one CU), so larger remainders stay on single-workgroup tiles.
   int cl = 1;
-  if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : 1;
+  if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : (n <= 2032 && A.xc.min_cl <= 2) ? 2 : 1;
   int tile = bidx, member = 0;
   if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8)
     const int g = bidx / (8 * cl), r = bidx % (8 * cl);
@@ -669,7 +682,8 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
   if (MODE != MODE_EVAL && cl > 1) {
     if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-    else pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+    else if (cl == 4) pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+    else pre = mlp_forward16_cl<2, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
     if (member != 0) return;            // only the lead member runs the epilogue
     clustered = S.fail == 0;
     if (!clustered) {

@@ -923,6 +923,7 @@ struct Xchg {
   uint32_t* flags;     // [256 clusters][16 barriers][8 members]
   uint32_t epoch;      // unique per launch (per region)
   int32_t max_cl;      // largest cluster size to use (8 or 4)
+  int32_t min_cl;      // smallest cluster size to use (4; 2 = also pair tiles up to 2032 rays, DISTR_CLUSTER_MIN=2)
   int32_t test_abort;  // tests (DISTR_CLUSTER_TEST_ABORT=1): every lead member behaves as if its cluster had not assembled
   long long* ts;       // debug (DISTR_XCHG_TS=1): wall-clock stamps of cluster 0 / member 0 at phase boundaries, else null
 };

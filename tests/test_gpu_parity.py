@@ -37,6 +37,13 @@ def orc():
     return oracle
 
 
+
+
+def _floors():
+    """The reference's own residuals under 1e-7 relative weight noise on the G4/G5/G9/G11 scenarios (oracle/gen_noise_floors.py)."""
+    return {k: float(v) for k, v in np.load(os.path.join(GOLDEN, 'noise_floor_g4_g5_g9_g11.npz')).items()}
+
+
 def _points(n, seed=3):
     rs = np.random.RandomState(seed)
     p = (rs.rand(n, 3) * 1.8 - 0.9).astype(np.float32)
@@ -376,18 +383,21 @@ def test_adam_single_view_matches_reference_golden(fixture_decoder):
     optimize_single_view([r], None, opt, lat, RT, gt_pack, wd, optimizer_type='shape', num_iters=5, on_iteration=record, silent=True)
     hist, ref = np.array(hist), g['history']
     print('ours\n', hist, '\nreference\n', ref[:, :6])
+    fl = _floors()
+    for i, nm in enumerate(('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg', 'loss')):
+        r_ = (np.abs(hist[:, i] - ref[:, i]) / np.maximum(np.abs(ref[:, i]), 1e-30)).max()
+        print('G5 %s: max relative residual over the 5 iterations %.3e (reference noise floor %.3e)' % (nm, r_, fl['g5_%s_rel' % nm]))
+    print('G5 final latent: max abs residual %.3e (reference noise floor %.3e)' % (np.abs(lat.detach().cpu().numpy() - g['latent_final']).max(), fl['g5_latent_final_abs']))
     # Observed agreement: 3-6 significant digits. The first iteration is exact to ~1e-7; later ones depend on Adam, whose
     # first update is lr*sign(g): a coordinate whose gradient is ~0 can flip sign through float-summation order alone
     # (ours vs the reference's autograd), which moves the loss by ~1e-5.
-    assert np.abs(hist[0, :] - ref[0, :6]).max() <= 2e-6
-    assert np.abs(hist[:, 0] - ref[:, 0]).max() <= 1e-2 * ref[:, 0].max()          # depth loss
-    assert np.abs(hist[:, 1] - ref[:, 1]).max() <= 5e-4                             # normal (cosine) loss
-    assert np.abs(hist[:, 2:4] - ref[:, 2:4]).max() <= 2e-5                          # mask hinge losses (threshold scale 5e-5)
-    assert np.abs(hist[:, 4] - ref[:, 4]).max() <= 1e-6                             # l2 regulariser
-    assert np.abs(hist[:, 5] - ref[:, 5]).max() <= 2e-3 * np.abs(ref[:, 5]).max()   # total
-    # Adam moves every coordinate by ~lr per step: the two trajectories must stay together
-    assert np.abs(lat.detach().cpu().numpy() - g['latent_final']).max() <= 1.5e-3
-    assert np.abs(lat.detach().cpu().numpy() - g['latent_final']).mean() <= 2e-4
+    assert np.abs(hist[0, :] - ref[0, :6]).max() <= 2e-6                 # first iteration: nothing has diverged yet
+    # later iterations: Adam's first update is lr*sign(g), so a coordinate whose gradient is ~0 flips through float-summation order
+    # alone; the reference itself moves by the recorded floors under 1e-7 weight noise. Bar = 2 x that floor per term.
+    for i, nm in enumerate(('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg', 'loss')):
+        r_ = (np.abs(hist[:, i] - ref[:, i]) / np.maximum(np.abs(ref[:, i]), 1e-30)).max()
+        assert r_ <= 2.0 * fl['g5_%s_rel' % nm], (nm, r_, fl['g5_%s_rel' % nm])
+    assert np.abs(lat.detach().cpu().numpy() - g['latent_final']).max() <= 2.0 * fl['g5_latent_final_abs']
 
 
 def test_bulk_sdf_grid(cpu_oracle, fixture_decoder):
@@ -470,7 +480,12 @@ def test_render_warp_matches_reference_golden(fixture_decoder):
     assert np.percentile(dn, 99) <= 1e-4
     assert np.abs(c1.cpu().numpy() - g['color_valid_1']).max() <= 1e-5 or (np.abs(c1.cpu().numpy() - g['color_valid_1']) > 1e-5).sum() <= 6
     rel = np.abs(lat.grad.cpu().numpy() - g['g_latent']).max() / np.abs(g['g_latent']).max()
-    assert rel <= 5e-3, rel
+    fl = _floors()
+    print('G4 residual vs reference: g_latent %.3e (reference noise floor %.3e), loss %.3e (floor %.3e), min_sdf %.3e (floor %.3e)'
+          % (rel, fl['g4_g_latent_rel'], abs(float(loss_color) - float(g['loss_color'])), fl['g4_loss_abs'],
+             np.abs(q1.detach().cpu().numpy() - g['min_sdf1']).max(), fl['g4_min_sdf']))
+    assert rel <= 2.0 * fl['g4_g_latent_rel'], (rel, fl['g4_g_latent_rel'])          # bar = 2 x the reference's own noise floor
+    assert np.abs(q1.detach().cpu().numpy() - g['min_sdf1']).max() <= 2.0 * fl['g4_min_sdf']
 
 
 BAND_CASES = [  # (H, W, bands, marcher, d2n)
@@ -705,9 +720,13 @@ def test_multi_view_round_matches_reference_golden():
     tot, glat, grot, gscale, gtrans = outs[0]
     assert abs(tot - float(g['loss_total'])) <= 2e-4 * abs(float(g['loss_total']))
     assert abs(float(pack['color']) - g['packs'][-1, 0]) <= 1e-4
+    fl = _floors()
     for name, a in (('g_latent', glat), ('g_rot', grot), ('g_scale', gscale), ('g_trans', gtrans)):
         rel = np.abs(a - g[name]).max() / np.abs(g[name]).max()
-        assert rel <= 1e-2, (name, rel)
+        print('G9 %s residual vs reference %.3e (reference noise floor %.3e)' % (name, rel, fl['g9_%s_rel' % name]))
+        # bar = 2 x the reference's own floor, but not below 5e-5: the f32 summation-order level of a gradient summed over ~1e3
+        # samples (one noise realisation under-estimates it for the smaller components)
+        assert rel <= max(2.0 * fl['g9_%s_rel' % name], 5e-5), (name, rel)
     for a, b in zip(outs[0], outs[1]):     # stream count changes nothing
         assert np.asarray(a).tobytes() == np.asarray(b).tobytes()
 
@@ -844,9 +863,16 @@ def test_decode_sdf_autograd_matches_reference_golden(fixture_decoder):
         # latent gradient to 2e-3.
         ref = g['g_points_' + name]
         err = np.abs(x.grad.cpu().numpy() - ref).max(1)
-        assert (err > 2e-5 * np.abs(ref).max()).sum() <= 7, int((err > 2e-5 * np.abs(ref).max()).sum())
-        ref = g['g_latent_' + name]
-        assert np.abs(lat.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+        nbad = int((err > 2e-5 * np.abs(ref).max()).sum())
+        refl = g['g_latent_' + name]
+        rel_l = np.abs(lat.grad.cpu().numpy() - refl).max() / np.abs(refl).max()
+        print('G11 %s: points off by > 2e-5: %d of 777 (median residual %.2e); g_latent residual %.3e (reference noise floor %.3e)'
+              % (name, nbad, np.median(err) / np.abs(ref).max(), rel_l, _floors()['g11_g_latent_%s_rel' % name]))
+        # a unit whose pre-activation is ~1e-8 may sit on either side of the ReLU in two f32 summation orders (observed: ONE of the
+        # 777 points in the unclamped case, lin5 unit 1, pre-activation -4e-8); that point's gradient then differs by O(1e-3) and
+        # so does the summed latent gradient. Without such a point the bar is 2 x the reference's own noise floor.
+        assert nbad <= 1, nbad
+        assert rel_l <= (2e-3 if nbad else max(2.0 * _floors()['g11_g_latent_%s_rel' % name], 5e-6)), rel_l
     # only one of the two inputs requires grad / ragged sizes, against autograd through the module itself
     for n in (1, 63, 65, 200):
         lat = torch.from_numpy(g['latent']).cuda()
