@@ -158,9 +158,8 @@ class SDFRenderer(object):
                normalize_normal=True, use_transform=True, ray_marching_type='pyramid_recursive',
                num_forward_sampling=0):
         if sample_index_type != 'min_abs':
-            raise NotImplementedError("only sample_index_type='min_abs' is implemented")
-        if num_forward_sampling != 0:
-            raise NotImplementedError('forward_sampling (renderer.py:912; device-mismatch bug upstream) is not implemented')
+            raise NotImplementedError("only sample_index_type='min_abs' is implemented (the other four crash inside the reference "
+                                      "itself, oracle/probe_reference_dead_paths.py)")
         if no_grad:
             no_grad_depth, no_grad_normal, no_grad_mask, no_grad_camera = True, True, True, True
         h, w = self.img_hw
@@ -180,4 +179,36 @@ class SDFRenderer(object):
             normal = normal.detach()
         if no_grad_mask and no_grad_camera:
             min_sdf = min_sdf.detach()
+        if num_forward_sampling != 0:
+            inside = self.forward_sampling(latent, R, T, zdepth, mask.bool(), clamp_dist=clamp_dist,
+                                           num_forward_sampling=num_forward_sampling, use_transform=use_transform)
+            return depth, normal, mask.reshape(h, w), min_sdf.reshape(h, w), inside.reshape(h, w, num_forward_sampling)
         return depth, normal, mask.reshape(h, w), min_sdf.reshape(h, w)
+
+    # reference: renderer.py:912
+    def forward_sampling(self, latent, R, T, Zdepth, valid_mask, clamp_dist=0.1, num_forward_sampling=1, no_grad=False,
+                         use_transform=True):
+        """Samples BEHIND the rendered surface along every valid ray: inside_samples[px, i] = f(point(Zdepth + g_i)) + g_i with
+        g_i = 0.5 * clamp_dist * (i + 1) / k (renderer.py:912-941; zero on invalid pixels). Zdepth is detached, the latent code
+        and the camera keep their gradients (decode_sdf with autograd: distr_mlp_backward). One fused launch per offset."""
+        if num_forward_sampling <= 0:
+            raise AssertionError('num_forward_sampling must be positive')
+        P = self.img_hw[0] * self.img_hw[1]
+        out = torch.zeros(P, num_forward_sampling, dtype=torch.float32, device=Zdepth.device)
+        idx = torch.nonzero(valid_mask.reshape(-1)).reshape(-1)
+        if idx.numel() == 0:
+            return out
+        cam_pos = self.get_camera_location(R, T)
+        rays = self.get_camera_rays(R)[:, idx]
+        z = Zdepth.reshape(-1)[idx]
+        cols = []
+        for i in range(num_forward_sampling):
+            g = 0.5 * clamp_dist * (i + 1) / num_forward_sampling
+            pts = self.generate_point_samples(cam_pos, rays, z + g, inv_transform=use_transform, has_zdepth_grad=False)
+            if no_grad:
+                with torch.no_grad():
+                    sdf = functions.mlp_eval(self._engine, latent, pts.t().contiguous())
+            else:
+                sdf = functions.mlp_eval_autograd(self._engine, latent, pts.t().contiguous(), None)
+            cols.append(sdf.reshape(-1, 1) + g)
+        return out.index_copy(0, idx, torch.cat(cols, 1))

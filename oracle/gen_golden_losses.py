@@ -217,6 +217,28 @@ def golden_g11():
     print('g11', {k: float(np.abs(v).max()) for k, v in out.items()}, 'clamped pts', int((np.abs(out['sdf_raw']) > 0.1).sum()))
 
 
+def golden_g12():
+    """G12: SDFRenderer.render(num_forward_sampling=3) (renderer.py:912-941, 982-985): the k samples behind the surface and the
+    gradients of a seeded weighted sum of them w.r.t. the latent code and the camera."""
+    rh.install_shims()
+    SDFRenderer = rh.reference_modules()[0]
+    Ws, bs, latent = fixture.make_decoder_weights()
+    dec = rh.build_reference_decoder(Ws, bs)
+    H = W = 40
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-25, 18, 1.6, 5)
+    r = SDFRenderer(dec, K, img_hw=(H, W), march_step=30, buffer_size=3, use_gpu=False)
+    lat = torch.from_numpy(latent).clone().requires_grad_(True)
+    Rt, Tt = torch.from_numpy(R).clone().requires_grad_(True), torch.from_numpy(T).clone().requires_grad_(True)
+    depth, normal, mask, q, inside = r.render(lat, Rt, Tt, num_forward_sampling=3)
+    wts = np.random.RandomState(12).rand(H, W, 3).astype(np.float32)
+    (inside * torch.from_numpy(wts)).sum().backward()
+    np.savez_compressed(os.path.join(OUT, 'g12_forward_sampling.npz'), weights_sha256=fixture.weights_sha256(Ws, bs), latent=latent, K=K, R=R, T=T,
+                        H=H, W=W, march_step=30, buffer_size=3, num_forward_sampling=3, weights=wts, mask=mask.numpy(),
+                        inside_samples=inside.detach().numpy(), g_latent=lat.grad.numpy(), g_R=Rt.grad.numpy(), g_T=Tt.grad.numpy())
+    print('g12 valid', int(mask.sum()), 'inside range', float(inside.min()), float(inside.max()), 'glat', float(lat.grad.norm()))
+
+
 def golden_g6():
     """G6: structure of the reference's march, recorded by wrapping its decode_sdf (core/utils/decoder_utils.py:53): the
     number of points of every decoder call of render_depth in call order (= live rays per march step, then the
@@ -265,6 +287,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if sys.argv[1:2] == ['--g10']:
         golden_g10()
+        sys.exit(0)
+    if sys.argv[1:2] == ['--g12']:
+        golden_g12()
         sys.exit(0)
     if sys.argv[1:2] != ['--g9']:
         golden_g7()

@@ -425,6 +425,33 @@ def test_bulk_sdf_grid(cpu_oracle, fixture_decoder):
     big = create_sdf_grid(dec, lat, 128)                                        # 2.1 M points in one launch
     assert big.shape == (128, 128, 128) and torch.isfinite(big).all()
 
+    # ---- against the oracle on the REFERENCE's sample ordering (create_mesh.py:16-33: x slowest, z fastest, integer division; the
+    # transform swaps (x, y, z) -> (x, z, -y), :10-14), for the plain and the coarse-to-fine variant (create_mesh.py:100-142)
+    def ref_samples(n, voxel_size, transform):
+        idx = np.arange(n ** 3)
+        xyz = np.stack([(idx // n // n) % n, (idx // n) % n, idx % n], 1).astype(np.float32) * np.float32(voxel_size) + np.float32(-1.0)
+        return np.stack([xyz[:, 0], xyz[:, 2], -xyz[:, 1]], 1) if transform else xyz
+
+    def ref_speedup(n, transform):
+        vs, vs_half, nh = 2.0 / (n - 1), 2.0 / (n / 2 - 1), n // 2
+        half = cpu_oracle.decode_sdf(latent, ref_samples(nh, vs_half, transform), clamp_dist=0.1).reshape(nh, nh, nh)
+        up = np.repeat(np.repeat(np.repeat(half, 2, 0), 2, 1), 2, 2).reshape(-1)            # upsample_cubic: nearest
+        pos, neg, valid = up > vs_half * 1.5, -up > vs_half * 1.5, np.abs(up) <= vs_half * 1.5
+        out = np.zeros(n ** 3, np.float32)
+        out[pos], out[neg] = 0.1, -0.1
+        out[valid] = cpu_oracle.decode_sdf(latent, ref_samples(n, vs, transform)[valid], clamp_dist=0.1)
+        return out.reshape(n, n, n), int(valid.sum())
+    for transform in (False, True):
+        n = 48
+        want = cpu_oracle.decode_sdf(latent, ref_samples(n, 2.0 / (n - 1), transform), clamp_dist=0.1).reshape(n, n, n)
+        got = create_sdf_grid(dec, lat, n, transform=transform).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-7, transform
+        want_s, nvalid = ref_speedup(n, transform)
+        got_s = create_sdf_grid_speedup(dec, lat, n, transform=transform).cpu().numpy()
+        assert 0 < nvalid < n ** 3 // 2
+        assert np.abs(got_s - want_s).max() <= 1e-7, transform
+    assert not np.array_equal(create_sdf_grid(dec, lat, 48, transform=True).cpu().numpy(), create_sdf_grid(dec, lat, 48).cpu().numpy())
+
 
 def test_rccl_allreduce_packed_single_rank():
     """The collective path of bench.py --gpus N (backend 'nccl' = RCCL) on the one GPU this box has: process-group
@@ -1030,6 +1057,37 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
             assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes(), i
         st = engine.ctx.render_stats(cfg, got[i][1])
         assert st['num_in_sphere'] > 0     # (cluster_fallbacks may be > 0 here: clusters of concurrent launches compete for CUs)
+
+
+@pytest.mark.gpu
+def test_forward_sampling_matches_reference_golden(fixture_decoder):
+    """G12: render(num_forward_sampling=3) -- the k samples behind the surface (renderer.py:912-941) and the gradients of a
+    weighted sum of them w.r.t. latent and camera, against the reference."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.graph.deep_sdf_decoder import Decoder
+    g = dict(np.load(os.path.join(GOLDEN, 'g12_forward_sampling.npz')))
+    Ws, bs, _ = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W), ('bias', b))})
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer(dec.cuda(), g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']))
+    c = lambda k: torch.from_numpy(g[k]).cuda().requires_grad_(True)
+    lat, R, T = c('latent'), c('R'), c('T')
+    out = r.render(lat, R, T, num_forward_sampling=int(g['num_forward_sampling']))
+    assert len(out) == 5 and out[4].shape == (H, W, 3)
+    inside = out[4]
+    m = out[2].cpu().numpy().astype(bool)
+    assert int((m != g['mask'].astype(bool)).sum()) <= 1
+    both = m & g['mask'].astype(bool)
+    assert np.abs(inside.detach().cpu().numpy() - g['inside_samples'])[both].max() <= 1e-4
+    assert np.all(inside.detach().cpu().numpy()[~m] == 0)
+    (inside * torch.from_numpy(g['weights']).cuda()).sum().backward()
+    for t, k in ((lat, 'g_latent'), (R, 'g_R'), (T, 'g_T')):
+        rel = np.abs(t.grad.cpu().numpy() - g[k]).max() / np.abs(g[k]).max()
+        assert rel <= 2e-3, (k, rel)
+    with pytest.raises(NotImplementedError):
+        r.render(lat, R, T, sample_index_type='min')
 
 
 @pytest.mark.gpu
