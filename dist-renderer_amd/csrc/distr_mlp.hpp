@@ -745,6 +745,11 @@ struct Smem16 {
   long long mb[16];
 };
 
+struct Smem16CL : Smem16 {
+  uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
+  int32_t fail;           // != 0: this member gave up on the cluster (assembly or barrier timed out / aborted)
+};
+
 struct DecoderDev16 {
   const float* Wf[8];   // 16x16x4 A-fragments: float4 ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + i][16g + 4s + kq] : s=0..3 }
 };
@@ -810,59 +815,91 @@ __device__ __forceinline__ uint32_t writeback16(float* X, const f32x4 (&acc)[NB]
 }
 
 // nib[l]: per-lane nibble words of layer l (see writeback16). Returns pre-tanh for ray = tid & 15.
+// Layers 1..7 run on the hand-scheduled loop (distr_dense_asm.hpp, dense16_asm_*): no VALU / 64-bit-address instruction beside the
+// 32-cycle MFMAs, the next layer's first weight group and bias are requested before the current layer's loop (nothing is
+// exposed at a layer start but one LDS round trip). S.mk (idle outside the cluster path) is the scratch of the tuple -> register move.
 template <bool KEEP>
 __device__ __forceinline__ float mlp_forward16(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
-                                               const float* __restrict__ c4, Smem16& S, uint32_t (&nib)[8]) {
+                                               const float* __restrict__ c4, Smem16CL& S, uint32_t (&nib)[8]) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int kq = lane >> 4;
   const int ray = tid & 15;
   float* X = S.X;
+  const uint32_t xaddr = lds_off(X) + (uint32_t)lane * 4;
+  const uint32_t voff = (uint32_t)lane * 16;
+  const uint32_t scratch = lds_off(S.mk) + (uint32_t)wave * 1024 + (uint32_t)lane * 16;
+  const uint32_t soff8 = (uint32_t)wave * 8192, soff4 = (uint32_t)wave * 4096;
+  rsrc_t rs[8];
+#pragma unroll
+  for (int l = 1; l < 8; ++l) rs[l] = weight_rsrc(D16.Wf[l]);
+  f32x4 t[8];
+  {  // lin1's first group travels while lin0 runs
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(D16.Wf[1]) + (size_t)wave * 8 * 64 + lane;
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) t[ob] = w1[ob * 64];
+  }
+  f32x4 accA[8], accB[8];
+  acc_init16<8>(accB, D.bias[1], wave * 128, kq);         // bias of the NEXT layer: requested one layer ahead throughout
   X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;   // rows 0..15 of the layer-0 input: xyz + zero padding to K = 16
   __syncthreads();
   {
-    f32x4 acc[8];
-    acc_init16<8>(acc, c0, wave * 128, kq);
-    dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
+    acc_init16<8>(accA, c0, wave * 128, kq);
+    dense16<16, 8>(D16.Wf[0], X, accA, wave, lane);
     __syncthreads();
-    nib[0] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int l = 1; l <= 2; ++l) {
-    f32x4 acc[8];
-    acc_init16<8>(acc, D.bias[l], wave * 128, kq);
-    dense16<512, 8>(D16.Wf[l], X, acc, wave, lane);
-    __syncthreads();
-    nib[l] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    nib[0] = writeback16<8, KEEP>(X, accA, wave * 128, lane);
     __syncthreads();
   }
-  {
-    f32x4 acc[4];
-    acc_init16<4>(acc, D.bias[3], wave * 64, kq);
-    dense16<512, 4>(D16.Wf[3], X, acc, wave, lane);
+  {  // lin1 (bias in accB)
+    acc_init16<8>(accA, D.bias[2], wave * 128, kq);
+    dense16_asm_k512_n8_o8(accB, t, xaddr, voff, rs[1], rs[2], soff8, soff8, scratch);
     __syncthreads();
-    nib[3] = writeback16<4, KEEP>(X, acc, wave * 64, lane);
+    nib[1] = writeback16<8, KEEP>(X, accB, wave * 128, lane);
+    __syncthreads();
+  }
+  f32x4 acc3[4];
+  {  // lin2 (bias in accA)
+    acc_init16<4>(acc3, D.bias[3], wave * 64, kq);
+    dense16_asm_k512_n8_o4(accA, t, xaddr, voff, rs[2], rs[3], soff8, soff4, scratch);
+    __syncthreads();
+    nib[2] = writeback16<8, KEEP>(X, accA, wave * 128, lane);
+    __syncthreads();
+  }
+  {  // lin3: 512 -> 253 (+3 rows that carry xyz into lin4)
+    acc_init16<8>(accA, c4, wave * 128, kq);
+    dense16_asm_k512_n4_o8(acc3, t, xaddr, voff, rs[3], rs[4], soff4, soff8, scratch);
+    __syncthreads();
+    nib[3] = writeback16<4, KEEP>(X, acc3, wave * 64, lane);
     __syncthreads();
     if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
     __syncthreads();
   }
-  {
-    f32x4 acc[8];
-    acc_init16<8>(acc, c4, wave * 128, kq);
-    dense16<256, 8>(D16.Wf[4], X, acc, wave, lane);
+  {  // lin4 (c4 in accA)
+    acc_init16<8>(accB, D.bias[5], wave * 128, kq);
+    dense16_asm_k256_n8_o8(accA, t, xaddr, voff, rs[4], rs[5], soff8, soff8, scratch);
     __syncthreads();
-    nib[4] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    nib[4] = writeback16<8, KEEP>(X, accA, wave * 128, lane);
     __syncthreads();
   }
-#pragma unroll
-  for (int l = 5; l <= 7; ++l) {
-    f32x4 acc[8];
-    acc_init16<8>(acc, D.bias[l], wave * 128, kq);
-    dense16<512, 8>(D16.Wf[l], X, acc, wave, lane);
+  {  // lin5 (accB)
+    acc_init16<8>(accA, D.bias[6], wave * 128, kq);
+    dense16_asm_k512_n8_o8(accB, t, xaddr, voff, rs[5], rs[6], soff8, soff8, scratch);
     __syncthreads();
-    nib[l] = writeback16<8, KEEP>(X, acc, wave * 128, lane);
+    nib[5] = writeback16<8, KEEP>(X, accB, wave * 128, lane);
+    __syncthreads();
+  }
+  {  // lin6 (accA)
+    acc_init16<8>(accB, D.bias[7], wave * 128, kq);
+    dense16_asm_k512_n8_o8(accA, t, xaddr, voff, rs[6], rs[7], soff8, soff8, scratch);
+    __syncthreads();
+    nib[6] = writeback16<8, KEEP>(X, accA, wave * 128, lane);
+    __syncthreads();
+  }
+  {  // lin7 (accB)
+    dense16_asm_k512_n8_o0(accB, t, xaddr, voff, rs[7], rs[7], soff8, soff8, scratch);
+    __syncthreads();
+    nib[7] = writeback16<8, KEEP>(X, accB, wave * 128, lane);
     __syncthreads();
   }
   {
@@ -938,10 +975,6 @@ constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for t
 constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per layer barrier
 #define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) xc.ts[(i)] = (long long)wall_clock64(); } while (0)
 
-struct Smem16CL : Smem16 {
-  uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
-  int32_t fail;           // != 0: this member gave up on the cluster (assembly or barrier timed out / aborted)
-};
 
 // Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
 // The A-fragments a wave needs for a layer are streamed in chunks of 16 float4 (G = 16/NBL feature groups of 16) through

@@ -192,6 +192,117 @@ __device__ __forceinline__ void %s(f32x16 (&acc)[%d][2], f32x4 (&t)[4], uint32_t
 ''' % (K, NOB, NOUT, 'the LDS bias tuples' if INIT == 'bias' else 'zero', name, NOB, body, outs, ins, ', '.join(clob))
 
 
+# =====================================================================================================================
+# 16-ray tile: v_mfma_f32_16x16x4_f32 (32 cycles), the latency-bound tail of the march. A VALU instruction costs the same 8 + 8
+# cycles beside it, i.e. twice as much relative to the MFMA, so the hand-scheduled loop pays off more here. Layout =
+# distr_mlp.hpp::dense16(): A fragments float4 index ((g*4 + wave)*NB + ob)*64 + lane (g = group of 16 features), activations
+# X[feature][16 rays], lane (j, kq) reads X[16g + 4s + kq][j] = byte offset lane*4 + (16g + 4s)*64.
+# Fixed registers: v[100:131] A0, v[132:163] A1 (NB x float4), v[164:167] B0, v[168:171] B1, v172 running LDS address.
+# The accumulators are in/out operands initialised by the caller (bias), the next layer's first group travels in t[0..NB).
+A16 = (100, 132)
+B16 = (164, 168)
+VX16 = 172
+
+
+def gen16(K, NB, NOUT):
+    NG = K // 16
+    assert NG % 2 == 0 and NG >= 4
+    NIT = (NG - 2) // 2
+    GS = 4 * NB * 1024
+    L = []
+    emit = L.append
+
+    def mfma(buf, s, ob):
+        emit('v_mfma_f32_16x16x4_f32 %%[c%d], %s, %s, %%[c%d]' % (ob, vr(A16[buf] + 4 * ob + s), vr(B16[buf] + s), ob))
+
+    S_OFF2, S_OFFN2 = 's92', 's93'        # the 12-bit immediate reaches 4 fragments; the upper four go through a second SGPR offset
+
+    def load_a(buf, ob):
+        emit('buffer_load_dwordx4 %s, %%[voff], %%[rs], %s offen offset:%d' % (vr(A16[buf] + 4 * ob, 4), S_OFF if ob < 4 else S_OFF2, (ob % 4) * 1024))
+
+    def bump():
+        emit('s_add_u32 %s, %s, %d' % (S_OFF, S_OFF, GS))
+        emit('s_add_u32 %s, %s, 4096' % (S_OFF2, S_OFF))
+
+    def load_b(buf, s, base, goff):
+        emit('ds_read_b32 %s, %s offset:%d' % (vr(B16[buf] + s), base, goff * 1024 + s * 256))
+
+    def group(cur, nxt, base, goff, loads=True, tail_prefetch=False):
+        emit('s_waitcnt vmcnt(0) lgkmcnt(0)')
+        pend = []
+        if loads:
+            pend += [('a', ob) for ob in range(NB)] + [('b', s) for s in range(4)] + [('soff',)]
+        if tail_prefetch:
+            pend += [('t', ob) for ob in range(NOUT)]
+        for s in range(4):
+            for ob in range(NB):
+                mfma(cur, s, ob)
+                if pend:
+                    p = pend.pop(0)
+                    if p[0] == 'a':
+                        load_a(nxt, p[1])
+                    elif p[0] == 'b':
+                        load_b(nxt, p[1], base, goff)
+                    elif p[0] == 'soff':
+                        bump()
+                    else:
+                        emit('buffer_load_dwordx4 %%[t%d], %%[voff], %%[rsn], %s offen offset:%d' % (p[1], '%[soffn]' if p[1] < 4 else S_OFFN2, (p[1] % 4) * 1024))
+        assert not pend
+
+    # prologue: group 1's weights first (longest latency), then this layer's first group from the operand tuples through LDS
+    emit('s_nop 4')
+    emit('s_add_u32 %s, %%[soff], %d' % (S_OFF, GS))
+    emit('s_add_u32 %s, %s, 4096' % (S_OFF2, S_OFF))
+    emit('s_add_u32 %s, %%[soffn], 4096' % S_OFFN2)
+    for ob in range(NB):
+        load_a(1, ob)
+    bump()
+    emit('s_mov_b32 %s, %d' % (S_CNT, NIT))
+    for s in range(4):
+        load_b(0, s, '%[xaddr]', 0)
+    for ob in range(NB):
+        emit('ds_write_b128 %%[scr], %%[t%d]' % ob)
+        emit('ds_read_b128 %s, %%[scr]' % vr(A16[0] + 4 * ob, 4))
+        if ob % 4 == 3 and ob + 1 < NB:
+            emit('s_waitcnt lgkmcnt(0)')                   # keep the LGKM queue below its 15 entries
+    emit('v_add_u32 %s, 1024, %%[xaddr]' % vr(VX16))
+    emit('s_waitcnt lgkmcnt(0)')
+    pend = list(range(4))
+    for s in range(4):                                     # peeled group 0 (B1 of group 1 is read on the way)
+        for ob in range(NB):
+            mfma(0, s, ob)
+            if pend and s >= 1:
+                load_b(1, pend.pop(0), '%[xaddr]', 1)
+    assert not pend
+    emit('.Ldense16_loop_%=:')
+    group(1, 0, vr(VX16), 1)
+    group(0, 1, vr(VX16), 2)
+    emit('v_add_u32 %s, 2048, %s' % (vr(VX16), vr(VX16)))
+    emit('s_sub_u32 %s, %s, 1' % (S_CNT, S_CNT))
+    emit('s_cmp_lg_u32 %s, 0' % S_CNT)
+    emit('s_cbranch_scc1 .Ldense16_loop_%=')
+    group(1, 0, vr(VX16), 0, loads=False, tail_prefetch=NOUT > 0)
+    emit('s_waitcnt vmcnt(0)')
+    emit('s_nop 7')
+    emit('s_nop 3')
+    body = '\n'.join('      "%s\\n"' % x for x in L)
+    name = 'dense16_asm_k%d_n%d_o%d' % (K, NB, NOUT)
+    outs = ', '.join('[c%d] "+v"(acc[%d])' % (ob, ob) for ob in range(NB))
+    outs += ', ' + ', '.join('[t%d] "+v"(t[%d])' % (i, i) for i in range(8))
+    ins = '[xaddr] "v"(xaddr), [voff] "v"(voff), [rs] "s"(rs), [rsn] "s"(rsn), [soff] "s"(soff), [soffn] "s"(soffn), [scr] "v"(scratch)'
+    clob = ['"v%d"' % i for i in range(A16[0], VX16 + 1)] + ['"%s"' % S_CNT, '"%s"' % S_OFF, '"s92"', '"s93"', '"scc"', '"memory"']
+    return name, '''// 16-ray tile: K = %d input features, %d row blocks of 16 per wave, fetches %d fragments of the next layer's first group
+__device__ __forceinline__ void %s(f32x4 (&acc)[%d], f32x4 (&t)[8], uint32_t xaddr, uint32_t voff, rsrc_t rs, rsrc_t rsn,
+    uint32_t soff, uint32_t soffn, uint32_t scratch) {
+  asm volatile(
+%s
+      : %s
+      : %s
+      : %s);
+}
+''' % (K, NB, NOUT, name, NB, body, outs, ins, ', '.join(clob))
+
+
 def main():
     out = ['// GENERATED by gen_dense_asm.py -- do not edit; see that file for the design notes.',
            '#pragma once', '#include <hip/hip_runtime.h>', '#include <stdint.h>', '', 'namespace distr {', '',
@@ -200,6 +311,8 @@ def main():
     for init in ('bias', 'zero'):
         for (K, NOB, NOUT) in ((512, 4, 4), (512, 4, 2), (512, 2, 4), (256, 4, 4), (512, 4, 0)):
             out.append(gen(K, NOB, NOUT, init)[1])
+    for (K, NB, NOUT) in ((512, 8, 8), (512, 8, 4), (512, 4, 8), (256, 8, 8), (512, 8, 0)):
+        out.append(gen16(K, NB, NOUT)[1])
     out.append('}  // namespace distr')
     sys.stdout.write('\n'.join(out) + '\n')
 
