@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collects the judged evidence of a round on the GPU box (run from the repo root THROUGH gpurun; everything lands in <out>/, which
+# gpurun merges back; copy what is kept into profiles/ afterwards):
+#   bench.json           default `python bench.py` (C3, 20 steps, cpu baselines)
+#   kernel_stats.md      rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu-baseline`, condensed by summarize.py
+#   pmc_fetch / pmc_write / pmc_mfma .md   separate rocprofv3 --pmc passes of the same command (never combined with tracing domains)
+#   steps_c3.md          per-launch table of one forward (tests/gpu_diag_steps.py)
+#   dense.log            dense decoder rate + in-kernel phase stamps (tests/gpu_diag_dense.py)
+#   extra_*.json         other configurations through the same bench.py
+# Usage: bash profiles/run_round.sh gpurun_out/r02_final
+set -u
+OUT=${1:-gpurun_out/round}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+python tests/gpu_diag_steps.py --out "$OUT/steps_c3.md" > /dev/null 2>&1
+python tests/gpu_diag_dense.py --stamps 2>&1 | grep -v amdgpu.ids > "$OUT/dense.log"
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+R=$(pwd)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- bash -c "cd $R && $CMD" > "$R/$OUT/rocprof_kt.log" 2>&1 )
+python profiles/summarize.py /tmp/prof_kt "$OUT/kernel_stats.md" > /dev/null 2>&1
+for P in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "l2:TCC_HIT_sum TCC_MISS_sum"; do
+  N=${P%%:*}; C=${P#*:}
+  ( cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$N -- bash -c "cd $R && $CMD" > "$R/$OUT/rocprof_$N.log" 2>&1 )
+  python profiles/summarize.py /tmp/prof_$N "$OUT/pmc_$N.md" --pmc > /dev/null 2>&1
+done
+python bench.py --loss reference --no-cpu-baseline > "$OUT/extra_c3_reference_loss.json" 2>/dev/null
+python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/extra_c5_n1.json" 2>/dev/null
+python bench.py --size 256 --no-cpu-baseline > "$OUT/extra_c2_256.json" 2>/dev/null
+python bench.py --size 64 --march-step 20 --no-cpu-baseline > "$OUT/extra_c1_64.json" 2>/dev/null
+python bench.py --marcher recursive --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/extra_c3_recursive.json" 2>/dev/null
+python bench.py --marcher trivial --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/extra_c3_trivial.json" 2>/dev/null
+python tests/gpu_diag_loop.py 64 137 224 > "$OUT/loop.log" 2>&1
+python tests/gpu_diag_multiview.py > "$OUT/multiview.log" 2>&1
+python tests/gpu_diag_grid.py > "$OUT/grid256.log" 2>&1
+ls -la "$OUT" | tail -30
