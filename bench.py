@@ -255,11 +255,13 @@ def main():
     # ---- third pass: roofline of the march kernels. Every march launch is bracketed by hipEvents on the launch stream (the
     # brackets serialise a little, which is why they are not in the timed region); algorithmic FLOP / summed kernel time
     ROOF_STEPS = min(5, max(args.steps, 1))
+    saved_streams, pool.streams = pool.streams, []       # one stream: brackets of concurrent streams would overlap and double count
     eng.ctx.profile_enable(True)
     for _ in range(ROOF_STEPS):
         step()
     launches, kernel_ms = eng.ctx.profile_read()
     eng.ctx.profile_enable(False)
+    pool.streams = saved_streams
 
     # forward / backward split of one step (outside the timed region; hipEvents on the current stream)
     def timed(fn):
