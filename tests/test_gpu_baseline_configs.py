@@ -372,3 +372,43 @@ def test_optimize_multi_view_distributed_on_hip_path():
         assert abs(r[0] - serial[0]) <= 2e-5 * abs(serial[0]), rank
         for a, b in zip(r[1:], serial[1:]):
             assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), rank
+
+
+def _rccl_worker(rank, world, port, q):
+    for p_ in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('DISTR_DIST_BACKEND', None)
+    import torch
+    from distr import parallel
+    r, w, local = parallel.init_from_env()            # backend nccl = RCCL, one GPU per rank
+    assert torch.distributed.get_backend() == 'nccl' and torch.cuda.current_device() == local
+    res, _ = _g9_round_hip(True)
+    q.put((rank, res))
+    torch.distributed.destroy_process_group()
+
+
+def test_optimize_multi_view_distributed_rccl_multi_gpu():
+    """The same shipped loop over RCCL with one GPU per rank. Needs >= 2 GPUs: skipped on the single-GPU build boxes (two RCCL
+    ranks cannot share a device), runs wherever the suite meets a multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (RCCL ranks cannot share a device)')
+    import torch.multiprocessing as mp
+    serial, g = _g9_round_hip(False)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29750 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    for rank, r in res:
+        assert abs(r[0] - serial[0]) <= 2e-5 * abs(serial[0]), rank
+        for a, b in zip(r[1:], serial[1:]):
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), rank
