@@ -30,6 +30,7 @@ A = (176, 192)
 B = (208, 216)
 VX = 224
 BIAS = (128, 144, 160)
+ACC_VGPR = False     # measured: VGPR accumulators (no v_accvgpr_read in the write-back) change nothing -- the write-back is bound by LDS write bandwidth + its two barriers (2.1 k cycles per layer either way) and only raise register pressure
 S_CNT, S_OFF = 's90', 's91'
 TILE = 64
 
@@ -39,7 +40,7 @@ def vr(lo, n=1):
 
 
 def ar(lo, n):
-    return 'a[%d:%d]' % (lo, lo + n - 1)
+    return ('v[%d:%d]' if ACC_VGPR else 'a[%d:%d]') % (lo, lo + n - 1)
 
 
 def gen(K, NOB, NOUT, INIT):
@@ -176,10 +177,10 @@ def gen(K, NOB, NOUT, INIT):
     body = '\n'.join('      "%s\\n"' % x for x in L)
 
     name = 'dense_asm_k%d_n%d_o%d_%s' % (K, NOB, NOUT, INIT)
-    outs = ', '.join('[c%d%d] "=&a"(acc[%d][%d])' % (ob, rb, ob, rb) for ob in range(NOB) for rb in range(2))
+    outs = ', '.join('[c%d%d] "=&%s"(acc[%d][%d])' % (ob, rb, 'v' if ACC_VGPR else 'a', ob, rb) for ob in range(NOB) for rb in range(2))
     outs += ', ' + ', '.join('[t%d] "+v"(t[%d])' % (i, i) for i in range(4))
     ins = '[xaddr] "v"(xaddr), [voff] "v"(voff), [rs] "s"(rs), [rsn] "s"(rsn), [soff] "s"(soff), [soffn] "s"(soffn), [bias] "v"(biasaddr), [scr] "v"(scratch)'
-    clob = ['"v%d"' % i for i in range(A[0], VX + 1)] + ['"a%d"' % i for i in range(BIAS[0], BIAS[2] + 16)] + ['"%s"' % S_CNT, '"%s"' % S_OFF, '"scc"', '"memory"']
+    clob = ['"v%d"' % i for i in range(A[0], VX + 1)] + ['"%s%d"' % ('v' if ACC_VGPR else 'a', i) for i in range(BIAS[0], BIAS[2] + 16)] + ['"%s"' % S_CNT, '"%s"' % S_OFF, '"scc"', '"memory"']
     return name, '''// K = %d input features, %d row blocks of 32 per wave, fetches %d fragments of the next layer's first group, accumulators start from %s
 __device__ __forceinline__ void %s(f32x16 (&acc)[%d][2], f32x4 (&t)[4], uint32_t xaddr, uint32_t voff, rsrc_t rs, rsrc_t rsn,
     uint32_t soff, uint32_t soffn, uint32_t biasaddr, uint32_t scratch) {
