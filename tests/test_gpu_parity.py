@@ -446,6 +446,7 @@ def test_bulk_sdf_grid(cpu_oracle, fixture_decoder):
         want = cpu_oracle.decode_sdf(latent, ref_samples(n, 2.0 / (n - 1), transform), clamp_dist=0.1).reshape(n, n, n)
         got = create_sdf_grid(dec, lat, n, transform=transform).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-7, transform
+        n = 96          # (below ~N = 64 the band 1.5 * coarse voxel exceeds the 0.1 clamp: every point is re-evaluated, as in the reference)
         want_s, nvalid = ref_speedup(n, transform)
         got_s = create_sdf_grid_speedup(dec, lat, n, transform=transform).cpu().numpy()
         assert 0 < nvalid < n ** 3 // 2
