@@ -70,12 +70,13 @@ def decode_sdf_gradient(decoder, latent_vector, points, clamp_dist=0.1, MAX_POIN
 
 
 def decode_color(decoder, color_code, shape_code, points, MAX_POINTS=100000, no_grad=False):
-    """(n,3) surface points -> (n,3) rgb of the colour decoder (decoder_utils.py:94-112). Forward-only, like every use in
-    the reference (demo/demo_360.py): no gradient reaches the codes or the points."""
-    if (not no_grad) and torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (color_code, shape_code, points)):
-        raise NotImplementedError('decode_color is forward-only here; pass no_grad=True or wrap in torch.no_grad().')
+    """(n,3) surface points -> (n,3) rgb of the colour decoder (decoder_utils.py:94-112); differentiable w.r.t. the colour code,
+    the shape code and the points unless `no_grad` (distr_color_backward). MAX_POINTS chunking is unnecessary (accepted, ignored)."""
     dev = points.device
     if dev.type != 'cuda':
         raise RuntimeError('decode_color: tensors must be on the GPU (no CPU path in this build)')
     eng = functions.get_color_engine(decoder, dev.index if dev.index is not None else torch.cuda.current_device())
+    needs = (not no_grad) and torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (color_code, shape_code, points))
+    if needs:
+        return functions.color_eval_autograd(eng, color_code, shape_code, points)
     return functions.color_eval(eng, color_code, shape_code, points)

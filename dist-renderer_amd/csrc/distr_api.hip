@@ -465,6 +465,32 @@ int distr_color_eval(distr_ctx* ctx, const float* latent_cat, const float* xyz, 
 }
 
 
+int distr_color_backward(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, const float* g_rgb, float* g_xyz,
+                         float* g_latent_cat, void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  if (!ctx->has_color) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_color_decoder has not been called");
+  if (n < 0 || !latent_cat || (n > 0 && (!xyz || !g_rgb)) || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  if (ws_bytes < distr_mlp_backward_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "colour backward workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (g_latent_cat) HIP_TRY(hipMemsetAsync(g_latent_cat, 0, (size_t)ctx->DC.nlat * sizeof(float), s));
+    return DISTR_OK;
+  }
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  float* partial = (float*)(((uintptr_t)(c0c4 + 2 * HID) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->DC, latent_cat);
+  LAUNCH_CHECK("k_latent_consts");
+  const unsigned tiles = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(k_color_bwd, dim3(tiles), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, g_rgb, g_xyz, partial, ctx->DC);
+  LAUNCH_CHECK("k_color_bwd");
+  if (g_latent_cat) {
+    hipLaunchKernelGGL(k_points_latent_grad, dim3(1), dim3(256), 0, s, (const float*)partial, (int)tiles, ctx->DC, g_latent_cat);
+    LAUNCH_CHECK("k_points_latent_grad");
+  }
+  return DISTR_OK;
+}
+
 int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* fwd, size_t* bwd) {
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;

@@ -815,6 +815,48 @@ __global__ void __launch_bounds__(256, 1) k_color(const float* __restrict__ xyz,
   }
 }
 
+// Backward of decode_color (decoder_utils.py:94-112 differentiated by autograd in the reference): recompute the colour decoder's
+// forward for a tile of 64 points keeping the ReLU masks, d8_c = g_rgb_c * (1 - rgb_c^2), dX chain with the 3-row lin8, per-tile
+// delta sums for the [shape | colour] code gradient, d rgb / d xyz per point.
+__global__ void __launch_bounds__(256, 1) k_color_bwd(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
+                                                      const float* __restrict__ g_rgb, float* __restrict__ g_xyz, float* __restrict__ partial,
+                                                      DecoderDev D) {
+  constexpr int RB = 2, TILE = 64;
+  __shared__ Smem<RB> S;
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  if (base >= n) return;
+  const bool valid = tid < TILE && base + tid < n;
+  if (tid < TILE) {
+    S.xyz[tid] = valid ? xyz[(base + tid) * 3] : 0.f; S.xyz[TILE + tid] = valid ? xyz[(base + tid) * 3 + 1] : 0.f;
+    S.xyz[2 * TILE + tid] = valid ? xyz[(base + tid) * 3 + 2] : 0.f;
+  }
+  __syncthreads();
+  uint32_t masks[8][4];
+  float pre[3];
+  pre[0] = mlp_forward<RB, true>(D, c0c4, c0c4 + HID, S, masks);
+#pragma unroll
+  for (int c = 1; c < 3; ++c) {
+    __syncthreads();
+    pre[c] = lin8_row<RB>(D.w8 + c * HID, D.b8x[c - 1], S);
+  }
+  __syncthreads();
+  if (tid < TILE) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float y = tanh_spec(pre[c]);
+      S.aux[c * TILE + tid] = valid ? g_rgb[(base + tid) * 3 + c] * __builtin_fmaf(-y, y, 1.0f) : 0.f;
+    }
+  }
+  __syncthreads();
+  float* part = partial + (size_t)blockIdx.x * PSTRIDE;
+  mlp_backward<RB, 3>(D, S, masks, part, part + HID);
+  if (g_xyz && valid) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g_xyz[(base + tid) * 3 + c] = S.aux[(1 + c) * TILE + tid];
+  }
+}
+
 // test/debug only: post-activation of layer `layer` for n points -> out[n][512] (see tests/test_gpu_parity.py)
 template <int RB>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const float* xyz, int64_t n, const float* c0c4, int layer,
@@ -1371,17 +1413,19 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial
 // decode_sdf backward (explicit points): ordered column sums of the tile partials, then g_latent as in k_bwd_final
 __global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial, int ntiles, DecoderDev D, float* g_latent) {
   __shared__ float red[2 * HID];
-  const int k = threadIdx.x;
-  for (int col = k; col < 2 * HID; col += 256) {
+  for (int col = threadIdx.x; col < 2 * HID; col += 256) {
     float s = 0.f;
     for (int t = 0; t < ntiles; ++t) s += partial[(size_t)t * PSTRIDE + col];
     red[col] = s;
   }
   __syncthreads();
-  float a = 0.f;
+  const int nlat = D.nlat;                           // 256 (SDF decoder) or 256 + color_size (colour decoder)
+  for (int k = threadIdx.x; k < nlat; k += 256) {
+    float a = 0.f;
 #pragma unroll 16
-  for (int o = 0; o < HID; ++o) a += D.W0lat[o * LAT + k] * red[o] + D.W4lat[o * LAT + k] * red[HID + o];
-  g_latent[k] = a;
+    for (int o = 0; o < HID; ++o) a += D.W0lat[(size_t)o * nlat + k] * red[o] + D.W4lat[(size_t)o * nlat + k] * red[HID + o];
+    g_latent[k] = a;
+  }
 }
 
 // g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)

@@ -580,7 +580,9 @@ __device__ __forceinline__ void row_sums(const float* X, float* __restrict__ dst
   }
 }
 
-template <int RB>
+// NOUT: rows of lin8 (1: SDF decoder; 3: colour decoder -- then S.aux rows 0..2 hold the three d8 rows and
+// delta7 = relu'(h7) * sum_c w8[c][k] * d8_c, accumulated in channel order)
+template <int RB, int NOUT = 1>
 __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, uint32_t (&masks)[8][4],
                                              float* __restrict__ sd0, float* __restrict__ sd4) {
   constexpr int TILE = 32 * RB;
@@ -592,18 +594,24 @@ __device__ __forceinline__ void mlp_backward(const DecoderDev& D, Smem<RB>& S, u
   float* X = S.X;
   // delta7[k][ray] = relu'(h7) * w8[k] * d8[ray]
   {
-    float d8[RB];
+    float d8[NOUT][RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) d8[rb] = S.aux[32 * rb + j];
+    for (int c = 0; c < NOUT; ++c)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) d8[c][rb] = S.aux[c * TILE + 32 * rb + j];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
       const uint32_t m = masks[7][ob];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wave * 128 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float w = D.w8[row];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) X[row * TILE + 32 * rb + j] = gate(w * d8[rb], (m >> (16 * rb + r)) & 1u);
+        for (int rb = 0; rb < RB; ++rb) {
+          float v = D.w8[row] * d8[0][rb];
+#pragma unroll
+          for (int c = 1; c < NOUT; ++c) v = __builtin_fmaf(D.w8[c * HID + row], d8[c][rb], v);
+          X[row * TILE + 32 * rb + j] = gate(v, (m >> (16 * rb + r)) & 1u);
+        }
       }
     }
   }

@@ -22,7 +22,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
            'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward',
-           'distr_profile_read_list', 'distr_get_live_counts']
+           'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward']
 
 
 class DistrError(RuntimeError):
@@ -138,6 +138,7 @@ def lib():
             L.distr_warp_loss_backward.argtypes = [vp, C.POINTER(WarpCfg), fp, u8p, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
             L.distr_set_color_decoder.argtypes = [vp, C.POINTER(DecoderDesc), C.POINTER(C.c_float), C.c_size_t]
             L.distr_color_eval.argtypes = [vp, fp, fp, C.c_int64, fp, vp, C.c_size_t, vp]
+            L.distr_color_backward.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp, vp, C.c_size_t, vp]
             L.distr_debug_xchg_ts.argtypes = [vp, vp, C.POINTER(C.c_int64)]
             L.distr_mlp_backward_workspace_bytes.argtypes = [C.c_int64]
             L.distr_mlp_backward_workspace_bytes.restype = C.c_size_t

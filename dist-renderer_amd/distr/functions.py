@@ -121,6 +121,42 @@ def color_eval(engine, color_code, shape_code, points):
     return out
 
 
+class ColorDecodeFunction(torch.autograd.Function):
+    """decode_color with autograd (decoder_utils.py:94-112 called with no_grad=False): (color_code (1,cs), shape_code (1,256),
+    points (n,3)) -> rgb (n,3); backward = distr_color_backward (fused forward recompute + dX chain with the 3-row output layer;
+    the code gradients come from the per-tile delta sums)."""
+
+    @staticmethod
+    def forward(ctx, color_code, shape_code, points, engine):
+        out = color_eval(engine, color_code, shape_code, points)
+        ctx.engine = engine
+        ctx.save_for_backward(color_code.detach(), shape_code.detach(), points.detach())
+        ctx.need = (color_code.requires_grad, shape_code.requires_grad, points.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        engine = ctx.engine
+        dev = engine.device
+        color_code, shape_code, points = ctx.saved_tensors
+        lat = torch.cat([_f32c(shape_code, dev).reshape(-1), _f32c(color_code, dev).reshape(-1)])
+        x = _f32c(points, dev).reshape(-1, 3)
+        n = x.shape[0]
+        gs = _f32c(g, dev).reshape(-1, 3)
+        g_x = torch.empty(n, 3, dtype=torch.float32, device=dev) if ctx.need[2] else None
+        g_l = torch.empty(engine.latent_size, dtype=torch.float32, device=dev) if (ctx.need[0] or ctx.need[1]) else None
+        ws = torch.empty(engine.ctx.L.distr_mlp_backward_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_color_backward(engine.ctx.h, p(lat), p(x), n, p(gs), p(g_x), p(g_l), p(ws), ws.numel(), engine.ctx.stream()))
+        ns = shape_code.numel()
+        return ((g_l[ns:].reshape(color_code.shape) if ctx.need[0] else None), (g_l[:ns].reshape(shape_code.shape) if ctx.need[1] else None),
+                (g_x.reshape(points.shape) if ctx.need[2] else None), None)
+
+
+def color_eval_autograd(engine, color_code, shape_code, points):
+    return ColorDecodeFunction.apply(color_code, shape_code, points, engine)
+
+
 def _f32c(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 

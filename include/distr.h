@@ -185,13 +185,19 @@ int distr_debug_xchg_ts(distr_ctx* ctx, void* stream, int64_t* out64);
 /* ---- Colour decoder: SDFRenderer_color.render_color (core/sdfrenderer/renderer_rgb.py:20-38) evaluates
  * a second DeepSDF-8x512-shaped decoder with latent = [shape code | colour code] (256 + color_size) and last_dim = 3
  * (load_decoder(color_size=...), core/utils/decoder_utils.py:16-24) at the surface points; decode_color
- * (decoder_utils.py:94-112). Forward only, like the reference's demo use (demo/demo_360.py). Weights: same flat layout as
+ * (decoder_utils.py:94-112). Weights: same flat layout as
  * distr_set_decoder with lin0 (512, 259+cs), lin4 (512, 512+cs), lin8 (3, 512); desc->latent_size = 256 + cs. */
 int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* weights, size_t n_floats);
 /* latent_cat[256+cs] = cat(shape_code, color_code) (device), xyz[n][3] -> rgb[n][3] = tanh(lin8(...)). Workspace:
  * distr_mlp_workspace_bytes(n). */
 int distr_color_eval(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, float* rgb, void* ws, size_t ws_bytes,
                      void* stream);
+
+/* Backward of distr_color_eval (decode_color differentiated, decoder_utils.py:94-112 with no_grad=False): g_rgb[n][3] = upstream
+ * gradient of the colours; writes g_xyz[n][3] = d/d points (may be null) and g_latent_cat[256+cs] = d/d [shape code | colour code]
+ * (may be null). Workspace: distr_mlp_backward_workspace_bytes(n). */
+int distr_color_backward(distr_ctx* ctx, const float* latent_cat, const float* xyz, int64_t n, const float* g_rgb, float* g_xyz,
+                         float* g_latent_cat, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Image-space consumers right after the hot path, fused into a few element-wise
  * kernels. Same rules as above: caller-owned device buffers, everything enqueued on `stream`, no host sync. Scalars

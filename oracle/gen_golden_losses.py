@@ -217,6 +217,35 @@ def golden_g11():
     print('g11', {k: float(np.abs(v).max()) for k, v in out.items()}, 'clamped pts', int((np.abs(out['sdf_raw']) > 0.1).sum()))
 
 
+def golden_g13():
+    """G13: the reference's decode_color (decoder_utils.py:94-112) differentiated by autograd w.r.t. the colour code, the shape code
+    and the points, with seeded per-point upstream gradients (colour decoder fixture of G10)."""
+    rh.install_shims()
+    mods = rh.reference_modules()
+    Decoder, decoder_utils = mods[2], mods[3]
+    _, _, latent = fixture.make_decoder_weights()
+    cs = 256
+    Wc, bc, color_code = fixture.make_color_decoder_weights(color_size=cs)
+    dims = [512] * 8
+    dims[3] += cs
+    dec_c = Decoder(256 + cs, dims, last_dim=3, dropout=list(range(8)), dropout_prob=0.2, norm_layers=(), latent_in=[4])
+    dec_c.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a.copy()) for l, (W, b) in enumerate(zip(Wc, bc))
+                           for n, a in (('weight', W), ('bias', b))})
+    dec_c.eval()
+    rs = np.random.RandomState(33)
+    pts = (rs.rand(333, 3) * 1.4 - 0.7).astype(np.float32)
+    wts = rs.standard_normal((333, 3)).astype(np.float32)
+    cc = torch.from_numpy(color_code).clone().requires_grad_(True)
+    sc = torch.from_numpy(latent).clone().requires_grad_(True)
+    x = torch.from_numpy(pts).clone().requires_grad_(True)
+    rgb = decoder_utils.decode_color(dec_c, cc, sc, x)
+    (rgb * torch.from_numpy(wts)).sum().backward()
+    np.savez_compressed(os.path.join(OUT, 'g13_decode_color_grad.npz'), color_weights_sha256=fixture.weights_sha256(Wc, bc), color_size=cs,
+                        latent=latent, color_code=color_code, points=pts, weights=wts, rgb=rgb.detach().numpy(), g_color_code=cc.grad.numpy(),
+                        g_shape_code=sc.grad.numpy(), g_points=x.grad.numpy())
+    print('g13', float(rgb.abs().max()), float(cc.grad.abs().max()), float(sc.grad.abs().max()), float(x.grad.abs().max()))
+
+
 def golden_g12():
     """G12: SDFRenderer.render(num_forward_sampling=3) (renderer.py:912-941, 982-985): the k samples behind the surface and the
     gradients of a seeded weighted sum of them w.r.t. the latent code and the camera."""
@@ -290,6 +319,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if sys.argv[1:2] == ['--g12']:
         golden_g12()
+        sys.exit(0)
+    if sys.argv[1:2] == ['--g13']:
+        golden_g13()
         sys.exit(0)
     if sys.argv[1:2] != ['--g9']:
         golden_g7()

@@ -1061,6 +1061,47 @@ def test_many_streams_with_cluster_tiles(engine, fixture_decoder):
 
 
 @pytest.mark.gpu
+def test_decode_color_autograd_matches_reference_golden():
+    """G13: decode_color differentiated (distr_color_backward: fused forward recompute + dX chain through the 3-row output layer)
+    against the reference's autograd: gradients w.r.t. the colour code, the shape code and the points; ragged sizes against
+    autograd through the module itself."""
+    import torch
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.utils.decoder_utils import decode_color
+    from distr import fixture
+    g = dict(np.load(os.path.join(GOLDEN, 'g13_decode_color_grad.npz')))
+    cs = int(g['color_size'])
+    Wc, bc, _ = fixture.make_color_decoder_weights(color_size=cs)
+    dims = [512] * 8
+    dims[3] += cs
+    dec = Decoder(256 + cs, dims, last_dim=3, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Wc, bc)) for n, a in (('weight', W), ('bias', b))})
+    dec = dec.cuda()
+    c = lambda k: torch.from_numpy(g[k]).cuda().requires_grad_(True)
+    cc, sc, x = c('color_code'), c('latent'), c('points')
+    rgb = decode_color(dec, cc, sc, x)
+    assert rgb.requires_grad and np.abs(rgb.detach().cpu().numpy() - g['rgb']).max() <= 2e-6
+    (rgb * torch.from_numpy(g['weights']).cuda()).sum().backward()
+    err = np.abs(x.grad.cpu().numpy() - g['g_points']).max(1)
+    nbad = int((err > 2e-5 * np.abs(g['g_points']).max()).sum())
+    rc = np.abs(cc.grad.cpu().numpy() - g['g_color_code']).max() / np.abs(g['g_color_code']).max()
+    rs_ = np.abs(sc.grad.cpu().numpy() - g['g_shape_code']).max() / np.abs(g['g_shape_code']).max()
+    print('G13: points off by > 2e-5: %d of 333; g_color_code residual %.3e, g_shape_code residual %.3e' % (nbad, rc, rs_))
+    assert nbad <= 1 and rc <= (2e-3 if nbad else 5e-5) and rs_ <= (2e-3 if nbad else 5e-5)
+    for n in (1, 63, 65, 130):
+        cc2, sc2 = torch.from_numpy(g['color_code']).cuda().requires_grad_(True), torch.from_numpy(g['latent']).cuda()
+        x2 = torch.from_numpy(g['points'][:n]).cuda().requires_grad_(True)
+        decode_color(dec, cc2, sc2, x2)[:, 1].sum().backward()
+        cr, xr = torch.from_numpy(g['color_code']).cuda().requires_grad_(True), torch.from_numpy(g['points'][:n]).cuda().requires_grad_(True)
+        dec.inference(torch.cat([sc2.expand(n, -1), cr.expand(n, -1), xr], 1))[:, 1].sum().backward()
+        assert (x2.grad - xr.grad).abs().max() <= 5e-5 * xr.grad.abs().max() + 1e-7
+        assert (cc2.grad - cr.grad).abs().max() <= 1e-4 * cr.grad.abs().max()
+    with torch.no_grad():
+        assert not decode_color(dec, cc, sc, x).requires_grad
+    assert not decode_color(dec, cc, sc, x, no_grad=True).requires_grad
+
+
+@pytest.mark.gpu
 def test_forward_sampling_matches_reference_golden(fixture_decoder):
     """G12: render(num_forward_sampling=3) -- the k samples behind the surface (renderer.py:912-941) and the gradients of a
     weighted sum of them w.r.t. latent and camera, against the reference."""
