@@ -129,6 +129,9 @@ def main():
                          'vectors; the heaviest backward: every in-sphere ray carries a gradient sample); reference: the single-view '
                          'loss of run_single_shape.py:93-98 against a ground truth rendered once from a perturbed latent')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU (c5 at N <= 4)')
+    ap.add_argument('--no-balance', action='store_true',
+                    help='c3 at N > 1: keep exactly one whole view per GPU (default: after the warm-up the ranks exchange their step times and '
+                         'the slowest views hand row bands to the fastest ranks, distr.parallel.balance_views)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
@@ -210,7 +213,13 @@ def main():
             outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
         return image_loss(outs, r0, r1, (shape, v))
 
-    def step():
+    last = {}              # gradients of the most recent step (reported as a norm: lets two runs be compared)
+    local_ms = []          # (calibration only) GPU milliseconds of this rank's own work of a step, without the wait in the all-reduce
+
+    def step(measure=False):
+        if measure:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for l in lats:
             l.grad = None
         for (Rt, Tt) in cams.values():
@@ -222,15 +231,38 @@ def main():
         for L in losses[1:]:
             total = total + L
         total.backward()
+        if measure:
+            e1.record()
+            e1.synchronize()
+            local_ms.append(e0.elapsed_time(e1))
         loss_buf.copy_(total.detach().reshape(1))
         for l in lats:
             if l.grad is None:
                 l.grad = zero_grad.clone()
         parallel.allreduce_packed([l.grad for l in lats] + [loss_buf])   # one RCCL all-reduce: [latent grads | loss]
+        last['grads'] = [l.grad for l in lats]
         return total
 
-    for _ in range(args.warmup):
-        step()
+    # ---- warm-up. View-parallel runs (c3, N > 1, dense loss) use it to balance the views: the eight cameras differ by up to 25 % in cost
+    # and every step ends in the all-reduce, so the slowest view would pace the job. The ranks all-gather their own step times, every rank
+    # computes the same plan (distr.parallel.balance_views), and the slowest views hand row bands (bit-identical to the same rows of
+    # the full render, gradients sum exactly) to the fastest ranks. Total work is unchanged: N whole views per step.
+    balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and args.warmup >= 3
+    plan = None
+    for w in range(args.warmup):
+        step(measure=balance and w < args.warmup - 1)
+        if balance and w == args.warmup - 2:
+            mine = float(np.median(local_ms[1:])) if len(local_ms) > 1 else local_ms[0]
+            fake = os.environ.get('DISTR_BENCH_FAKE_TIMES')          # tests: force a plan on a box where the ranks share one GPU
+            times = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(mine, device=dev)
+            plan = parallel.balance_views(times, H)
+            view_of = lambda r: (r + args.view_offset) % 8
+            items[:] = [(0, view_of(v), r0, r1) for (v, r0, r1) in plan[rank]]
+            for (_, v, _, _) in items:
+                if v not in cams:
+                    R, T = view_camera(fixture, v)
+                    cams[v] = (torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True))
+            pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
     # ---- the timed region: exactly K steps between barrier + synchronize on both sides; nothing is recorded inside it
     torch.cuda.synchronize()
     parallel.barrier()
@@ -262,6 +294,8 @@ def main():
     launches, kernel_ms = eng.ctx.profile_read()
     eng.ctx.profile_enable(False)
     pool.streams = saved_streams
+
+    grad_norm = float(sum(float(g.norm()) for g in last['grads']))
 
     # forward / backward split of one step (outside the timed region; hipEvents on the current stream)
     def timed(fn):
@@ -323,8 +357,9 @@ def main():
                                                          args.marcher, BUFFER_SIZE, RATIO,
                                                          'dense per-pixel' if args.loss == 'dense' else 'reference single-view',
                                                          'fixed total work split shape-major then in row bands' if c5 else '1 view per GPU'),
-                       'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + ' (RCCL all-reduce of packed latent grad)',
-                       'rank0_items': [list(it) for it in items],
+                       'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
+                       'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'loss_sum_all_ranks': float(loss_buf.item()),
+                       'latent_grad_norm_all_ranks': grad_norm,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
                        'decoder_evals_per_step_rank0': stats['num_point_evals'],
                        'march_launches_per_step_rank0': stats['num_march_launches'],

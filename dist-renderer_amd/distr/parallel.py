@@ -96,6 +96,54 @@ def allreduce_grads(params, scalars=(), group=None):
     return out
 
 
+def balance_views(times, H, align=4, min_rows=16, halo_rows=8, tolerance=0.02):
+    """Row-band load balancing of a view-parallel step. `times[r]` = seconds rank r needs for ITS view (one H-row view per rank);
+    the views are not equally expensive (number of rays that graze the surface), and every step ends in the gradient all-reduce,
+    so the slowest view paces the job. Ranks above the mean hand the bottom rows of their view to ranks below it, as row bands
+    (multiples of `align` = 4 rows: a band renders bit-identically to the same rows of the full image, distr.functions.
+    render_band_call; the receiver also pays `halo_rows` of depth2normal halo). Pure function of `times`, so every rank computes the
+    same plan from the all-gathered times. Returns plan[r] = [(view, r0, r1), ...] (first entry: what is left of the rank's own view);
+    every row of every view appears exactly once. Views within `tolerance` of the mean are left alone."""
+    N = len(times)
+    plan = [[(r, 0, H)] for r in range(N)]
+    if N < 2 or min(times) <= 0:
+        return plan
+    mean = sum(times) / N
+    excess = [t - mean for t in times]
+    if max(excess) <= tolerance * mean:
+        return plan
+    rows_left = [H] * N
+    donors = sorted((r for r in range(N) if excess[r] > 0), key=lambda r: (-excess[r], r))
+    receivers = sorted((r for r in range(N) if excess[r] < 0), key=lambda r: (excess[r], r))
+    deficit = {r: -excess[r] for r in receivers}
+    extra = [[] for _ in range(N)]
+    for d in donors:
+        per_row = times[d] / H
+        ex = excess[d]
+        for r in receivers:
+            if ex < min_rows * per_row:
+                break
+            k = int(min(ex, deficit[r] - halo_rows * per_row) / per_row) // align * align
+            k = min(k, rows_left[d] - H // 2)          # a view keeps at least half of its rows
+            if k < min_rows:
+                continue
+            extra[r].append((d, rows_left[d] - k, rows_left[d]))
+            rows_left[d] -= k
+            ex -= k * per_row
+            deficit[r] -= (k + halo_rows) * per_row
+    return [[(r, 0, rows_left[r])] + extra[r] for r in range(N)]
+
+
+def allgather_scalar(value, device=None, group=None):
+    """[value of rank 0, ..., value of rank N-1] on every rank (one tiny all-gather)."""
+    if not is_distributed(group):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]
+
+
 def allreduce_packed(tensors, group=None):
     """Sums every tensor of `tensors` over all ranks with ONE all-reduce of a packed flat f32 buffer (in place)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

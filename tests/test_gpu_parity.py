@@ -942,6 +942,37 @@ def test_bench_two_ranks_on_one_gpu(workload):
 
 
 @pytest.mark.gpu
+def test_bench_view_balancing_two_ranks():
+    """bench.py's row-band load balancing of the view-parallel step (distr.parallel.balance_views): two ranks sharing this GPU
+    (gloo), step times forced to 70 / 40 ms so that rank 0 hands the bottom rows of its view to rank 1. The all-reduced loss and
+    latent gradient of a step must equal the unbalanced run's (the work moved, nothing else)."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    outs = []
+    for extra, fake in ((['--no-balance'], None), ([], '70,40')):
+        env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if fake:
+            env['DISTR_BENCH_FAKE_TIMES'] = fake
+        port = 29860 + (os.getpid() % 60) + len(outs)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--size', '192',
+               '--march-step', '30'] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
+    plain, bal = outs
+    assert plain['config']['balance_plan'] is None and plain['config']['rank0_items'] == [[0, 0, 0, 192]]
+    plan = bal['config']['balance_plan']
+    assert plan[0] == [[0, 0, 160]] and plan[1] == [[1, 0, 192], [0, 160, 192]], plan
+    assert bal['config']['rank0_items'] == [[0, 0, 0, 160]] and 'load balancing' in bal['config']['parallelism']
+    a, b = plain['config']['loss_sum_all_ranks'], bal['config']['loss_sum_all_ranks']
+    assert abs(a - b) <= 1e-5 * abs(a), (a, b)
+    ga, gb = plain['config']['latent_grad_norm_all_ranks'], bal['config']['latent_grad_norm_all_ranks']
+    assert abs(ga - gb) <= 1e-4 * abs(ga), (ga, gb)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(8))
 def test_random_configs_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
     """Seeded random draws over image size (ragged), steps, buffer_size, ratio, marcher, normal mode and camera: HIP vs

@@ -329,3 +329,28 @@ def test_compute_loss_color_and_mask_visualizer():
     miss, extra = (m2 & ~m1).numpy(), (m1 & ~m2).numpy()
     assert abs(float(lg) - np.maximum(q.numpy()[miss] - 5e-5, 0).mean()) < 1e-9
     assert abs(float(lo) - np.maximum(5e-5 - q.numpy()[extra], 0).mean()) < 1e-9
+
+
+def test_balance_views_plan():
+    """distr.parallel.balance_views: a pure function of the gathered step times; every row of every view is assigned exactly once,
+    bands are 4-row aligned, the estimated maximum drops, balanced inputs are left alone."""
+    from distr import parallel
+    H = 512
+    times = [56.4, 57.9, 54.6, 53.8, 51.3, 49.8, 53.1, 63.4]          # the eight C4 cameras, ms per step (profiles/README.md)
+    plan = parallel.balance_views(times, H)
+    cover = np.zeros((8, H), np.int32)
+    est = []
+    for r, items in enumerate(plan):
+        assert items[0][0] == r and items[0][1] == 0
+        t = 0.0
+        for (v, r0, r1) in items:
+            assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H) and r1 - r0 >= 16
+            cover[v, r0:r1] += 1
+            t += (r1 - r0 + (8 if v != r else 0)) * times[v] / H
+        est.append(t)
+    assert (cover == 1).all()
+    assert max(est) < 0.93 * max(times) and plan == parallel.balance_views(list(times), H)
+    assert parallel.balance_views([50.0, 50.5], H) == [[(0, 0, H)], [(1, 0, H)]]
+    assert parallel.balance_views([60.0], H) == [[(0, 0, H)]]
+    two = parallel.balance_views([70.0, 40.0], 192)
+    assert two == [[(0, 0, 160)], [(1, 0, 192), (0, 160, 192)]]
