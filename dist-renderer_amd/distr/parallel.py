@@ -138,6 +138,8 @@ def allgather_scalar(value, device=None, group=None):
     """[value of rank 0, ..., value of rank N-1] on every rank (one tiny all-gather)."""
     if not is_distributed(group):
         return [float(value)]
+    if str(dist.get_backend(group)) != 'nccl':        # gloo has no device all-gather
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, t, group=group)

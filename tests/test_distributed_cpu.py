@@ -43,6 +43,15 @@ def _worker(rank, world, port, q):
     parallel.allreduce_packed([g, loss, cover])
     assert bool((cover[:, :70] == 1).all()) and bool((cover[:, 70:] == 0).all())
     mx = parallel.allreduce_max_scalar(float(rank))
+    # the view balancer: every rank gathers all step times and derives the same plan; its pieces tile every view once
+    times = parallel.allgather_scalar(70.0 if rank == 0 else 40.0)
+    assert times == [70.0, 40.0]
+    plan = parallel.balance_views(times, 192)
+    rows = torch.zeros(2, 192)
+    for (v, r0, r1) in plan[rank]:
+        rows[v, r0:r1] += 1
+    parallel.allreduce_packed([rows])
+    assert bool((rows == 1).all()) and len(plan[1]) == 2
     parallel.barrier()
     q.put((rank, g.numpy().copy(), float(loss), mx))
     dist.destroy_process_group()
