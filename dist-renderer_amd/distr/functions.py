@@ -2,7 +2,7 @@
 
 Replaces the autograd tape the reference records through ~50 decode_sdf calls per render
 (core/sdfrenderer/renderer.py:382-420, 836-878): the forward keeps O(buffer_size) selected rows per ray
-in the workspace tensor, the backward kernel recomputes the decoder at exactly those points.
+in the workspace tensor together with the ReLU masks of those rows, the backward kernel runs the dX chain at exactly those points.
 """
 import ctypes as C
 import weakref
@@ -190,6 +190,7 @@ class RenderFunction(torch.autograd.Function):
             p(ws), ws.numel(), engine.ctx.stream()))
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes = engine, cfg, ws, bwd_bytes
         ctx.shapes = (latent.shape, R.shape, T.shape)
+        ctx.in_meta = tuple((t.device, t.dtype) for t in (latent, R, T))
         ctx.mark_non_differentiable(mask)
         return zdepth, mask, min_sdf, depth, normal
 
@@ -215,7 +216,8 @@ class RenderFunction(torch.autograd.Function):
             p(ws_b), ws_b.numel(), engine.ctx.stream()))
         ctx.last_ws = ws
         ls, rs, ts = ctx.shapes
-        return g_lat.reshape(ls), g_R.reshape(rs), g_T.reshape(ts), None, None
+        # gradients go back in the inputs' own device / dtype (a host-resident or f64 camera tensor keeps working)
+        return tuple(g.reshape(sh).to(device=d, dtype=dt) for g, sh, (d, dt) in zip((g_lat, g_R, g_T), (ls, rs, ts), ctx.in_meta)) + (None, None)
 
 
 def render_call(engine, cfg, latent, R, T):

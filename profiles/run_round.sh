@@ -33,4 +33,9 @@ python bench.py --marcher trivial --steps 3 --warmup 1 --no-cpu-baseline > "$OUT
 python tests/gpu_diag_loop.py 64 137 224 > "$OUT/loop.log" 2>&1
 python tests/gpu_diag_multiview.py > "$OUT/multiview.log" 2>&1
 python tests/gpu_diag_grid.py > "$OUT/grid256.log" 2>&1
+# cost of each of the eight C4 views on one GPU -> the row-band plan bench.py --gpus 8 would derive from them (view_balance.md)
+for V in 0 1 2 3 4 5 6 7; do
+  python bench.py --view-offset $V --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/view_$V.json" 2>/dev/null
+done
+python profiles/view_balance.py "$OUT" > "$OUT/view_balance.md" 2>&1
 ls -la "$OUT" | tail -30
