@@ -44,7 +44,7 @@ struct distr_ctx {
   XRegion xr[NXR];
   bool cluster = true;          // DISTR_CLUSTER=0: single-workgroup 16-ray tiles only
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
-  int min_cl = 4;               // DISTR_CLUSTER_MIN=2: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032
+  int min_cl = 2;               // smallest cluster: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032 (DISTR_CLUSTER_MIN=4: off)
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
   bool persist64 = true;        // DISTR_PERSIST64=0: one workgroup per 64-ray tile in the merged launch
   bool merged_step = true;      // DISTR_MERGED_STEP=0: one launch per tile size and step instead of one merged launch per step
@@ -195,7 +195,7 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   return free_slot;
 }
 
-inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8, int test_abort = 0, int min_cl = 4) {
+inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8, int test_abort = 0, int min_cl = 2) {
   Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
   if (r) { if (++r->epoch == 0) ++r->epoch; x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch; }

@@ -627,14 +627,15 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   int64_t lo = 0, hi = count;
   if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
   const int64_t n = hi - lo;
-  // Cluster size from the (device-side) number of rays of this launch: with at most 31 / 63 tiles, 8 / 4 compute units share
-  // each tile (+1 tile for f(origin) on the launch that carries it keeps the grid within 256 workgroups). Measured step
-  // time: 68 us (8), 80 us (4), 111 us (single workgroup); 2 per tile gains nothing (the two halves of a layer plus the
-  // exchange cost what the whole layer costs on one CU), so larger remainders stay on single-workgroup tiles.
+  // Cluster size from the (device-side) number of rays of this launch: with at most 31 / 63 / 127 tiles, 8 / 4 / 2 compute units
+  // share each tile (+1 tile for f(origin) on the launch that carries it keeps the grid within 256 workgroups). Measured step
+  // time (C3 tail, profiles/r02_steps_c3.md): 52 us (8), 64 us (4), 94 us (2), 107 us (single workgroup).
   int cl = 1;
   if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : (n <= 2032 && A.xc.min_cl <= 2) ? 2 : 1;
   int tile = bidx, member = 0;
-  if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8)
+  if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8).
+    // (Measured alternative: member m of every cluster on XCD m, so that an XCD streams only its 1/cl slice of the weights from a
+    // warm L2 -- the compute phase did not change, it is not bound by weight latency, and the exchange across XCDs cost 1 us more.)
     const int g = bidx / (8 * cl), r = bidx % (8 * cl);
     tile = g * 8 + (r & 7);
     member = r >> 3;
@@ -735,7 +736,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
-    if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (masks_from_lds)
+    if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (mask_nibble_or)
       const int j = tid >> 4, q = tid & 15;
       const long long b = S.mb[j];
       if (b >= 0) {

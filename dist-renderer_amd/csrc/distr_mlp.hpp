@@ -968,7 +968,7 @@ struct Xchg {
   uint32_t* flags;     // [256 clusters][16 barriers][8 members]
   uint32_t epoch;      // unique per launch (per region)
   int32_t max_cl;      // largest cluster size to use (8 or 4)
-  int32_t min_cl;      // smallest cluster size to use (4; 2 = also pair tiles up to 2032 rays, DISTR_CLUSTER_MIN=2)
+  int32_t min_cl;      // smallest cluster size to use (2 = pair tiles up to 2032 rays; DISTR_CLUSTER_MIN=4 turns them off)
   int32_t test_abort;  // tests (DISTR_CLUSTER_TEST_ABORT=1): every lead member behaves as if its cluster had not assembled
   long long* ts;       // debug (DISTR_XCHG_TS=1): wall-clock stamps of cluster 0 / member 0 at phase boundaries, else null
 };
@@ -981,30 +981,63 @@ struct Xchg {
 constexpr long long CL_T_ARRIVE = 30 * 100;      // 30 us (members of a cluster are dispatched within ~1 us of each other when CUs are free)
 constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for the lead's verdict
 constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per layer barrier
-#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) xc.ts[(i)] = (long long)wall_clock64(); } while (0)
+#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); __builtin_amdgcn_s_waitcnt(0); } } while (0)
 
 
 // Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
-// The A-fragments a wave needs for a layer are streamed in chunks of 16 float4 (G = 16/NBL feature groups of 16) through
-// two register buffers; chunk 0 of a layer is requested BEFORE the exchange barrier of the previous layer (weights do not
-// depend on activations), so its latency hides behind the exchange, and chunk c+1 is requested before chunk c is used.
+// The A-fragments a wave needs are streamed in chunks of 8 float4 (G = 8/NBL feature groups of 16) through a RING of four
+// register buffers, three chunks ahead of their use: a chunk is 32 MFMAs of work (about 0.45 us at the issue rate), a request
+// needs about 1 us from L2, so one chunk of look-ahead (the first version) stalled every chunk. The ring runs across layers:
+// the first chunks of the next layer(s) are requested during the last chunks of this one, i.e. BEFORE its exchange barrier
+// (weights do not depend on activations), so their latency hides behind the exchange.
 template <int K, int O, int CL>
 struct ClGeom {
   static constexpr int RBT = O / 16, PER = RBT / CL, NBL = (PER >= 4) ? PER / 4 : 1, ACT = (PER >= 4) ? 4 : PER;
-  static constexpr int NG = K / 16, G = 16 / NBL, NCH = (NG + G - 1) / G;
+  static constexpr int NG = K / 16, G = 8 / NBL, NCH = (NG + G - 1) / G;
 };
+constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
+
+// The weight stream is issued with inline-asm loads and waited for with explicit vmcnt counts: the compiler's own wait-count
+// insertion drains the whole queue (vmcnt(0)) in front of every chunk here, which serialises each request with its use. Loads
+// of one wave return in order, so "the chunk requested 3 chunks ago has landed" = "at most 8 x (younger requests) loads are
+// outstanding". EVERY wave issues every request (waves without rows in a layer fetch another wave's fragments and drop them),
+// so the count is the same in all waves. Other memory operations in flight only make a wait stricter.
+__device__ __forceinline__ void cl_ld(f32x4& dst, const f32x4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void cl_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// "the value of these registers is final from here on": an empty asm that redefines them, so that nothing the compiler derives
+// from a loaded value (a copy into an accumulator register, a move) can be placed before the wait that precedes this statement
+__device__ __forceinline__ void cl_landed(f32x4 (&w)[8]) {
+  asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
+}
+__device__ __forceinline__ void cl_landed(f32x4& a) { asm volatile("" : "+v"(a)); }
 
 template <int K, int O, int CL>
-__device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, f32x4 (&w)[16], int c, int member, int wave, int lane) {
+__device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, f32x4 (&w)[8], int c, int member, int wave, int lane) {
   using Ge = ClGeom<K, O, CL>;
-  if (wave >= Ge::ACT) return;
-  const int rb0 = member * Ge::PER + wave * Ge::NBL;
+  static_assert(Ge::NG % Ge::G == 0, "whole chunks only");
+  const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1)) * Ge::NBL;
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wf) + (size_t)rb0 * 64 + lane;   // float4 index (g*RBT + rb)*64 + lane
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int g = c * Ge::G + i / Ge::NBL, ob = i % Ge::NBL;
-    if (g < Ge::NG) w[i] = wp[((size_t)g * Ge::RBT + ob) * 64];
+    cl_ld(w[i], wp + ((size_t)g * Ge::RBT + ob) * 64);
   }
+}
+
+// start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector), as counted loads
+template <int K, int O, int CL>
+__device__ __forceinline__ void cl_load_start(const float* __restrict__ init, f32x4 (&start)[4], int member, int wave, int kq) {
+  using Ge = ClGeom<K, O, CL>;
+  static_assert(Ge::NBL <= 4, "start[] holds at most 4 row blocks");
+  if (wave >= Ge::ACT) return;
+  const int rb0 = member * Ge::PER + wave * Ge::NBL;
+#pragma unroll
+  for (int ob = 0; ob < Ge::NBL; ++ob) cl_ld(start[ob], reinterpret_cast<const f32x4*>(init + 16 * (rb0 + ob) + 4 * kq));
 }
 
 // slot layout of a cluster's flag words ([16][8] uint32): slot 0 = arrival words, slots 1..7 = the layers' barriers,
@@ -1059,15 +1092,37 @@ __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_
   __syncthreads();
 }
 
+// KEEP, lead member: the ReLU bits of 4 consecutive rows (row0 = multiple of 4) of ray jj, taken from the REGISTERS that hold the
+// values anyway (own slice at write-back, the other members' slices on their way into LDS), go into the ray's mask block as one
+// nibble with an LDS atomic-or (S.mk is zeroed at the start of the tile). Format of store_mask_chunk: chunk (w, h), word
+// layer*4 + ob, bit r <-> row w*WR + 32*ob + (r&3) + 8*(r>>2) + 4*h, WR = 1 << wr_log = rows per wave of the 32x32 tiles (128; 64
+// for lin3, whose words ob = 2, 3 stay zero). (Re-reading the finished layer from LDS cost 2 us per layer on the lead member.)
+__device__ __forceinline__ void mask_nibble_or(Smem16CL& S, int layer, int row0, int wr_log, int jj, const f32x4& v) {
+  // (bit = "the float's integer pattern is positive", exactly the test of the other tile sizes' write-back)
+  const uint32_t nib = (__float_as_int(v[0]) > 0 ? 1u : 0u) | (__float_as_int(v[1]) > 0 ? 2u : 0u) | (__float_as_int(v[2]) > 0 ? 4u : 0u) |
+                       (__float_as_int(v[3]) > 0 ? 8u : 0u);
+  const int w = row0 >> wr_log, rem = row0 & ((1 << wr_log) - 1), ob = rem >> 5, rr = rem & 31, h = (rr >> 2) & 1, n = rr >> 3;
+  const int idx = (w * 2 + h) * 32 + layer * 4 + ob;
+  atomicOr(reinterpret_cast<uint32_t*>(&S.mk[jj][0]) + (idx >> 1), nib << (4 * n + 16 * (idx & 1)));
+}
+
 // One dense layer of the cluster tile: this member's row slice, ReLU, slice -> own LDS + exchange buffer, barrier, the
 // other members' slices -> LDS. On return X holds the full post-ReLU output of the layer (O rows) in every member.
-// w[START] holds chunk 0 of this layer on entry; on return w[(START + NCH) & 1] holds chunk 0 of the next layer (KN > 0).
-template <int K, int O, int CL, int START, int KN, int ON>
-__device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const float* __restrict__ init, const float* __restrict__ WfNext,
-                                         f32x4 (&w)[2][16], Smem16CL& S, const Xchg& xc, float* xbase, uint32_t* flags, int layer,
-                                         int member) {
+// `start` = this layer's accumulator start values (requested by the previous layer); it is dead once the accumulators are
+// initialised, so the next layer's values (initNext) are requested into the same registers after the chunk loop.
+// GB = index of this layer's chunk 0 in the network-wide chunk sequence (ring slot = index & 3). On entry the first
+// min(CL_AHEAD, NCH) chunks of this layer are in flight / in their slots; while chunk c is used, chunk c + CL_AHEAD of the
+// sequence is requested: of this layer, of the next one (KN x ON, WfNext) or of the one after it (KN2 x ON2, WfNext2).
+template <int K, int O, int CL, int GB, int TOT, int KN, int ON, int KN2, int ON2>
+__device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const float* __restrict__ WfNext,
+                                         const float* __restrict__ WfNext2, f32x4 (&w)[4][8], f32x4 (&start)[4], const float* __restrict__ initNext,
+                                         Smem16CL& S, const Xchg& xc, float* xbase, uint32_t* flags, int layer, int member, bool keep,
+                                         int wr_log = 7) {
   using Ge = ClGeom<K, O, CL>;
+  using GeN = ClGeom<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>;
+  using GeN2 = ClGeom<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL>;
   constexpr int RBT = Ge::RBT, PER = Ge::PER, NBL = Ge::NBL, ACT = Ge::ACT, G = Ge::G, NCH = Ge::NCH, NG = Ge::NG;
+  constexpr int NCHN = (KN > 0) ? GeN::NCH : 0, NCHN2 = (KN2 > 0) ? GeN2::NCH : 0;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, kq = lane >> 4, j = lane & 15;
@@ -1075,40 +1130,56 @@ __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const flo
   float* slot = xbase + (layer & 1) * 8192;
   f32x4 acc[NBL];
   const int rb0 = member * PER + wave * NBL;
-  if (wave < ACT) {
+  if (wave < ACT) {   // start values (bias / latent constants): requested by the previous layer before its exchange (cl_load_start)
 #pragma unroll
-    for (int ob = 0; ob < NBL; ++ob) acc[ob] = *reinterpret_cast<const f32x4*>(init + 16 * (rb0 + ob) + 4 * kq);
+    for (int ob = 0; ob < NBL; ++ob) { cl_landed(start[ob]); acc[ob] = start[ob]; }
   }
   const float* xb = X + lane;
-  float b[4], bn[4];
+  float b[3][4];                      // B fragments (LDS) run two feature groups ahead
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) b[s4] = xb[(4 * s4) * 16];            // B fragments (LDS) run one feature group ahead
+  for (int s4 = 0; s4 < 4; ++s4) { b[0][s4] = xb[(4 * s4) * 16]; b[1][s4] = xb[(16 * (NG > 1 ? 1 : 0) + 4 * s4) * 16]; }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    if (c + 1 < NCH) cl_load_chunk<K, O, CL>(Wf, w[(START + c + 1) & 1], c + 1, member, wave, lane);
-    else if (KN > 0) cl_load_chunk<(KN > 0 ? KN : 16), (KN > 0 ? ON : 16 * CL), CL>(WfNext, w[(START + c + 1) & 1], 0, member, wave, lane);
+    const int t = c + CL_AHEAD;       // (compile-time after unrolling)
+    if (t < NCH) cl_load_chunk<K, O, CL>(Wf, w[(GB + t) & 3], t, member, wave, lane);
+    else if (t - NCH < NCHN) cl_load_chunk<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>(WfNext, w[(GB + t) & 3], t - NCH, member, wave, lane);
+    else if (t - NCH - NCHN < NCHN2) cl_load_chunk<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL>(WfNext2, w[(GB + t) & 3], t - NCH - NCHN, member, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (wave < ACT) {
+      // requests issued in iterations i of this layer: issued(i) = (GB + i + CL_AHEAD < TOT). Chunk c was requested in iteration
+      // c - CL_AHEAD (c >= CL_AHEAD; earlier chunks were requested in a previous layer and drained at its exchange); at c = 0 the
+      // start values must have landed (older than this iteration's request)
+      if (c == 0) {   // (layer 1 only: the start values and first chunks requested before lin0; later layers drained them at the exchange)
+        if (GB + CL_AHEAD < TOT) cl_wait_vm<8>(); else cl_wait_vm<0>();
+      } else if (c >= CL_AHEAD) {
+        const int younger = ((GB + c + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 2 + CL_AHEAD < TOT) ? 1 : 0);
+        if (younger == 3) cl_wait_vm<24>(); else if (younger == 2) cl_wait_vm<16>(); else if (younger == 1) cl_wait_vm<8>(); else cl_wait_vm<0>();
+      }
+      if (c == 0) {
+#pragma unroll
+        for (int ob = 0; ob < NBL; ++ob) cl_landed(acc[ob]);
+      }
+      cl_landed(w[(GB + c) & 3]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int gi = 0; gi < G; ++gi) {
         const int g = c * G + gi;
         if (g < NG) {
-          const int gn = (g + 1 < NG) ? g + 1 : g;
+          const int gn = (g + 2 < NG) ? g + 2 : NG - 1;
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) bn[s4] = xb[(16 * gn + 4 * s4) * 16];
+          for (int s4 = 0; s4 < 4; ++s4) b[(g + 2) % 3][s4] = xb[(16 * gn + 4 * s4) * 16];
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int ob = 0; ob < NBL; ++ob)
-              acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(START + c) & 1][gi * NBL + ob][s4], b[s4], acc[ob], 0, 0, 0);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) b[s4] = bn[s4];
+              acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(GB + c) & 3][gi * NBL + ob][s4], b[g % 3][s4], acc[ob], 0, 0, 0);
         }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (KN > 0) cl_load_start<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>(initNext, start, member, wave, kq);   // lands during the exchange
   DISTR_XTS(4 * layer);
   __syncthreads();                         // everybody is done reading the layer input
   if (wave < ACT) {
@@ -1121,51 +1192,43 @@ __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const flo
         X[(16 * (rb0 + ob) + 4 * kq + r) * 16 + j] = v[r];
       }
       __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(slot) + (rb0 + ob) * 64 + lane);
+      if (keep) mask_nibble_or(S, layer, 16 * (rb0 + ob) + 4 * kq, wr_log, j, v);
     }
   }
-  // Wait for this wave's slice stores only (they were issued after the weight prefetch of the next layer, and memory
-  // operations of one wave complete in order, so waiting for ALL of them would also wait for the prefetch -- which is
-  // what we want to overlap with the exchange). vmcnt counts outstanding operations: the stores are the youngest, so a
-  // full wait is needed for them; the prefetch was issued earlier and has normally landed by now.
+  // Wait for this wave's slice stores (memory operations of one wave complete in order, so this also waits for the weight
+  // chunks requested above -- they were issued during the layer's last chunks and have normally landed by now).
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   DISTR_XTS(4 * layer + 1);
   cl_barrier<CL>(flags, layer, member, xc.epoch, tid, &S.fail);
   if (S.fail) return;                      // (uniform: written before the barrier's __syncthreads)
   DISTR_XTS(4 * layer + 2);
-  // other members' slices: float4 index i over the row blocks not owned by this member
-  constexpr int OTHER = (RBT - PER) * 64;
-  for (int i = tid; i < OTHER; i += NTHREADS) {
+  // other members' slices: float4 index i over the row blocks not owned by this member; all loads first (ONE round trip to the
+  // uncached buffer), then the LDS writes
+  constexpr int OTHER = (RBT - PER) * 64, NLD = (OTHER + NTHREADS - 1) / NTHREADS;
+  f32x4 v[NLD];
+#pragma unroll
+  for (int q = 0; q < NLD; ++q) {
+    const int i = tid + q * NTHREADS;
+    int rb = i >> 6;
+    rb += (rb >= member * PER) ? PER : 0;
+    if (i < OTHER) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slot) + rb * 64 + (i & 63));
+  }
+#pragma unroll
+  for (int q = 0; q < NLD; ++q) {
+    const int i = tid + q * NTHREADS;
     int rb = i >> 6;
     const int l = i & 63;
     rb += (rb >= member * PER) ? PER : 0;
-    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slot) + rb * 64 + l);
     const int row = 16 * rb + 4 * (l >> 4), jj = l & 15;
+    if (i < OTHER) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[(row + r) * 16 + jj] = v[r];
+      for (int r = 0; r < 4; ++r) X[(row + r) * 16 + jj] = v[q][r];
+      if (keep) mask_nibble_or(S, layer, row, wr_log, jj, v[q]);
+    }
   }
   __syncthreads();
   DISTR_XTS(4 * layer + 3);
-}
-
-// mask words of `layer` for the 16 rays from the post-ReLU activations in X (bit = activation > 0), into S.mk in the
-// per-ray block format of store_mask_chunk: chunk (w, h), word layer*4 + ob, bit r <-> row w*WR + 32*ob + (r&3) + 8*(r>>2) + 4*h,
-// WR = rows per wave of the 32x32 tiles (128; 64 for lin3, whose words ob = 2, 3 are zero)
-__device__ __forceinline__ void masks_from_lds(Smem16CL& S, int layer, int rows, int tid, int WR = 128) {
-  const int j = tid & 15, c = tid >> 4;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int om = c + 16 * e, w = om >> 3, h = (om >> 2) & 1, ob = om & 3;
-    const int base = w * WR + 32 * ob + 4 * h;
-    uint32_t m = 0u;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = base + (r & 3) + 8 * (r >> 2);
-      const float v = (row < rows && 32 * ob < WR) ? S.X[row * 16 + j] : 0.f;
-      m |= (v > 0.f ? 1u : 0u) << r;
-    }
-    S.mk[j][(w * 2 + h) * 32 + layer * 4 + ob] = (uint16_t)m;
-  }
 }
 
 // Cluster forward. Every member returns after its last contribution; member 0 returns the pre-tanh value (ray = tid & 15)
@@ -1184,14 +1247,22 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   float* xbase = xc.buf + (size_t)cluster * 2 * 8192;
   uint32_t* flags = xc.flags + (size_t)cluster * 128;
   const bool lead = (member == 0);
-  f32x4 w[2][16];
+  f32x4 w[4][8];
   DISTR_XTS(0);
   if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
     S.fail = 0;
     __hip_atomic_store(flags + member, xc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  cl_load_chunk<512, 512, CL>(D16.Wf[1], w[0], 0, member, wave, lane);      // lin1's first weights travel while lin0 runs
+#pragma unroll
+  for (int c = 0; c < CL_AHEAD; ++c) cl_load_chunk<512, 512, CL>(D16.Wf[1], w[c], c, member, wave, lane);   // lin1's first weights travel while lin0 runs
+  f32x4 sa[4];                                                                                              // start values of the next layer
+  cl_load_start<512, 512, CL>(D.bias[1], sa, member, wave, kq);
   X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;
+  if (KEEP && lead) {   // the rays' mask blocks are OR-ed together nibble by nibble (mask_nibble_or)
+    uint4* z = reinterpret_cast<uint4*>(&S.mk[0][0]);
+    z[tid] = make_uint4(0u, 0u, 0u, 0u);
+    z[tid + NTHREADS] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __syncthreads();
   {  // lin0 (K = 16 padded): cheaper to compute whole in every member than to exchange
     f32x4 acc[8];
@@ -1199,40 +1270,37 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
     __syncthreads();
     (void)writeback16<8, false>(X, acc, wave * 128, lane);
+    if (KEEP && lead) {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) mask_nibble_or(S, 0, wave * 128 + 16 * ob + 4 * kq, 7, ray, acc[ob]);
+    }
     __syncthreads();
-    if (KEEP && lead) masks_from_lds(S, 0, 512, tid);
   }
   DISTR_XTS(1);
   cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, xc.test_abort);
   if (S.fail) return 0.f;
-  // buffer parity of every layer's chunk 0 (see layer_cl)
+  // position of every layer's chunk 0 in the network-wide chunk sequence (see layer_cl)
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
-  constexpr int S1 = 0, S2 = (S1 + N1) & 1, S3 = (S2 + N1) & 1, S4 = (S3 + N3) & 1, S5 = (S4 + N4) & 1, S6 = (S5 + N1) & 1, S7 = (S6 + N1) & 1;
-  layer_cl<512, 512, CL, S1, 512, 512>(D16.Wf[1], D.bias[1], D16.Wf[2], w, S, xc, xbase, flags, 1, member);
+  static_assert(N1 >= CL_AHEAD, "the initial requests cover lin1's first chunks");
+  constexpr int G1 = 0, G2 = G1 + N1, G3 = G2 + N1, G4 = G3 + N3, G5 = G4 + N4, G6 = G5 + N1, G7 = G6 + N1, GT = G7 + N1;
+  layer_cl<512, 512, CL, G1, GT, 512, 512, 512, 256>(D16.Wf[1], D16.Wf[2], D16.Wf[3], w, sa, D.bias[2], S, xc, xbase, flags, 1, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 1, 512, tid);
-  layer_cl<512, 512, CL, S2, 512, 256>(D16.Wf[2], D.bias[2], D16.Wf[3], w, S, xc, xbase, flags, 2, member);
+  layer_cl<512, 512, CL, G2, GT, 512, 256, 256, 512>(D16.Wf[2], D16.Wf[3], D16.Wf[4], w, sa, D.bias[3], S, xc, xbase, flags, 2, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 2, 512, tid);
-  layer_cl<512, 256, CL, S3, 256, 512>(D16.Wf[3], D.bias[3], D16.Wf[4], w, S, xc, xbase, flags, 3, member);
+  layer_cl<512, 256, CL, G3, GT, 256, 512, 512, 512>(D16.Wf[3], D16.Wf[4], D16.Wf[5], w, sa, c4, S, xc, xbase, flags, 3, member, KEEP && lead, 6);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 3, 253, tid, 64);     // rows 253..255 are padding (bias 0 -> relu 0 -> bit 0), as in the other tiles
   __syncthreads();
   if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
   __syncthreads();
-  layer_cl<256, 512, CL, S4, 512, 512>(D16.Wf[4], c4, D16.Wf[5], w, S, xc, xbase, flags, 4, member);
+  layer_cl<256, 512, CL, G4, GT, 512, 512, 512, 512>(D16.Wf[4], D16.Wf[5], D16.Wf[6], w, sa, D.bias[5], S, xc, xbase, flags, 4, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 4, 512, tid);
-  layer_cl<512, 512, CL, S5, 512, 512>(D16.Wf[5], D.bias[5], D16.Wf[6], w, S, xc, xbase, flags, 5, member);
+  layer_cl<512, 512, CL, G5, GT, 512, 512, 512, 512>(D16.Wf[5], D16.Wf[6], D16.Wf[7], w, sa, D.bias[6], S, xc, xbase, flags, 5, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 5, 512, tid);
-  layer_cl<512, 512, CL, S6, 512, 512>(D16.Wf[6], D.bias[6], D16.Wf[7], w, S, xc, xbase, flags, 6, member);
+  layer_cl<512, 512, CL, G6, GT, 512, 512, 0, 0>(D16.Wf[6], D16.Wf[7], nullptr, w, sa, D.bias[7], S, xc, xbase, flags, 6, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (KEEP && lead) masks_from_lds(S, 6, 512, tid);
-  layer_cl<512, 512, CL, S7, 0, 0>(D16.Wf[7], D.bias[7], nullptr, w, S, xc, xbase, flags, 7, member);
+  layer_cl<512, 512, CL, G7, GT, 0, 0, 0, 0>(D16.Wf[7], nullptr, nullptr, w, sa, nullptr, S, xc, xbase, flags, 7, member, KEEP && lead);
   if (S.fail) return 0.f;
   if (!lead) return 0.f;
-  if (KEEP) masks_from_lds(S, 7, 512, tid);
   DISTR_XTS(32);
   {
     float p = 0.f;
