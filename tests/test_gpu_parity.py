@@ -973,6 +973,47 @@ def test_bench_view_balancing_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_view_balancing_eight_ranks():
+    """The shape of the driver's 8-GPU run, on this one GPU: eight ranks (gloo), the step times of the eight C4 views as measured on
+    one MI355X (profiles/r02_view_balance.md) forced in, so that the plan has one donor and two receivers. Every row of every view
+    is rendered exactly once, and the all-reduced loss / latent gradient equal the unbalanced run's."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    from distr import parallel
+    H = 512
+    times = [52.71, 54.40, 51.19, 50.40, 47.98, 46.50, 49.57, 58.67]
+    expect = parallel.balance_views(times, H)
+    assert sum(len(p) for p in expect) > 8               # the plan really moves rows at this size
+    outs = []
+    for extra, fake in ((['--no-balance'], None), ([], ','.join('%.2f' % t for t in times))):
+        env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        if fake:
+            env['DISTR_BENCH_FAKE_TIMES'] = fake
+        port = 29930 + (os.getpid() % 40) + len(outs)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '3', '--size', str(H),
+               '--march-step', '30'] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
+    plain, bal = outs
+    assert plain['n_gpus'] == 8 and plain['config']['balance_plan'] is None
+    plan = [[tuple(x) for x in p] for p in bal['config']['balance_plan']]
+    assert plan == expect, plan
+    cover = np.zeros((8, H), np.int32)
+    for p in plan:
+        for (v, r0, r1) in p:
+            cover[v, r0:r1] += 1
+    assert (cover == 1).all()
+    a, b = plain['config']['loss_sum_all_ranks'], bal['config']['loss_sum_all_ranks']
+    assert abs(a - b) <= 1e-5 * abs(a), (a, b)
+    ga, gb = plain['config']['latent_grad_norm_all_ranks'], bal['config']['latent_grad_norm_all_ranks']
+    assert abs(ga - gb) <= 1e-4 * abs(ga), (ga, gb)
+    assert abs(bal['value'] - 8 * H * H / (bal['ms_per_step'] * 1e-3)) <= 1e-6 * bal['value']      # whole-job rays / max-over-ranks time
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(8))
 def test_random_configs_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
     """Seeded random draws over image size (ragged), steps, buffer_size, ratio, marcher, normal mode and camera: HIP vs
