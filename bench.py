@@ -129,6 +129,9 @@ def main():
                          'vectors; the heaviest backward: every in-sphere ray carries a gradient sample); reference: the single-view '
                          'loss of run_single_shape.py:93-98 against a ground truth rendered once from a perturbed latent')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU (c5 at N <= 4)')
+    ap.add_argument('--items', default=None,
+                    help='diagnostics (N = 1, c3): the work items of the step as view:r0:r1[,view:r0:r1...] instead of one whole view, e.g. '
+                         '"5:0:512,7:480:512" = what rank 5 renders under the N = 8 balance plan (profiles/r02_view_balance.md)')
     ap.add_argument('--no-balance', action='store_true',
                     help='c3 at N > 1: keep exactly one whole view per GPU (default: after the warm-up the ranks exchange their step times and '
                          'the slowest views hand row bands to the fastest ranks, distr.parallel.balance_views)')
@@ -165,6 +168,10 @@ def main():
     else:
         n_shapes = 1
         items = [(0, (v + args.view_offset) % 8, 0, H) for v in parallel.shard_views(args.gpus, rank, world)]     # one view per GPU
+        if args.items:
+            if world != 1:
+                raise SystemExit('--items is a single-GPU diagnostic')
+            items = [(0,) + tuple(int(x) for x in it.split(':')) for it in args.items.split(',')]
         lats_np = [latent_np]
     cams = {}
     for (_, v, _, _) in items:
@@ -211,9 +218,12 @@ def main():
             outs = functions.render_call(eng, cfg, lats[shape], Rt, Tt)
         else:
             outs = functions.render_band_call(eng, cfg, lats[shape], Rt, Tt, r0, r1)
+        if (r0, r1) == (0, H):
+            last_mask[v] = outs[1]
         return image_loss(outs, r0, r1, (shape, v))
 
     last = {}              # gradients of the most recent step (reported as a norm: lets two runs be compared)
+    last_mask = {}         # rendered mask of every whole view of the most recent step (row cost profile of the balancer)
     local_ms = []          # (calibration only) GPU milliseconds of this rank's own work of a step, without the wait in the all-reduce
 
     def step(measure=False):
@@ -244,25 +254,42 @@ def main():
         return total
 
     # ---- warm-up. View-parallel runs (c3, N > 1, dense loss) use it to balance the views: the eight cameras differ by up to 25 % in cost
-    # and every step ends in the all-reduce, so the slowest view would pace the job. The ranks all-gather their own step times, every rank
-    # computes the same plan (distr.parallel.balance_views), and the slowest views hand row bands (bit-identical to the same rows of
-    # the full render, gradients sum exactly) to the fastest ranks. Total work is unchanged: N whole views per step.
-    balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and args.warmup >= 3
+    # and every step ends in the all-reduce, so the slowest view would pace the job. The ranks all-gather their own step times and the
+    # row cost profile of their view (from its rendered mask), every rank computes the same plan (distr.parallel.balance_views), and
+    # the slowest views hand row bands (bit-identical to the same rows of the full render, gradients sum exactly) to the fastest
+    # ranks. With >= 5 warm-up steps the plan is refined once from the times measured under it (distr.parallel.refine_profiles).
+    # Total work is unchanged: N whole views per step. Every plan gets one unmeasured step first (new band shapes: allocator).
+    balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and args.warmup >= 3 and not args.items
     plan = None
+    view_of = lambda r: (r + args.view_offset) % 8
+    fake = os.environ.get('DISTR_BENCH_FAKE_TIMES')                  # tests: force the times on a box where the ranks share one GPU
+    refine = args.warmup >= 5 and not fake
+    i_plan = args.warmup - 4 if refine else args.warmup - 2          # W = 5: plan after steps 0-1, step 2 warms it, step 3 measures it,
+    i_refine = args.warmup - 2 if refine else -1                      # refinement after step 3, step 4 warms the final plan
+
+    def apply_plan(pl):
+        items[:] = [(0, view_of(v), r0, r1) for (v, r0, r1) in pl[rank]]
+        for (_, v, _, _) in items:
+            if v not in cams:
+                R, T = view_camera(fixture, v)
+                cams[v] = (torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True))
+        pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
+
     for w in range(args.warmup):
-        step(measure=balance and w < args.warmup - 1)
-        if balance and w == args.warmup - 2:
+        step(measure=balance and w <= max(i_plan, i_refine))
+        if balance and w == i_plan:
             mine = float(np.median(local_ms[1:])) if len(local_ms) > 1 else local_ms[0]
-            fake = os.environ.get('DISTR_BENCH_FAKE_TIMES')          # tests: force a plan on a box where the ranks share one GPU
             times = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(mine, device=dev)
-            plan = parallel.balance_views(times, H)
-            view_of = lambda r: (r + args.view_offset) % 8
-            items[:] = [(0, view_of(v), r0, r1) for (v, r0, r1) in plan[rank]]
-            for (_, v, _, _) in items:
-                if v not in cams:
-                    R, T = view_camera(fixture, v)
-                    cams[v] = (torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True))
-            pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
+            m = last_mask.get(view_of(rank))
+            prof = parallel.row_profile(m.reshape(H, W).detach().cpu().numpy()) if m is not None else [1.0] * ((H + 3) // 4)
+            profiles = parallel.allgather_vector(prof, device=dev)
+            plan = parallel.balance_views(times, H, profiles)
+            apply_plan(plan)
+        elif balance and w == i_refine and plan is not None:
+            loads = parallel.allgather_scalar(local_ms[-1], device=dev)
+            profiles = parallel.refine_profiles(profiles, plan, times, loads, H)
+            plan = parallel.balance_views(times, H, profiles)
+            apply_plan(plan)
     # ---- the timed region: exactly K steps between barrier + synchronize on both sides; nothing is recorded inside it
     torch.cuda.synchronize()
     parallel.barrier()

@@ -96,42 +96,140 @@ def allreduce_grads(params, scalars=(), group=None):
     return out
 
 
-def balance_views(times, H, align=4, min_rows=16, halo_rows=8, tolerance=0.02):
-    """Row-band load balancing of a view-parallel step. `times[r]` = seconds rank r needs for ITS view (one H-row view per rank);
-    the views are not equally expensive (number of rays that graze the surface), and every step ends in the gradient all-reduce,
-    so the slowest view paces the job. Ranks above the mean hand the bottom rows of their view to ranks below it, as row bands
-    (multiples of `align` = 4 rows: a band renders bit-identically to the same rows of the full image, distr.functions.
-    render_band_call; the receiver also pays `halo_rows` of depth2normal halo). Pure function of `times`, so every rank computes the
-    same plan from the all-gathered times. Returns plan[r] = [(view, r0, r1), ...] (first entry: what is left of the rank's own view);
-    every row of every view appears exactly once. Views within `tolerance` of the mean are left alone."""
+BG_WEIGHT = 0.123      # cost of a background pixel (in the unit sphere, no surface) relative to a surface pixel: measured on the C4
+                       # views, 0.086 us against 0.70 us per pixel of a 512^2 / 50-step fwd+bwd (profiles/r02_band_cost.log)
+BAND_FIXED = 0.02      # fixed cost of rendering one extra band, as a fraction of the mean view time (~1 ms of 51: the band's own
+                       # latency-bound launches; measured with `bench.py --items`)
+
+
+def row_profile(mask, align=4):
+    """Relative cost of every `align`-row unit of a view from its rendered mask (H, W) (any array-like of 0 / 1): a surface pixel
+    counts 1, a background pixel BG_WEIGHT. The rows of a view are far from equally expensive -- the object sits in the middle of
+    the image, the top and bottom rows hold only rays that cross the sphere without finding a surface."""
+    import numpy as np
+    m = np.asarray(mask, dtype=np.float64)
+    H, W = m.shape
+    per_row = BG_WEIGHT * W + (1.0 - BG_WEIGHT) * m.sum(1)
+    U = (H + align - 1) // align
+    out = np.zeros(U)
+    for u in range(U):
+        out[u] = per_row[u * align:(u + 1) * align].sum()
+    return out.tolist()
+
+
+def balance_views(times, H, profiles=None, align=4, min_rows=16, halo_rows=4, tolerance=0.02, fixed=BAND_FIXED):
+    """Row-band load balancing of a view-parallel step. `times[r]` = time rank r needs for ITS view (one H-row view per rank);
+    the views are not equally expensive (surface pixels, grazing rays), and every step ends in the gradient all-reduce, so the
+    slowest view paces the job. Slow ranks hand the BOTTOM rows of their view to fast ranks as row bands (multiples of `align` = 4
+    rows: a band renders bit-identically to the same rows of the full image, distr.functions.render_band_call).
+    `profiles[r]` = relative cost of every 4-row unit of view r (row_profile of its rendered mask; None: uniform) -- rows are
+    converted to time through it, which matters: the bottom 52 rows of a C4 view are 10 % of its rows and 4 % of its time.
+    Cost model of a plan (checked against single-GPU measurements, profiles/r02_band_cost.log): a rank pays the profile time of
+    the rows it renders, `halo_rows` more on every cut edge (depth2normal halo), and `fixed` x mean time per received band.
+    The plan minimises the slowest rank: the lowest level L (searched upward from the mean in 0.25 % steps) at which every rank
+    above L can shed its excess to ranks below L. Pure function of its arguments, so every rank computes the same plan from the
+    all-gathered inputs. Returns plan[r] = [(view, r0, r1), ...] (first entry: what is left of the rank's own view); every row of
+    every view appears exactly once. Nothing moves if the slowest view is within `tolerance` of the mean."""
     N = len(times)
-    plan = [[(r, 0, H)] for r in range(N)]
+    plan0 = [[(r, 0, H)] for r in range(N)]
     if N < 2 or min(times) <= 0:
-        return plan
+        return plan0
     mean = sum(times) / N
-    excess = [t - mean for t in times]
-    if max(excess) <= tolerance * mean:
-        return plan
-    rows_left = [H] * N
-    donors = sorted((r for r in range(N) if excess[r] > 0), key=lambda r: (-excess[r], r))
-    receivers = sorted((r for r in range(N) if excess[r] < 0), key=lambda r: (excess[r], r))
-    deficit = {r: -excess[r] for r in receivers}
-    extra = [[] for _ in range(N)]
-    for d in donors:
-        per_row = times[d] / H
-        ex = excess[d]
-        for r in receivers:
-            if ex < min_rows * per_row:
-                break
-            k = int(min(ex, deficit[r] - halo_rows * per_row) / per_row) // align * align
-            k = min(k, rows_left[d] - H // 2)          # a view keeps at least half of its rows
-            if k < min_rows:
-                continue
-            extra[r].append((d, rows_left[d] - k, rows_left[d]))
-            rows_left[d] -= k
-            ex -= k * per_row
-            deficit[r] -= (k + halo_rows) * per_row
-    return [[(r, 0, rows_left[r])] + extra[r] for r in range(N)]
+    if max(times) - mean <= tolerance * mean:
+        return plan0
+    U = (H + align - 1) // align
+    prof = []
+    for r in range(N):
+        p = list(profiles[r]) if (profiles is not None and profiles[r] is not None and len(profiles[r]) == U) else [1.0] * U
+        tot = sum(p)
+        prof.append([times[r] * x / tot for x in p] if tot > 0 else [times[r] / U] * U)        # time of every unit of view r
+    hu = (halo_rows + align - 1) // align                                                        # halo in units
+    band_fixed = fixed * mean
+    min_units = (min_rows + align - 1) // align
+
+    pre = [[0.0] * (U + 1) for _ in range(N)]            # prefix sums of the unit times
+    for r in range(N):
+        for u in range(U):
+            pre[r][u + 1] = pre[r][u] + prof[r][u]
+
+    def span(d, lo, hi):                                 # time of units [lo, hi) of view d (clipped to the image)
+        lo, hi = max(0, lo), min(U, hi)
+        return pre[d][hi] - pre[d][lo] if hi > lo else 0.0
+
+    def own_cost(d, top):                                # view d cut at unit `top`: its rows + the halo below the cut
+        return span(d, 0, top) + (span(d, top, top + hu) if top < U else 0.0)
+
+    def band_cost(d, lo, hi):                            # a received band [lo, hi) of view d: its rows + halo on every cut edge
+        return span(d, lo, hi) + span(d, lo - hu, lo) + (span(d, hi, hi + hu) if hi < U else 0.0)
+
+    def attempt(L):
+        top = [U] * N                       # view d keeps units [0, top[d])
+        load = list(times)
+        extra = [[] for _ in range(N)]
+        for d in sorted((r for r in range(N) if times[r] > L), key=lambda r: (-times[r], r)):
+            for r in sorted((r for r in range(N) if times[r] < L), key=lambda r: (load[r], r)):
+                if load[d] <= L or top[d] - min_units < U // 2:
+                    break
+                room = L - load[r] - band_fixed
+                lo = top[d]
+                while lo - 1 >= U // 2 and band_cost(d, lo - 1, top[d]) <= room and own_cost(d, lo) > L:
+                    lo -= 1
+                if top[d] - lo < min_units:
+                    continue
+                extra[r].append((d, lo * align, min(H, top[d] * align)))
+                load[r] += band_cost(d, lo, top[d]) + band_fixed
+                top[d] = lo
+                load[d] = own_cost(d, lo)
+        return all(load[r] <= L * 1.0000001 for r in range(N)), [[(r, 0, min(H, top[r] * align))] + extra[r] for r in range(N)], max(load)
+
+    best = None
+    L = mean
+    while L < max(times):
+        ok, plan, worst = attempt(L)
+        if best is None or worst < best[1]:
+            best = (plan, worst)
+        if ok:
+            break
+        L *= 1.0025
+    if best is None or best[1] >= max(times) * (1.0 - 1e-9):
+        return plan0
+    return best[0]
+
+
+def refine_profiles(profiles, plan, times, loads, H, align=4, halo_rows=4):
+    """One feedback step of the balancer. `loads[r]` = what rank r measured for its work under `plan`; for a donor (its own
+    view cut at row r1 < H) `times[d] - loads[d]` is the REAL cost of the rows it gave away, while the profile predicted
+    `times[d] - own_cost`. The given-away part of the profile is scaled by their ratio (clamped to [0.5, 2.5]): the rows at the
+    lower edge of the object carry the grazing rays and cost more per surface pixel than the view's average. Returns the
+    corrected profiles; balance_views(times, H, corrected) is the refined plan."""
+    U = (H + align - 1) // align
+    hu = (halo_rows + align - 1) // align
+    out = []
+    for d, p in enumerate(profiles):
+        p = list(p) if (p is not None and len(p) == U) else [1.0] * U
+        top = (plan[d][0][2] + align - 1) // align
+        if top < U and sum(p) > 0:
+            tot = sum(p)
+            own = times[d] * (sum(p[:top]) + sum(p[top:top + hu])) / tot
+            pred, real = times[d] - own, times[d] - loads[d]
+            if pred > 1e-9:
+                k = min(2.5, max(0.5, real / pred))
+                p = p[:top] + [x * k for x in p[top:]]
+        out.append(p)
+    return out
+
+
+def allgather_vector(vec, device=None, group=None):
+    """[vector of rank 0, ..., vector of rank N-1] (equal lengths) on every rank."""
+    v = [float(x) for x in vec]
+    if not is_distributed(group):
+        return [v]
+    if str(dist.get_backend(group)) != 'nccl':
+        device = None
+    t = torch.tensor(v, dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [[float(x) for x in o.tolist()] for o in out]
 
 
 def allgather_scalar(value, device=None, group=None):

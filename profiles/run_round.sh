@@ -38,4 +38,6 @@ for V in 0 1 2 3 4 5 6 7; do
   python bench.py --view-offset $V --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/view_$V.json" 2>/dev/null
 done
 python profiles/view_balance.py "$OUT" > "$OUT/view_balance.md" 2>&1
+# the plan with the row cost profiles of the rendered masks, every rank's items timed on this GPU (bench.py --items)
+python profiles/plan_check.py "$OUT" 2>&1 | grep -v amdgpu.ids > "$OUT/plan_check.md"
 ls -la "$OUT" | tail -30

@@ -1,6 +1,7 @@
 """Per-view step times of the eight C4 cameras (bench.py --view-offset v on ONE GPU, written by run_round.sh as view_<v>.json)
 -> the row-band plan `bench.py --gpus N` derives from such times at N = 2, 4, 8 (distr.parallel.balance_views) and the estimated
-step time with / without it. An estimate from single-GPU measurements: no multi-GPU run is behind these numbers."""
+step time with / without it, with UNIFORM row costs (the plan bench.py really uses weighs the rows by the rendered mask and is
+checked rank by rank in plan_check.py). An estimate from single-GPU measurements: no multi-GPU run is behind these numbers."""
 import json
 import os
 import sys

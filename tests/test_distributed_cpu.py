@@ -46,7 +46,9 @@ def _worker(rank, world, port, q):
     # the view balancer: every rank gathers all step times and derives the same plan; its pieces tile every view once
     times = parallel.allgather_scalar(70.0 if rank == 0 else 40.0)
     assert times == [70.0, 40.0]
-    plan = parallel.balance_views(times, 192)
+    profs = parallel.allgather_vector([1.0 + rank] * 48)
+    assert profs == [[1.0] * 48, [2.0] * 48]
+    plan = parallel.balance_views(times, 192, profs)
     rows = torch.zeros(2, 192)
     for (v, r0, r1) in plan[rank]:
         rows[v, r0:r1] += 1

@@ -332,25 +332,47 @@ def test_compute_loss_color_and_mask_visualizer():
 
 
 def test_balance_views_plan():
-    """distr.parallel.balance_views: a pure function of the gathered step times; every row of every view is assigned exactly once,
-    bands are 4-row aligned, the estimated maximum drops, balanced inputs are left alone."""
+    """distr.parallel.balance_views: a pure function of the gathered step times (+ row cost profiles); every row of every view is
+    assigned exactly once, bands are 4-row aligned and at least 16 rows, the modelled slowest rank drops, balanced inputs are left
+    alone; row_profile weighs surface rows above background rows; refine_profiles moves the plan the way a measurement says."""
     from distr import parallel
     H = 512
-    times = [56.4, 57.9, 54.6, 53.8, 51.3, 49.8, 53.1, 63.4]          # the eight C4 cameras, ms per step (profiles/README.md)
+    times = [52.71, 54.40, 51.19, 50.40, 47.98, 46.50, 49.57, 58.67]          # the eight C4 cameras, ms per step (profiles/r02_view_balance.md)
+
+    def check(plan, N, Hh):
+        cover = np.zeros((N, Hh), np.int32)
+        for r, items in enumerate(plan):
+            assert items[0][0] == r and items[0][1] == 0 and items[0][2] >= Hh // 2
+            for (v, r0, r1) in items:
+                assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == Hh) and r1 - r0 >= 16
+                cover[v, r0:r1] += 1
+        assert (cover == 1).all()
+
     plan = parallel.balance_views(times, H)
-    cover = np.zeros((8, H), np.int32)
-    est = []
-    for r, items in enumerate(plan):
-        assert items[0][0] == r and items[0][1] == 0
-        t = 0.0
-        for (v, r0, r1) in items:
-            assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H) and r1 - r0 >= 16
-            cover[v, r0:r1] += 1
-            t += (r1 - r0 + (8 if v != r else 0)) * times[v] / H
-        est.append(t)
-    assert (cover == 1).all()
-    assert max(est) < 0.93 * max(times) and plan == parallel.balance_views(list(times), H)
+    check(plan, 8, H)
+    assert plan == parallel.balance_views(list(times), H) and plan[7][0][2] < H and len(plan[5]) == 2      # view 7 gives, the cheapest rank takes
+    est = [sum((r1 - r0 + (4 if i else 0) + (4 if (r1 < H) else 0)) * times[v] / H for i, (v, r0, r1) in enumerate(items)) for items in plan]
+    assert max(est) < 0.95 * max(times)
     assert parallel.balance_views([50.0, 50.5], H) == [[(0, 0, H)], [(1, 0, H)]]
     assert parallel.balance_views([60.0], H) == [[(0, 0, H)]]
     two = parallel.balance_views([70.0, 40.0], 192)
-    assert two == [[(0, 0, 160)], [(1, 0, 192), (0, 160, 192)]]
+    check(two, 2, 192)
+    assert two[0] == [(0, 0, 152)] and two[1] == [(1, 0, 192), (0, 152, 192)]
+    # row profile: object in rows 110..436 -> the bottom rows are background and cheap, so more of them move
+    mask = np.zeros((H, H), np.uint8)
+    mask[110:436, 128:384] = 1
+    prof = parallel.row_profile(mask)
+    assert len(prof) == H // 4 and prof[0] == prof[-1] and prof[60] > 4 * prof[0]
+    pl2 = parallel.balance_views(times, H, [prof] * 8)
+    check(pl2, 8, H)
+    assert pl2[7][0][2] < plan[7][0][2]
+    # feedback: the donors measured a larger saving than the model predicted -> their lower rows cost more -> fewer rows move
+    U = H // 4
+    loads = []
+    for r in range(8):
+        top = pl2[r][0][2] // 4
+        own = times[r] * (sum(prof[:top]) + sum(prof[top:top + 1])) / sum(prof)
+        loads.append(own - 0.5 * (times[r] - own) if top < U else times[r])
+    pl3 = parallel.balance_views(times, H, parallel.refine_profiles([prof] * 8, pl2, times, loads, H))
+    check(pl3, 8, H)
+    assert pl3[7][0][2] > pl2[7][0][2]
