@@ -412,3 +412,29 @@ def test_optimize_multi_view_distributed_rccl_multi_gpu():
         assert abs(r[0] - serial[0]) <= 2e-5 * abs(serial[0]), rank
         for a, b in zip(r[1:], serial[1:]):
             assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), rank
+
+
+def test_bench_rccl_multi_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, RCCL, one GPU per rank), including the view
+    balancing of a 5-step warm-up. Needs >= 2 GPUs: skipped on the single-GPU build boxes."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (RCCL ranks cannot share a device)')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('DISTR_DIST_BACKEND', None)
+    outs = []
+    for extra in (['--view-offset', '6', '--no-balance'], ['--view-offset', '6']):          # views 6 and 7 differ by 18 %: the plan moves rows
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(29790 + (os.getpid() % 40) + len(outs)), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+               '--warmup', '5'] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
+    plain, bal = outs
+    assert plain['n_gpus'] == 2 and plain['scaling'] == 'weak' and plain['config']['cluster_fallbacks'] == 0
+    assert abs(plain['value'] - 2 * 512 * 512 / (plain['ms_per_step'] * 1e-3)) <= 1e-6 * plain['value']
+    plan = bal['config']['balance_plan']
+    assert plan is not None and plan[1][0][2] < 512, plan              # view 7 (rank 1) hands rows to rank 0
+    assert bal['ms_per_step'] <= 1.02 * plain['ms_per_step']           # and the step is not slower than with whole views
