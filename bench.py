@@ -383,7 +383,9 @@ def main():
                                    '%s loss, fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
                                                          args.marcher, BUFFER_SIZE, RATIO,
                                                          'dense per-pixel' if args.loss == 'dense' else 'reference single-view',
-                                                         'fixed total work split shape-major then in row bands' if c5 else '1 view per GPU'),
+                                                         'fixed total work split shape-major then in row bands' if c5 else
+                                                         ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
+                                                          'ranks' if plan else '1 view per GPU')),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
                        'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
