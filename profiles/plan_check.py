@@ -1,7 +1,7 @@
 """Single-GPU check of the view balancer's cost model (run on the GPU box): renders the eight C4 views once for their masks, builds
 the plan distr.parallel.balance_views derives from the per-view step times given on the command line (view_<v>.json of
 run_round.sh, or measured here with --measure), and times every rank's work items of that plan through `bench.py --items`.
-    python profiles/plan_check.py gpurun_out/r02_final            -> every rank's measured ms under the first and the refined plan"""
+    python profiles/plan_check.py gpurun_out/r02_final [N = 8]            -> every rank's measured ms under the first and the refined plan"""
 import json
 import os
 import subprocess
@@ -36,7 +36,8 @@ def main():
         with torch.no_grad():
             _, mask, _, _, _ = functions.render_call(eng, cfg, lat, torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda())
         profs.append(parallel.row_profile(mask.reshape(H, W).cpu().numpy()))
-    N = 8
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    print('## N = %d' % N)
     plan = parallel.balance_views(times[:N], H, profs[:N])
     for title in ('first plan (row cost profile from the rendered masks)', 'refined plan (one feedback step: distr.parallel.refine_profiles with the times measured under the first plan)'):
         print('\n### %s\n' % title)
