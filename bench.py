@@ -133,8 +133,9 @@ def main():
                     help='diagnostics (N = 1, c3): the work items of the step as view:r0:r1[,view:r0:r1...] instead of one whole view, e.g. '
                          '"5:0:512,7:480:512" = what rank 5 renders under the N = 8 balance plan (profiles/r02_view_balance.md)')
     ap.add_argument('--no-balance', action='store_true',
-                    help='c3 at N > 1: keep exactly one whole view per GPU (default: after the warm-up the ranks exchange their step times and '
-                         'the slowest views hand row bands to the fastest ranks, distr.parallel.balance_views)')
+                    help='c3 at N > 1: keep exactly one whole view per GPU (default: five untimed calibration steps before the warm-up, in which the '
+                         'ranks exchange step times and row cost profiles and the slowest views hand row bands to the fastest ranks, '
+                         'distr.parallel.balance_views)')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
@@ -253,19 +254,17 @@ def main():
         last['grads'] = [l.grad for l in lats]
         return total
 
-    # ---- warm-up. View-parallel runs (c3, N > 1, dense loss) use it to balance the views: the eight cameras differ by up to 25 % in cost
-    # and every step ends in the all-reduce, so the slowest view would pace the job. The ranks all-gather their own step times and the
-    # row cost profile of their view (from its rendered mask), every rank computes the same plan (distr.parallel.balance_views), and
-    # the slowest views hand row bands (bit-identical to the same rows of the full render, gradients sum exactly) to the fastest
-    # ranks. With >= 5 warm-up steps the plan is refined once from the times measured under it (distr.parallel.refine_profiles).
-    # Total work is unchanged: N whole views per step. Every plan gets one unmeasured step first (new band shapes: allocator).
-    balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and args.warmup >= 3 and not args.items
+    # ---- calibration (view-parallel runs only: c3, N > 1, dense loss), BEFORE the W warm-up steps and like them untimed. The eight
+    # cameras differ by up to 25 % in cost and every step ends in the all-reduce, so the slowest view would pace the job. The ranks
+    # all-gather their own step times and the row cost profile of their view (from its rendered mask), every rank computes the same
+    # plan (distr.parallel.balance_views), and the slowest views hand row bands (bit-identical to the same rows of the full render,
+    # gradients sum exactly) to the fastest ranks; the plan is refined once from the times measured under it
+    # (distr.parallel.refine_profiles). Total work is unchanged: N whole views per step. Five steps: 0-1 measure the whole views,
+    # 2 warms the first plan (new band shapes: allocator), 3 measures it, 4 warms the refined plan.
+    balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and not args.items
     plan = None
     view_of = lambda r: (r + args.view_offset) % 8
     fake = os.environ.get('DISTR_BENCH_FAKE_TIMES')                  # tests: force the times on a box where the ranks share one GPU
-    refine = args.warmup >= 5 and not fake
-    i_plan = args.warmup - 4 if refine else args.warmup - 2          # W = 5: plan after steps 0-1, step 2 warms it, step 3 measures it,
-    i_refine = args.warmup - 2 if refine else -1                      # refinement after step 3, step 4 warms the final plan
 
     def apply_plan(pl):
         items[:] = [(0, view_of(v), r0, r1) for (v, r0, r1) in pl[rank]]
@@ -275,21 +274,31 @@ def main():
                 cams[v] = (torch.from_numpy(R).to(dev).requires_grad_(True), torch.from_numpy(T).to(dev).requires_grad_(True))
         pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
 
-    for w in range(args.warmup):
-        step(measure=balance and w <= max(i_plan, i_refine))
-        if balance and w == i_plan:
-            mine = float(np.median(local_ms[1:])) if len(local_ms) > 1 else local_ms[0]
-            times = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(mine, device=dev)
-            m = last_mask.get(view_of(rank))
-            prof = parallel.row_profile(m.reshape(H, W).detach().cpu().numpy()) if m is not None else [1.0] * ((H + 3) // 4)
-            profiles = parallel.allgather_vector(prof, device=dev)
-            plan = parallel.balance_views(times, H, profiles)
-            apply_plan(plan)
-        elif balance and w == i_refine and plan is not None:
+    calibration_steps = 0
+    if balance:
+        step(measure=True)
+        step(measure=True)
+        times = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(local_ms[-1], device=dev)
+        m = last_mask.get(view_of(rank))
+        prof = parallel.row_profile(m.reshape(H, W).detach().cpu().numpy()) if m is not None else [1.0] * ((H + 3) // 4)
+        profiles = parallel.allgather_vector(prof, device=dev)
+        plan = parallel.balance_views(times, H, profiles)
+        apply_plan(plan)
+        step()
+        calibration_steps = 3
+        if not fake:                                                 # (forced times cannot be re-measured)
+            step(measure=True)
             loads = parallel.allgather_scalar(local_ms[-1], device=dev)
             profiles = parallel.refine_profiles(profiles, plan, times, loads, H)
             plan = parallel.balance_views(times, H, profiles)
             apply_plan(plan)
+            step()
+            calibration_steps = 5
+        if all(len(p) == 1 for p in plan):
+            plan = None                                              # nothing moved: plain one-view-per-GPU run
+    # ---- W warm-up steps
+    for w in range(args.warmup):
+        step()
     # ---- the timed region: exactly K steps between barrier + synchronize on both sides; nothing is recorded inside it
     torch.cuda.synchronize()
     parallel.barrier()
@@ -387,7 +396,7 @@ def main():
                                                          ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
                                                           'ranks' if plan else '1 view per GPU')),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
-                       'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'loss_sum_all_ranks': float(loss_buf.item()),
+                       'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'calibration_steps_before_warmup': calibration_steps, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
                        'decoder_evals_per_step_rank0': stats['num_point_evals'],
