@@ -376,3 +376,45 @@ def test_balance_views_plan():
     pl3 = parallel.balance_views(times, H, parallel.refine_profiles([prof] * 8, pl2, times, loads, H))
     check(pl3, 8, H)
     assert pl3[7][0][2] > pl2[7][0][2]
+
+
+def test_balance_views_properties_random():
+    """Randomised property check of the view balancer (the N > 1 path of bench.py runs for the first time on the driver's multi-GPU
+    node, so the planner is exercised here on everything it could meet): for random step times, row cost profiles and image heights
+    the plan tiles every view exactly once with aligned bands of >= 16 rows, every view keeps at least half of its rows, the plan is
+    a pure function of its inputs, and under the planner's own cost model the slowest rank never gets slower."""
+    from distr import parallel
+    rs = np.random.RandomState(7)
+    moved = 0
+    for trial in range(300):
+        N = int(rs.randint(2, 9))
+        H = int(rs.choice([64, 128, 192, 256, 512, 1024])) + (int(rs.choice([0, 0, 2, 6])) if trial % 5 == 0 else 0)
+        U = (H + 3) // 4
+        times = (50.0 * (1.0 + 0.3 * rs.rand(N))).tolist()
+        if trial % 7 == 0:
+            times[int(rs.randint(N))] *= 1.5
+        profs = None
+        if trial % 3:
+            profs = []
+            for r in range(N):
+                c, w = rs.uniform(0.3, 0.7) * U, rs.uniform(0.1, 0.4) * U
+                profs.append((0.123 + np.exp(-0.5 * ((np.arange(U) - c) / w) ** 2) * rs.uniform(0.5, 3.0)).tolist())
+        plan = parallel.balance_views(times, H, profs)
+        assert plan == parallel.balance_views(list(times), H, profs)
+        cover = np.zeros((N, H), np.int32)
+        load = np.zeros(N)
+        for r, items in enumerate(plan):
+            assert items[0][0] == r and items[0][1] == 0 and items[0][2] >= (U // 2) * 4
+            for i, (v, r0, r1) in enumerate(items):
+                assert 0 <= r0 < r1 <= H and r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H)
+                assert i == 0 or r1 - r0 >= 16 or r1 == H
+                cover[v, r0:r1] += 1
+                p = np.asarray(profs[v]) if profs is not None else np.ones(U)
+                t = times[v] * p / p.sum()
+                lo, hi = r0 // 4, (r1 + 3) // 4
+                load[r] += t[lo:hi].sum() + (t[max(0, lo - 1):lo].sum() if i > 0 else 0.0) + (t[hi:hi + 1].sum() if hi < U else 0.0)
+                load[r] += parallel.BAND_FIXED * np.mean(times) if i > 0 else 0.0
+        assert (cover == 1).all()
+        assert load.max() <= max(times) * (1.0 + 1e-9)
+        moved += sum(len(p) > 1 for p in plan) > 0
+    assert moved > 100          # the sweep really exercises plans that move rows
