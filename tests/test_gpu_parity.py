@@ -394,6 +394,9 @@ def test_adam_single_view_matches_reference_golden(fixture_decoder):
     assert np.abs(hist[0, :] - ref[0, :6]).max() <= 2e-6                 # first iteration: nothing has diverged yet
     # later iterations: Adam's first update is lr*sign(g), so a coordinate whose gradient is ~0 flips through float-summation order
     # alone; the reference itself moves by the recorded floors under 1e-7 weight noise. Bar = 2 x that floor per term.
+    # (The bar is met by the default kernel configuration. Non-default debug knobs that change the summation order of the latent
+    # gradient -- DISTR_TILE_RB=2, DISTR_SAVE_MASKS=0 -- land at a different, equally valid point of that noise and can exceed 2 x
+    # floor on iterations 2-5 while every single-render golden still passes.)
     for i, nm in enumerate(('depth', 'normal', 'mask_gt', 'mask_out', 'l2reg', 'loss')):
         r_ = (np.abs(hist[:, i] - ref[:, i]) / np.maximum(np.abs(ref[:, i]), 1e-30)).max()
         assert r_ <= 2.0 * fl['g5_%s_rel' % nm], (nm, r_, fl['g5_%s_rel' % nm])
