@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
   RESOLVE(distr_mlp_backward_workspace_bytes); RESOLVE(distr_get_render_stats); RESOLVE(distr_profile_enable); RESOLVE(distr_profile_read); RESOLVE(distr_profile_read_list); RESOLVE(distr_get_live_counts);
   RESOLVE(distr_loss_workspace_bytes); RESOLVE(distr_single_loss_forward); RESOLVE(distr_single_loss_backward);
   RESOLVE(distr_warp_loss_forward); RESOLVE(distr_warp_loss_backward); RESOLVE(distr_set_color_decoder); RESOLVE(distr_color_eval); RESOLVE(distr_color_backward);
+  RESOLVE(distr_debug_mlp_layer); RESOLVE(distr_debug_tile_timing); RESOLVE(distr_debug_xchg_ts);
   const char* (*version)(void);
   size_t (*mlp_ws)(int64_t);
   size_t (*loss_ws)(int32_t, int32_t);

@@ -171,7 +171,7 @@ def test_c_abi_from_plain_c(libdistr, tmp_path):
     subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-o', exe, src, '-ldl'])
     out = subprocess.run([exe, binding.LIB_PATH], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert 'symbols=27' in out.stdout and 'version="distr' in out.stdout
+    assert 'symbols=30' in out.stdout and 'version="distr' in out.stdout
     assert ('sizeof(cfg)=%d' % C.sizeof(binding.RenderCfg)) in out.stdout
     import torch
     if not torch.cuda.is_available():
