@@ -439,7 +439,7 @@ enum { MODE_EVAL = 0, MODE_COARSE = 1, MODE_FINE = 2 };
 // A march step over `count` live rays is split by tile size so that no launch pays a full 64-ray tile latency for a small
 // remainder: rays [0, full) with full = floor(count / 16384) * 16384 (whole rounds of 256 CUs x 64 rays) go to the 64-ray
 // role; the remainder `rem` goes, by size, to
-//     rem <= t16 (4096)          16-ray tiles          (one wave of 111 us tiles; clusters below 1008 rays)
+//     rem <= t16 (4096)          16-ray tiles          (one wave of 107 us tiles; clusters up to 2048 rays)
 //     rem <= t32 (8192)          32-ray tiles          (203 us)
 //     rem <= t32 + t16 (12288)   32-ray tiles for the first t32 rays + 16-ray tiles for the rest (203 + 111 us on the same CUs:
 //                                the work is MFMA-bound, so 48 rays per CU cost 48/64 of a round whether the two tiles share
@@ -627,11 +627,15 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   int64_t lo = 0, hi = count;
   if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
   const int64_t n = hi - lo;
-  // Cluster size from the (device-side) number of rays of this launch: with at most 31 / 63 / 127 tiles, 8 / 4 / 2 compute units
-  // share each tile (+1 tile for f(origin) on the launch that carries it keeps the grid within 256 workgroups). Measured step
-  // time (C3 tail, profiles/r02_steps_c3.md): 52 us (8), 64 us (4), 94 us (2), 107 us (single workgroup).
+  // Cluster size from the (device-side) number of rays of this launch: with at most 32 / 64 / 128 tiles -- counting the extra
+  // tile for f(origin) on the one launch that carries it, so that the grid stays within 256 workgroups -- 8 / 4 / 2 compute units
+  // share each tile. Measured step time (C3 tail, profiles/r02_steps_c3.md): 52 us (8), 64 us (4), 94 us (2), 107 us (single
+  // workgroup).
   int cl = 1;
-  if (MODE != MODE_EVAL && A.xc.buf) cl = (n <= 496 && A.xc.max_cl >= 8) ? 8 : (n <= 1008 && A.xc.max_cl >= 4) ? 4 : (n <= 2032 && A.xc.min_cl <= 2) ? 2 : 1;
+  if (MODE != MODE_EVAL && A.xc.buf) {
+    const int64_t need = (n + TILE - 1) / TILE + ((MODE == MODE_FINE && origin_tile) ? 1 : 0);
+    cl = (need <= 32 && A.xc.max_cl >= 8) ? 8 : (need <= 64 && A.xc.max_cl >= 4) ? 4 : (need <= 128 && A.xc.min_cl <= 2) ? 2 : 1;
+  }
   int tile = bidx, member = 0;
   if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8).
     // (Measured alternative: member m of every cluster on XCD m, so that an XCD streams only its 1/cl slice of the weights from a
