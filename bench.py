@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# RCCL between processes needs dmabuf IPC on this driver stack (hipIpcGetMemHandle fails in legacy mode); must be in the
+# environment before the HIP runtime initialises, i.e. before `import torch`
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, 'dist-renderer_amd'), ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
@@ -65,6 +69,24 @@ def cpu_baseline(fixture, Ws, bs, latent, size, march_step, marcher):
             'sample': 'one fwd+bwd of the bench workload itself: %dx%d image of view 0, %d steps, %s, dense loss; %.1f s wall, OpenMP over rays'
                       % (size, size, march_step, marcher, t),
             'host': host_description()}
+
+
+def collective_info(world):
+    """What the collective layer itself reports (so that a reader can see RCCL saw N ranks): torch.distributed's backend and world
+    size, the RCCL version torch was built against, devices visible to rank 0."""
+    import torch.distributed as dist
+    info = {'backend': None, 'world_size': 1, 'devices_visible': torch.cuda.device_count()}
+    if world > 1 and dist.is_initialized():
+        info['backend'] = dist.get_backend()
+        info['world_size'] = dist.get_world_size()
+        info['backend_is_rccl'] = info['backend'] == 'nccl'       # torch's "nccl" backend IS RCCL on ROCm
+    try:
+        info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info['rccl_version'] = None
+    info['launcher'] = 'self-spawned torch.distributed.run' if os.environ.get('DISTR_BENCH_SPAWNED') else \
+        ('external launcher' if world > 1 else 'single process')
+    return info
 
 
 def host_description():
@@ -114,6 +136,22 @@ def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=25
             'c1_64x64_20steps': {'rays_per_s': 64 * 64 / t_c1, 'seconds': t_c1}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this very command line under torch.distributed.run with N ranks on
+    this node (one per GPU), a free rendezvous port on 127.0.0.1, and the IPC mode RCCL needs. Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), DISTR_BENCH_SPAWNED='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -140,6 +178,10 @@ def main():
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        if os.environ.get('DISTR_BENCH_SPAWNED'):
+            raise SystemExit('bench.py: spawned rank without RANK / WORLD_SIZE in its environment')
+        sys.exit(spawn_ranks(args.gpus))                 # no launcher around us: become the launcher (an external torchrun still works)
 
     global H, W, MARCH_STEP
     c5 = args.workload == 'c5'
@@ -150,9 +192,13 @@ def main():
     from distr import binding, fixture, functions, parallel
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback path exists)')
+    backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1 and backend == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit('--gpus %d but only %d HIP device(s) are visible: RCCL ranks cannot share a device (tests that time-share one '
+                         'GPU set DISTR_DIST_BACKEND=gloo; such a run is not a scaling measurement)' % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -396,6 +442,7 @@ def main():
                                                          ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
                                                           'ranks' if plan else '1 view per GPU')),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
+                       'rccl': collective_info(world),
                        'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'calibration_steps_before_warmup': calibration_steps, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],

@@ -38,17 +38,38 @@ def apply_sim3(R, T, sim3, sim3_scale):
     return R / sim3_scale, T / sim3_scale
 
 
-def compute_loss_color_warp(sdf_renderer, shape_code, images, cameras, idx1, idx2, weight_list, sim3=None, sim3_scale=None,
-                            visualizer=None):
-    dev = shape_code.device
+def pair_cameras(cameras, idx1, idx2, device, sim3=None, sim3_scale=None):
+    """Extrinsics of a view pair with the optional sim(3) folded in (loss_multi.py:10-22)."""
     cams = []
     for idx in (idx1, idx2):
         ext = cameras[idx].extrinsic
-        R, T = _as_device(ext[:, :3], dev), _as_device(ext[:, 3], dev)
+        R, T = _as_device(ext[:, :3], device), _as_device(ext[:, 3], device)
         if sim3 is not None:
             R, T = apply_sim3(R, T, sim3, sim3_scale)
         cams.append((R, T))
-    (R1, T1), (R2, T2) = cams
+    return cams
+
+
+def compute_loss_color_warp_batch(sdf_renderer, shape_code, images, cameras, pairs, weight_list, sim3=None, sim3_scale=None):
+    """compute_loss_color_warp for all view pairs of a round at once: one batched render of the 2n views
+    (SDFRenderer_warp.render_warp_batch). Returns [(loss, loss_pack), ...] in pair order, each equal to the per-pair call."""
+    dev = shape_code.device
+    args = []
+    for (idx1, idx2) in pairs:
+        (R1, T1), (R2, T2) = pair_cameras(cameras, idx1, idx2, dev, sim3, sim3_scale)
+        args.append((R1, T1, R2, T2, images[idx1], images[idx2]))
+    outs = sdf_renderer.render_warp_batch(shape_code, args)
+    loss_l2reg = torch.mean(shape_code.pow(2))
+    res = []
+    for out in outs:
+        loss = weight_list['color'] * out[0] + weight_list['l2reg'] * loss_l2reg
+        res.append((loss, {'color': _LazyScalar(out[0]), 'l2reg': _LazyScalar(loss_l2reg)}))
+    return res
+
+
+def compute_loss_color_warp(sdf_renderer, shape_code, images, cameras, idx1, idx2, weight_list, sim3=None, sim3_scale=None,
+                            visualizer=None):
+    (R1, T1), (R2, T2) = pair_cameras(cameras, idx1, idx2, shape_code.device, sim3, sim3_scale)
     view1, view2 = images[idx1], images[idx2]
     out = sdf_renderer.render_warp(shape_code, R1, T1, R2, T2, view1, view2, no_grad_normal=True)
     loss_color, color_valid_1, color_valid_2 = out[0], out[1], out[2]

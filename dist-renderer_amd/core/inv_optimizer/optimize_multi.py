@@ -23,7 +23,7 @@ import torch
 
 from core.utils.train_utils import params_to_mtrx
 
-from .loss_multi import compute_loss_color_warp
+from .loss_multi import compute_loss_color_warp, compute_loss_color_warp_batch
 
 
 def _dist_state(distributed):
@@ -75,8 +75,17 @@ def pair_indices(idx, i, rot_freq, sep_dist, num_images):
 
 
 def multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, sim3=None, sim3_scale=None, visualizer=None,
-                     pool=None):
-    """Sum of compute_loss_color_warp over `pairs` (the body of optimize_multi.py:59-76), pairs issued on the stream pool."""
+                     pool=None, batched=True):
+    """Sum of compute_loss_color_warp over `pairs` (the body of optimize_multi.py:59-76). batched (default): the 2n depth renders of
+    the round run as ONE batched launch sequence (every march step covers the live rays of all views; values and gradients are
+    those of the per-pair calls); otherwise -- or with a visualizer, which wants the pairs one by one -- the pairs are issued on the
+    stream pool."""
+    if batched and visualizer is None and hasattr(renderer, 'render_warp_batch') and 0 < 2 * len(pairs) <= 64:
+        results = compute_loss_color_warp_batch(renderer, shape_code, images, cameras, pairs, weight_list, sim3=sim3, sim3_scale=sim3_scale)
+        loss_total = 0.0
+        for loss, _ in results:
+            loss_total = loss_total + loss
+        return loss_total, results[-1][1]
     results = []
     for i, (idx1, idx2) in enumerate(pairs):
         fn = (lambda a=idx1, b=idx2: compute_loss_color_warp(renderer, shape_code, images, cameras, a, b, weight_list,
@@ -93,7 +102,7 @@ def multi_view_round(renderer, shape_code, images, cameras, pairs, weight_list, 
 def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images, cameras, weight_list,
                         num_views_per_round=8, num_iters=20, num_sample_points=30000, sep_dist=1, test_step=5, points_gt=None,
                         sim3=None, sim3_init=None, visualizer=None, vis_dir=None, vis_flag=None, full_flag=True, streams=4,
-                        on_round=None, distributed=None):
+                        on_round=None, distributed=None, batched=True):
     from distr import parallel
     rank, world = _dist_state(distributed)
     lead = rank == 0                         # printing / mesh extraction / evaluation happen once, on rank 0
@@ -118,7 +127,7 @@ def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images
             mine = pairs[rank::world]                  # view-parallel: this rank's share of the round (all of it when world == 1)
             if mine:
                 loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, mine, weight_list, sim3=sim_mtrx,
-                                                         sim3_scale=sim3_scale, visualizer=visualizer, pool=pool)
+                                                         sim3_scale=sim3_scale, visualizer=visualizer, pool=pool, batched=batched)
                 loss_total.backward()
             else:
                 loss_total = torch.zeros((), device=shape_code.device)

@@ -145,6 +145,35 @@ class SDFRenderer(object):
             min_sdf = min_sdf.detach()
         return zdepth, mask.bool(), min_sdf          # (H*W), (H*W), (H*W)
 
+    def render_depth_batch(self, latent, Rs, Ts, clamp_dist=0.1, no_grad_depth=None, no_grad_mask=None, no_grad_camera=None,
+                           ray_marching_type='recursive', use_transform=True):
+        """render_depth (renderer.py:836) of B views in ONE launch sequence (no counterpart in the reference, which renders view by
+        view: optimize_multi.py:62-81): Rs (B,3,3) / Ts (B,3) or sequences of per-view tensors, latent (1,L) shared by the views or
+        (B,L); no_grad_* = None or one bool per view. Returns (Zdepth (B,P), valid_mask (B,P) bool, min_sdf_sample (B,P)); row v is
+        bit-identical to render_depth(latent, Rs[v], Ts[v], no_grad_*=...[v]) and so are the gradients."""
+        Rs = torch.stack(list(Rs)) if not torch.is_tensor(Rs) else Rs
+        Ts = torch.stack(list(Ts)) if not torch.is_tensor(Ts) else Ts
+        B = Rs.shape[0]
+        ngd = [bool(x) for x in (no_grad_depth if no_grad_depth is not None else [False] * B)]
+        ngm = [bool(x) for x in (no_grad_mask if no_grad_mask is not None else [False] * B)]
+        ngc = [bool(x) for x in (no_grad_camera if no_grad_camera is not None else [False] * B)]
+        cfg = self._cfg(clamp_dist, self._check_marcher(ray_marching_type), use_transform, want_normal=False,
+                        no_grad_depth=all(ngd), no_grad_mask=all(ngm), no_grad_camera=all(ngc))
+        flags = [(0 if ngd[v] else binding.VIEW_GRAD_DEPTH) | (0 if ngm[v] else binding.VIEW_GRAD_MASK) |
+                 (0 if ngc[v] else binding.VIEW_GRAD_CAMERA) for v in range(B)]
+        zdepth, mask, min_sdf, _, _ = functions.render_batch_call(self._engine, cfg, latent, Rs, Ts, flags)
+        # (a view rendered with no_grad_depth ignores the upstream gradient of its Zdepth row in the backward kernel: the
+        # per-view flag does what the reference's .detach() does, renderer.py:876-877)
+        return zdepth, mask.bool(), min_sdf
+
+    def render_normal_batch(self, latent, Rs, Ts, Zdepth, valid_mask, clamp_dist=0.1, normalize=True, use_transform=True):
+        """render_normal (renderer.py:880) of B views in one launch sequence -> (B,3,P)."""
+        Rs = torch.stack(list(Rs)) if not torch.is_tensor(Rs) else Rs
+        Ts = torch.stack(list(Ts)) if not torch.is_tensor(Ts) else Ts
+        cfg = self._cfg(clamp_dist, 'recursive', use_transform, want_normal=True, normalize_normal=normalize)
+        cfg.use_depth2normal = 0
+        return functions.render_normal_batch_call(self._engine, cfg, latent, Rs, Ts, Zdepth, valid_mask)
+
     # reference: renderer.py:880
     def render_normal(self, latent, R, T, Zdepth, valid_mask, clamp_dist=0.1, MAX_POINTS=100000, no_grad=False,
                       normalize=True, use_transform=True):

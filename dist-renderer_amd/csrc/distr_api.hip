@@ -29,9 +29,8 @@ struct distr_ctx {
   DecoderDev16 D16{};
   bool has_decoder = false;
   bool profiling = false;
-  int tile_rb = 0;           // 0: hybrid (64-ray tiles, 32-ray tiles once few rays are live); 1 / 2: force 32 / 64-ray tiles
-  int hybrid_threshold = 8192;  // live-ray count below which a march step runs on 32-ray tiles
-  int tail16_threshold = 4096;  // ... and below which it runs on 16-ray tiles (16x16x4 MFMA)
+  int hybrid_threshold = 8192;  // t32: largest remainder of a march step (rays) that runs on 32-ray tiles (fine_split)
+  int tail16_threshold = 4096;  // t16: ... and on 16-ray tiles (16x16x4 MFMA)
   bool save_masks = true;       // save ReLU masks in the forward so that the backward skips the decoder recompute
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -46,8 +45,6 @@ struct distr_ctx {
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
   int min_cl = 2;               // smallest cluster: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032 (DISTR_CLUSTER_MIN=4: off)
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
-  bool persist64 = true;        // DISTR_PERSIST64=0: one workgroup per 64-ray tile in the merged launch
-  bool merged_step = true;      // DISTR_MERGED_STEP=0: one launch per tile size and step instead of one merged launch per step
 };
 
 namespace {
@@ -206,10 +203,11 @@ inline int band_rows(const distr_render_cfg& c) { return c.rows > 0 ? c.rows : c
 inline int band_row0(const distr_render_cfg& c) { return c.rows > 0 ? c.row0 : 0; }
 
 // Lays the forward workspace out; with base==nullptr only sizes are computed.
-size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks) {
+size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks, int nviews = 1) {
   Carver cv(base);
   memset(&V, 0, sizeof(V));
   V.cfg = c;
+  V.nviews = nviews;
   V.rows = band_rows(c); V.row0 = band_row0(c);
   V.band = (V.rows != c.H) ? 1 : 0;
   V.P = V.rows * c.W;
@@ -260,7 +258,8 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
     V.morigin = V.mfine + off;
     V.mstore = cv.take<uint4>((size_t)(V.morigin + 1) * 32);
   }
-  return (cv.off + 255) & ~(size_t)255;
+  V.vstride = (int64_t)((cv.off + 255) & ~(size_t)255);    // view b of a batch: the same layout b * vstride bytes further
+  return (size_t)V.vstride;
 }
 
 constexpr int BWD_CHUNK = 64;   // tiles per reduction chunk
@@ -270,8 +269,9 @@ size_t bwd_bytes(const distr_render_cfg& c) {
   const size_t smax = P * c.buffer_size + 1;
   const size_t tiles = (smax + 31) / 32 + 256;
   const size_t nblk = (P + 255) / 256, nchunks = (tiles + BWD_CHUNK - 1) / BWD_CHUNK;
-  return ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + nchunks * PSTRIDE * sizeof(float) +
-         nblk * (2 * sizeof(int32_t) + 16 * sizeof(float)) + 2048;
+  const size_t b = ((smax * sizeof(Sample) + 255) & ~(size_t)255) + tiles * PSTRIDE * sizeof(float) + nchunks * PSTRIDE * sizeof(float) +
+                   nblk * (2 * sizeof(int32_t) + 16 * sizeof(float)) + 2048;
+  return (b + 255) & ~(size_t)255;
 }
 
 inline dim3 grid1(int64_t n, int per = 256) { return dim3((unsigned)((n + per - 1) / per)); }
@@ -306,17 +306,25 @@ int distr_create(distr_ctx** out, int hip_device) {
   *out = nullptr;
   distr_ctx* ctx = new distr_ctx();
   ctx->device = hip_device;
-  if (const char* e = getenv("DISTR_TILE_RB")) ctx->tile_rb = atoi(e);
-  if (ctx->tile_rb < -1 || ctx->tile_rb > 2) ctx->tile_rb = 0;   // -1: force 16-ray tiles wherever they exist (tests)
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
+  if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
   if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
   if (const char* e = getenv("DISTR_CLUSTER_MIN")) ctx->min_cl = atoi(e);
   if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
   if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e) != 0;
-  if (const char* e = getenv("DISTR_MERGED_STEP")) ctx->merged_step = atoi(e) != 0;
-  if (const char* e = getenv("DISTR_PERSIST64")) ctx->persist64 = atoi(e) != 0;
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
-  if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
+  {
+    // invariants of the tile-size split (fine_split and the host-side grid sizes rely on them): multiples of 64,
+    // 64 <= t16 <= t32, and t16 + t32 below one full round (16384 rays) so that "remainder" ranges never reach a round
+    const int t32 = ctx->hybrid_threshold, t16 = std::min(ctx->tail16_threshold, ctx->hybrid_threshold);
+    if (t32 < 64 || t16 < 64 || (t32 & 63) || (ctx->tail16_threshold & 63) || t32 + t16 >= 16384) {
+      ctx->err = "DISTR_HYBRID_THRESHOLD / DISTR_TAIL16_THRESHOLD must be multiples of 64 with 64 <= tail16, 64 <= hybrid and "
+                 "min(tail16, hybrid) + hybrid < 16384 (got hybrid " + std::to_string(ctx->hybrid_threshold) + ", tail16 " +
+                 std::to_string(ctx->tail16_threshold) + ")";
+      *out = ctx;
+      return DISTR_ERR_INVALID_ARG;
+    }
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || hip_device < 0 || hip_device >= n) {
@@ -415,9 +423,6 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   D.b8 = b[8][0];
   D.b8x[0] = nout > 1 ? b[8][1] : 0.f; D.b8x[1] = nout > 2 ? b[8][2] : 0.f;
   D.nlat = nlat;
-  if (getenv("DISTR_DEBUG_ALIAS_WEIGHTS")) {   // timing experiment only (wrong values): every 512x512 layer streams lin1's fragments
-    for (int l : {2, 5, 6, 7}) { D.Wf[l] = D.Wf[1]; D.Wb[l] = D.Wb[1]; }
-  }
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
   return DISTR_OK;
 }
@@ -500,31 +505,55 @@ int distr_workspace_bytes(distr_ctx* ctx, const distr_render_cfg* cfg, size_t* f
   return DISTR_OK;
 }
 
-int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
-                         float* zdepth, uint8_t* mask, float* min_sdf, float* depth, float* normal, void* ws, size_t ws_bytes,
-                         void* stream) {
-  if (!ctx) return DISTR_ERR_INVALID_ARG;
-  EntryGuard guard_(ctx);
+namespace {
+
+inline int32_t cfg_view_flags(const distr_render_cfg& c) {
+  return (c.grad_depth ? VF_GRAD_DEPTH : 0) | (c.grad_mask ? VF_GRAD_MASK : 0) | (c.grad_camera ? VF_GRAD_CAMERA : 0);
+}
+
+// per-view gradient switches of a batch: null -> every view uses cfg's; a view may only switch OFF what cfg has on (the
+// workspace layout, e.g. whether ReLU masks are saved, follows cfg)
+int make_view_flags(distr_ctx* ctx, const distr_render_cfg& c, int nviews, const int32_t* view_flags, ViewFlags& vf) {
+  memset(&vf, 0, sizeof(vf));
+  const int32_t all = cfg_view_flags(c);
+  for (int b = 0; b < nviews; ++b) {
+    const int32_t f = view_flags ? view_flags[b] : all;
+    if (f & ~all) return fail(ctx, DISTR_ERR_INVALID_ARG, "view_flags[%d] = %d enables a gradient that cfg (flags %d) has off", b, f, all);
+    vf.f[b] = (uint8_t)f;
+  }
+  return DISTR_OK;
+}
+
+inline int64_t pad_to(int64_t v, int64_t g) { return (v + g - 1) / g * g; }
+
+int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews, const int32_t* view_flags, const float* latent,
+                        int64_t lat_stride, const float* R, const float* T, float* zdepth, uint8_t* mask, float* min_sdf,
+                        float* depth, float* normal, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
+  if (nviews < 1 || nviews > DISTR_MAX_VIEWS) return fail(ctx, DISTR_ERR_INVALID_ARG, "nviews %d not in [1, %d]", nviews, DISTR_MAX_VIEWS);
+  if (lat_stride != 0 && lat_stride < LAT) return fail(ctx, DISTR_ERR_INVALID_ARG, "latent_stride must be 0 (shared shape code) or >= %d", LAT);
   if (!latent || !R || !T || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
   View V;
-  const size_t need = make_view(*cfg, ws, V, ctx->save_masks);
-  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
+  const size_t single = make_view(*cfg, ws, V, ctx->save_masks, nviews);
+  if (ws_bytes < single * nviews) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, single * nviews);
+  ViewFlags vf;
+  rc = make_view_flags(ctx, *cfg, nviews, view_flags, vf);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const DecoderDev& D = ctx->D;
   const int P = V.P;
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;   // tile used for dense launches
-  const int TILE = 32 * rb_dense;
+  const unsigned NV = (unsigned)nviews;
+  auto gridv = [&](int64_t n) { return dim3((unsigned)((n + 255) / 256), NV); };   // (blocks of 256, view)
 
-  hipLaunchKernelGGL(k_prep, dim3(4), dim3(256), 0, s, V.C, D, latent, R, T);
+  hipLaunchKernelGGL(k_prep, dim3(4, NV), dim3(256), 0, s, V, D, latent, lat_stride, R, T, vf);
   LAUNCH_CHECK("k_prep");
   for (int l = 0; l < V.nlev; ++l) {
-    hipLaunchKernelGGL(k_setup_level, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
+    hipLaunchKernelGGL(k_setup_level, gridv(V.lv[l].n), dim3(256), 0, s, V, l);
     LAUNCH_CHECK("k_setup_level");
     if (V.band) {
-      hipLaunchKernelGGL(k_maxinit_full, grid1((int64_t)V.lv[l].full_h * V.lv[l].w), dim3(256), 0, s, V, l);
+      hipLaunchKernelGGL(k_maxinit_full, gridv((int64_t)V.lv[l].full_h * V.lv[l].w), dim3(256), 0, s, V, l);
       LAUNCH_CHECK("k_maxinit_full");
     }
   }
@@ -532,25 +561,25 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
   MarchArgs A;
   memset(&A, 0, sizeof(A));
   A.V = V;
-  A.t16 = 0; A.t32 = 0; A.which = 64;
-  // f(origin) (padded rows) is evaluated by one extra workgroup of ONE march launch: with the tile-size split it rides on
-  // the 16-ray launch of the last step (free: a tail step); otherwise on the first march launch of the render
-  const bool split_cfg = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0 && ctx->tail16_threshold > 0;
-  bool origin_done = split_cfg;
-  distr_ctx::XRegion* xr = (split_cfg || ctx->tile_rb == -1) ? xchg_region(ctx, s) : nullptr;
+  const bool recursive = cfg->marcher != DISTR_MARCH_TRIVIAL;     // live-ray lists + tile-size split (fine_split)
+  const int t32 = ctx->hybrid_threshold, t16 = std::min(ctx->tail16_threshold, ctx->hybrid_threshold);
+  A.t16 = recursive ? t16 : 0; A.t32 = recursive ? t32 : 0; A.which = 64;
+  // f(origin) of every view (sample point of padded rows) is evaluated by nviews extra workgroups of ONE march launch: for the
+  // recursive marchers they ride on the 16-ray role of the last step (free: a tail step); 'trivial' puts them on its first launch
+  distr_ctx::XRegion* xr = recursive ? xchg_region(ctx, s) : nullptr;
+  auto up8 = [](int64_t v) { return (int32_t)((v + 7) / 8 * 8); };
   for (int l = V.nlev - 1; l >= 1; --l) {
-    hipLaunchKernelGGL(k_coarse_init, grid1(V.lv[l].n), dim3(256), 0, s, V, l);
+    hipLaunchKernelGGL(k_coarse_init, gridv(V.lv[l].n), dim3(256), 0, s, V, l);
     LAUNCH_CHECK("k_coarse_init");
     for (int st = 0; st < V.lv[l].steps; ++st) {
-      A.lvl = l; A.step = st; A.origin_tile = origin_done ? 0 : 1;
-      origin_done = true;
-      // tile size of a coarse level from its (host-known) pixel count: a level that fits one round of 16- / 32-ray tiles
-      // runs on those (small images: 111 / 212 us per step instead of 380 us), see fine_range
+      A.lvl = l; A.step = st; A.origin_tile = 0;
+      // tile size of a coarse level from the (host-known) pixel count of all views: a level that fits one round of 16- / 32-ray
+      // tiles runs on those (small images: 111 / 212 us per step instead of 380 us)
       const int64_t ln = V.lv[l].n;
-      const bool c16 = !A.origin_tile && ((split_cfg && ln <= ctx->tail16_threshold) || ctx->tile_rb == -1);
-      const int crb = (split_cfg && ln <= ctx->hybrid_threshold) ? 1 : rb_dense;
+      const bool c16 = nviews * pad_to(ln, 16) <= t16;
+      const int crb = (nviews * pad_to(ln, 32) <= t32) ? 1 : 2;
       const int ctile = c16 ? 16 : 32 * crb;
-      unsigned tiles = (unsigned)((ln + ctile - 1) / ctile) + (A.origin_tile ? 1u : 0u);
+      unsigned tiles = NV * (unsigned)((ln + ctile - 1) / ctile);
       A.xc = next_xchg(c16 ? xr : nullptr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
       if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
@@ -568,98 +597,171 @@ int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const floa
       LAUNCH_CHECK("k_march<coarse>");
     }
   }
-  hipLaunchKernelGGL(k_fine_init, grid1(P), dim3(256), 0, s, V);
+  hipLaunchKernelGGL(k_fine_init, gridv(P), dim3(256), 0, s, V);
   LAUNCH_CHECK("k_fine_init");
+  // upper bounds of a step's live rays in the virtual concatenation of the views (every view padded to 16 / 64 rays)
+  const int64_t N64 = (int64_t)nviews * pad_to(P, 64);
   for (int st = 0; st < V.fine_steps; ++st) {
-    A.lvl = 0; A.step = st; A.origin_tile = origin_done ? 0 : 1;
-    origin_done = true;
-    const unsigned tiles = (unsigned)((P + TILE - 1) / TILE) + (A.origin_tile ? 1u : 0u);
-    // tile-size split of the step (fine_range): 64-ray kernel first, then the 32- and 16-ray kernels for the remainder
-    const bool split = ctx->tile_rb == 0 && cfg->marcher != DISTR_MARCH_TRIVIAL && ctx->hybrid_threshold > 0;
-    const bool force16 = ctx->tile_rb == -1 && cfg->marcher != DISTR_MARCH_TRIVIAL && !A.origin_tile;
-    A.t32 = split ? ctx->hybrid_threshold : 0;
-    A.t16 = split ? std::min(ctx->tail16_threshold, ctx->hybrid_threshold) : 0;
-    A.which = 32 * rb_dense;
-    if (force16) { A.t16 = 0x7fffffff; A.t32 = 0x7fffffff; }       // tests: whole step on 16-ray tiles (rem = count when < 16384...)
-    // the live count never exceeds P: with P <= t32 the 64-ray range of the split is provably empty (and with P <= t16 the
-    // 32-ray range too), so those launches are skipped on the host
-    const bool skip64 = split && !A.origin_tile && P <= A.t32 + A.t16 && A.t16 > 0;   // (up to t32 + t16 rays: 32- then 16-ray tiles)
-    const bool skip32 = split && P <= A.t16;
+    A.lvl = 0; A.step = st;
     timer.begin();
-    if (split_cfg && ctx->merged_step && !A.origin_tile) {
-      // one launch per step: the three tile sizes are roles of the same grid (k_step)
-      auto up8 = [](int64_t v) { return (int32_t)((v + 7) / 8 * 8); };
-      StepGrid G;
-      G.n64 = skip64 ? 0 : std::min(up8((P + 63) / 64), ctx->persist64 ? 256 : 0x7fffffff);   // persistent: at most one 64-ray workgroup per CU
-      G.n32 = (A.t32 > A.t16 && !skip32) ? up8((std::min(P, A.t32) + 31) / 32) : 0;
-      MarchArgs A2 = A;
-      A2.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
-      A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
-      unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
-      if (xr) n16 = std::max(n16, 256u);
-      G.n16 = up8(n16);
-      const unsigned grid = (unsigned)(G.n64 + G.n32 + G.n16);
-      if (V.save_masks) hipLaunchKernelGGL((k_step<true>), dim3(grid), dim3(NTHREADS), 0, s, A2, D, ctx->D16, G);
-      else hipLaunchKernelGGL((k_step<false>), dim3(grid), dim3(NTHREADS), 0, s, A2, D, ctx->D16, G);
+    if (!recursive) {
+      // 'trivial': every in-sphere ray, every step, on 64-ray tiles
+      A.origin_tile = (st == 0) ? 1 : 0;
+      const unsigned tiles = NV * (unsigned)((P + 63) / 64) + (A.origin_tile ? NV : 0u);
+      if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       timer.end();
-      LAUNCH_CHECK("k_step");
+      LAUNCH_CHECK("k_march<fine>");
       continue;
     }
-    if (!force16 && !skip64) {
-      if (V.save_masks) {
-        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-      } else {
-        if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
-      }
-    }
-    if (split || force16) {
-      MarchArgs A2 = A;
-      A2.origin_tile = 0;
-      if (split && A.t32 > A.t16 && !skip32) {
-        A2.which = 32;
-        const unsigned n32 = (unsigned)((std::min(P, A.t32) + 31) / 32);
-        if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 1, true>), dim3(n32), dim3(NTHREADS), 0, s, A2, D);
-        else hipLaunchKernelGGL((k_march<MODE_FINE, 1, false>), dim3(n32), dim3(NTHREADS), 0, s, A2, D);
-      }
-      if (A.t16 > 0) {
-        A2.which = 16;
-        A2.origin_tile = (split_cfg && st == V.fine_steps - 1) ? 1 : 0;
-        A2.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
-        // grid: one workgroup per 16-ray tile of the largest possible remainder (+1 for f(origin) in the launch that
-        // carries it); cluster tiles (8 / 4 workgroups per tile of at most 31 / 63 tiles + the origin tile) need 256
-        unsigned n16 = (unsigned)((std::min((int64_t)P, (int64_t)A.t16) + 15) / 16) + (A2.origin_tile ? 1u : 0u);
-        if (xr) n16 = std::max(n16, 256u);
-        const unsigned pad16 = 0u;
-        if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_FINE, true>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
-        else hipLaunchKernelGGL((k_march16<MODE_FINE, false>), dim3(n16), dim3(NTHREADS), pad16, s, A2, D, ctx->D16);
-      }
-    }
+    // one launch per step: the three tile sizes are roles of the same grid (k_step, fine_split). Roles that are provably empty
+    // from the pixel count alone get no workgroups: with N64 <= bound the remainder rules never reach the 64-ray role (bound <
+    // one round, distr_create), with N64 <= t16 the 32-ray role stays empty too.
+    const int64_t bound = (t16 < t32) ? (int64_t)t32 + t16 : t32;
+    const bool skip64 = N64 <= bound;
+    const bool skip32 = t32 <= t16 || N64 <= t16;
+    StepGrid G;
+    G.n64 = skip64 ? 0 : std::min(up8(N64 / 64), 256);            // persistent: at most one 64-ray workgroup per CU
+    G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
+    A.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
+    A.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
+    unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
+    if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
+    G.n16 = up8(n16);
+    const unsigned grid = (unsigned)(G.n64 + G.n32 + G.n16);
+    if (V.save_masks) hipLaunchKernelGGL((k_step<true>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+    else hipLaunchKernelGGL((k_step<false>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
     timer.end();
-    LAUNCH_CHECK("k_march<fine>");
+    LAUNCH_CHECK("k_step");
   }
-  hipLaunchKernelGGL(k_finalize, grid1(P), dim3(256), 0, s, V, zdepth, mask, min_sdf, depth);
+  hipLaunchKernelGGL(k_finalize, gridv(P), dim3(256), 0, s, V, zdepth, mask, min_sdf, depth);
   LAUNCH_CHECK("k_finalize");
   if (cfg->want_normal) {
     if (cfg->use_depth2normal) {
-      hipLaunchKernelGGL(k_depth2normal, grid1(P), dim3(256), 0, s, V, depth, normal);
+      hipLaunchKernelGGL(k_depth2normal, gridv(P), dim3(256), 0, s, V, depth, normal);
       LAUNCH_CHECK("k_depth2normal");
     } else {
-      if (normal) HIP_TRY(hipMemsetAsync(normal, 0, (size_t)P * 3 * sizeof(float), s));
+      if (normal) HIP_TRY(hipMemsetAsync(normal, 0, (size_t)nviews * P * 3 * sizeof(float), s));
       BwdArgs B;
       memset(&B, 0, sizeof(B));
-      B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = V.zdepth_s;
-      B.out_sdf = V.n_sdf; B.out_g = V.n_g;
-      if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
-      else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
+      B.V = V; B.zdepth = V.zdepth_s; B.zstride = V.vstride;
+      hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3(NV * (unsigned)((P + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
       LAUNCH_CHECK("k_bwd<pointgrad>");
-      hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
-                         (const float*)V.n_sdf, (const float*)V.n_g, normal, (float*)nullptr, V.nrm_t);
+      hipLaunchKernelGGL(k_normal_finish, gridv(P), dim3(256), 0, s, V, normal, (float*)nullptr, 1);
       LAUNCH_CHECK("k_normal_finish");
     }
   }
   return DISTR_OK;
+}
+
+int render_backward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews, const void* ws, size_t ws_bytes, const float* g_zdepth,
+                         const float* g_min_sdf, const float* g_depth, const float* g_normal, float* g_latent, float* g_R,
+                         float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  if (nviews < 1 || nviews > DISTR_MAX_VIEWS) return fail(ctx, DISTR_ERR_INVALID_ARG, "nviews %d not in [1, %d]", nviews, DISTR_MAX_VIEWS);
+  if (!ws || !ws_bwd) return fail(ctx, DISTR_ERR_INVALID_ARG, "null workspace");
+  if (!cfg->save_for_backward) return fail(ctx, DISTR_ERR_INVALID_ARG, "forward was run with save_for_backward=0");
+  View V;
+  const size_t single = make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks, nviews);
+  if (ws_bytes < single * nviews) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, single * nviews);
+  const size_t bsingle = bwd_bytes(*cfg);
+  if (ws_bwd_bytes < bsingle * nviews) return fail(ctx, DISTR_ERR_WORKSPACE, "backward workspace too small: %zu < %zu", ws_bwd_bytes, bsingle * nviews);
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderDev& D = ctx->D;
+  const int P = V.P;
+  const unsigned NV = (unsigned)nviews;
+  const size_t smax = (size_t)P * cfg->buffer_size + 1;
+  constexpr int TILE = 64;
+  Carver cv(ws_bwd);
+  BwdWs W;
+  W.bstride = (int64_t)bsingle;
+  W.samples = cv.take<Sample>(smax);
+  const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
+  const unsigned prows = (unsigned)((smax + 31) / 32) + 256;     // partial rows (sized for 32-sample tiles: bwd_bytes)
+  W.partial = cv.take<float>((size_t)prows * PSTRIDE);
+  const int nblk = (P + 255) / 256;
+  const unsigned nchunks = (prows + BWD_CHUNK - 1) / BWD_CHUNK;
+  W.chunk_part = cv.take<float>((size_t)nchunks * PSTRIDE);
+  W.BB.cnt = cv.take<int32_t>(nblk); W.BB.off = cv.take<int32_t>(nblk); W.BB.acc = cv.take<float>((size_t)nblk * 16);
+  hipLaunchKernelGGL(k_bwd_prep<false>, dim3(nblk, NV), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, W);
+  LAUNCH_CHECK("k_bwd_prep<count>");
+  hipLaunchKernelGGL(k_bwd_scan, dim3(NV), dim3(256), 0, s, V, W, nblk);
+  LAUNCH_CHECK("k_bwd_scan");
+  hipLaunchKernelGGL(k_bwd_prep<true>, dim3(nblk, NV), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, W);
+  LAUNCH_CHECK("k_bwd_prep<emit>");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.V = V; B.samples = W.samples; B.partial = W.partial; B.bstride = W.bstride;
+  // tile-size split of every view's sample list (bwd_range): full rounds on 64-sample tiles, a small remainder on 32-sample tiles
+  const bool bsplit = V.save_masks != 0;
+  if (bsplit) {
+    B.split = 1;
+    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+  } else {
+    hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(NV * tiles), dim3(NTHREADS), 0, s, B, D);     // DISTR_SAVE_MASKS=0: recompute the forward
+  }
+  LAUNCH_CHECK("k_bwd");
+  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, nchunks, NV), dim3(256), 0, s, V, W, BWD_CHUNK, bsplit ? -1 : TILE);
+  LAUNCH_CHECK("k_bwd_reduce");
+  hipLaunchKernelGGL(k_bwd_final, dim3(NV), dim3(256), 0, s, V, D, W, (int)nchunks, BWD_CHUNK, bsplit ? -1 : TILE, g_latent, g_R, g_T);
+  LAUNCH_CHECK("k_bwd_final");
+  return DISTR_OK;
+}
+
+int render_normal_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews, const float* latent, int64_t lat_stride, const float* R,
+                       const float* T, const float* zdepth, const uint8_t* mask, float* normal3xP, void* ws, size_t ws_bytes,
+                       void* stream) {
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  int rc = check_cfg(ctx, cfg);
+  if (rc) return rc;
+  if (nviews < 1 || nviews > DISTR_MAX_VIEWS) return fail(ctx, DISTR_ERR_INVALID_ARG, "nviews %d not in [1, %d]", nviews, DISTR_MAX_VIEWS);
+  if (lat_stride != 0 && lat_stride < LAT) return fail(ctx, DISTR_ERR_INVALID_ARG, "latent_stride must be 0 (shared shape code) or >= %d", LAT);
+  if (!latent || !R || !T || !zdepth || !mask || !normal3xP || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
+  View V;
+  const size_t single = make_view(*cfg, ws, V, ctx->save_masks, nviews);
+  if (ws_bytes < single * nviews) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, single * nviews);
+  hipStream_t s = (hipStream_t)stream;
+  const DecoderDev& D = ctx->D;
+  const int P = V.P;
+  const unsigned NV = (unsigned)nviews;
+  ViewFlags vf;
+  rc = make_view_flags(ctx, *cfg, nviews, nullptr, vf);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_prep, dim3(4, NV), dim3(256), 0, s, V, D, latent, lat_stride, R, T, vf);
+  LAUNCH_CHECK("k_prep");
+  HIP_TRY(hipMemsetAsync(normal3xP, 0, (size_t)nviews * P * 3 * sizeof(float), s));
+  hipLaunchKernelGGL(k_mask_list, dim3((unsigned)((P + 255) / 256), NV), dim3(256), 0, s, V, mask);
+  LAUNCH_CHECK("k_mask_list");
+  BwdArgs B;
+  memset(&B, 0, sizeof(B));
+  B.V = V; B.zdepth = zdepth; B.zstride = (int64_t)P * sizeof(float);
+  hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3(NV * (unsigned)((P + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+  LAUNCH_CHECK("k_bwd<pointgrad>");
+  hipLaunchKernelGGL(k_normal_finish, dim3((unsigned)((P + 255) / 256), NV), dim3(256), 0, s, V, (float*)nullptr, normal3xP, 0);
+  LAUNCH_CHECK("k_normal_finish");
+  return DISTR_OK;
+}
+
+}  // namespace
+
+int distr_render_forward(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
+                         float* zdepth, uint8_t* mask, float* min_sdf, float* depth, float* normal, void* ws, size_t ws_bytes,
+                         void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  return render_forward_impl(ctx, cfg, 1, nullptr, latent, 0, R, T, zdepth, mask, min_sdf, depth, normal, ws, ws_bytes, stream);
+}
+
+int distr_render_forward_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const int32_t* view_flags,
+                               const float* latent, int64_t latent_stride, const float* R, const float* T, float* zdepth,
+                               uint8_t* mask, float* min_sdf, float* depth, float* normal, void* ws, size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  return render_forward_impl(ctx, cfg, nviews, view_flags, latent, latent_stride, R, T, zdepth, mask, min_sdf, depth, normal, ws,
+                             ws_bytes, stream);
 }
 
 int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const void* ws, size_t ws_bytes, const float* g_zdepth,
@@ -667,95 +769,32 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
                           float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
   EntryGuard guard_(ctx);
-  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
-  int rc = check_cfg(ctx, cfg);
-  if (rc) return rc;
-  if (!ws || !ws_bwd) return fail(ctx, DISTR_ERR_INVALID_ARG, "null workspace");
-  if (!cfg->save_for_backward) return fail(ctx, DISTR_ERR_INVALID_ARG, "forward was run with save_for_backward=0");
-  View V;
-  const size_t need = make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks);
-  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "forward workspace too small: %zu < %zu", ws_bytes, need);
-  if (ws_bwd_bytes < bwd_bytes(*cfg)) return fail(ctx, DISTR_ERR_WORKSPACE, "backward workspace too small: %zu < %zu", ws_bwd_bytes, bwd_bytes(*cfg));
-  hipStream_t s = (hipStream_t)stream;
-  const DecoderDev& D = ctx->D;
-  const int P = V.P;
-  const size_t smax = (size_t)P * cfg->buffer_size + 1;
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  Carver cv(ws_bwd);
-  Sample* samples = cv.take<Sample>(smax);
-  const unsigned tiles = (unsigned)((smax + TILE - 1) / TILE);
-  const unsigned prows = tiles + 256;     // partial rows: a split list (bwd_range) has up to 256 32-sample tiles after the 64-sample ones
-  float* partial = cv.take<float>((size_t)prows * PSTRIDE);
+  return render_backward_impl(ctx, cfg, 1, ws, ws_bytes, g_zdepth, g_min_sdf, g_depth, g_normal, g_latent, g_R, g_T, ws_bwd,
+                              ws_bwd_bytes, stream);
+}
 
-  const int nblk = (P + 255) / 256;
-  const unsigned nchunks = (prows + BWD_CHUNK - 1) / BWD_CHUNK;
-  float* chunk_part = cv.take<float>((size_t)nchunks * PSTRIDE);
-  BwdBlocks BB;
-  BB.cnt = cv.take<int32_t>(nblk); BB.off = cv.take<int32_t>(nblk); BB.acc = cv.take<float>((size_t)nblk * 16);
-  hipLaunchKernelGGL(k_bwd_prep<false>, dim3(nblk), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples, BB);
-  LAUNCH_CHECK("k_bwd_prep<count>");
-  hipLaunchKernelGGL(k_bwd_scan, dim3(1), dim3(256), 0, s, V, BB, nblk, samples);
-  LAUNCH_CHECK("k_bwd_scan");
-  hipLaunchKernelGGL(k_bwd_prep<true>, dim3(nblk), dim3(256), 0, s, V, g_zdepth, g_min_sdf, g_depth, g_normal, samples, BB);
-  LAUNCH_CHECK("k_bwd_prep<emit>");
-  BwdArgs B;
-  memset(&B, 0, sizeof(B));
-  B.V = V; B.samples = samples; B.count_ptr = &V.C->cnt_samples; B.partial = partial;
-  // tile-size split of the sample list (bwd_range): full rounds on 64-sample tiles, a small remainder on 32-sample tiles
-  const bool bsplit = V.save_masks && ctx->tile_rb == 0 && ctx->hybrid_threshold > 0;
-  if (bsplit) {
-    B.split = 1;
-    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3((unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
-    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3((unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
-  } else if (V.save_masks) {
-    if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
-    else hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
-  } else {
-    if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_FULL, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
-    else hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, D);
-  }
-  LAUNCH_CHECK("k_bwd<full>");
-  hipLaunchKernelGGL(k_bwd_reduce, dim3((2 * HID + 12 + 255) / 256, nchunks), dim3(256), 0, s, V, (const float*)partial, chunk_part,
-                     BWD_CHUNK, bsplit ? -1 : TILE);
-  LAUNCH_CHECK("k_bwd_reduce");
-  hipLaunchKernelGGL(k_bwd_final, dim3(1), dim3(256), 0, s, V, D, (const float*)chunk_part, (int)nchunks, BWD_CHUNK,
-                     bsplit ? -1 : TILE, g_latent, g_R, g_T);
-  LAUNCH_CHECK("k_bwd_final");
-  return DISTR_OK;
+int distr_render_backward_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const void* ws, size_t ws_bytes,
+                                const float* g_zdepth, const float* g_min_sdf, const float* g_depth, const float* g_normal,
+                                float* g_latent, float* g_R, float* g_T, void* ws_bwd, size_t ws_bwd_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  return render_backward_impl(ctx, cfg, nviews, ws, ws_bytes, g_zdepth, g_min_sdf, g_depth, g_normal, g_latent, g_R, g_T, ws_bwd,
+                              ws_bwd_bytes, stream);
 }
 
 int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent, const float* R, const float* T,
                         const float* zdepth, const uint8_t* mask, float* normal3xP, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
   EntryGuard guard_(ctx);
-  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
-  int rc = check_cfg(ctx, cfg);
-  if (rc) return rc;
-  if (!latent || !R || !T || !zdepth || !mask || !normal3xP || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "null device pointer");
-  View V;
-  const size_t need = make_view(*cfg, ws, V, ctx->save_masks);
-  if (ws_bytes < need) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
-  hipStream_t s = (hipStream_t)stream;
-  const DecoderDev& D = ctx->D;
-  const int P = V.P;
-  hipLaunchKernelGGL(k_prep, dim3(4), dim3(256), 0, s, V.C, D, latent, R, T);
-  LAUNCH_CHECK("k_prep");
-  HIP_TRY(hipMemsetAsync(normal3xP, 0, (size_t)P * 3 * sizeof(float), s));
-  hipLaunchKernelGGL(k_mask_list, grid1(P), dim3(256), 0, s, P, mask, V.nlist, &V.C->cnt_normal);
-  LAUNCH_CHECK("k_mask_list");
-  BwdArgs B;
-  memset(&B, 0, sizeof(B));
-  B.V = V; B.count_ptr = &V.C->cnt_normal; B.pix_list = V.nlist; B.zdepth = zdepth; B.out_sdf = V.n_sdf; B.out_g = V.n_g;
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
-  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((P + TILE - 1) / TILE), dim3(NTHREADS), 0, s, B, D);
-  LAUNCH_CHECK("k_bwd<pointgrad>");
-  hipLaunchKernelGGL(k_normal_finish, grid1(P), dim3(256), 0, s, V, (const int32_t*)&V.C->cnt_normal, (const int32_t*)V.nlist,
-                     (const float*)V.n_sdf, (const float*)V.n_g, (float*)nullptr, normal3xP, (float*)nullptr);
-  LAUNCH_CHECK("k_normal_finish");
-  return DISTR_OK;
+  return render_normal_impl(ctx, cfg, 1, latent, 0, R, T, zdepth, mask, normal3xP, ws, ws_bytes, stream);
+}
+
+int distr_render_normal_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const float* latent, int64_t latent_stride,
+                              const float* R, const float* T, const float* zdepth, const uint8_t* mask, float* normal3xP, void* ws,
+                              size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  return render_normal_impl(ctx, cfg, nviews, latent, latent_stride, R, T, zdepth, mask, normal3xP, ws, ws_bytes, stream);
 }
 
 size_t distr_mlp_workspace_bytes(int64_t n) { (void)n; return 2 * HID * sizeof(float) + 256; }
@@ -776,12 +815,12 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   memset(&A, 0, sizeof(A));
   A.xyz = xyz; A.sdf_out = sdf; A.c0c4 = c0c4; A.n = n; A.clamp = clamp;
   MarchTimer timer(ctx, s);
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
   timer.begin();
-  if (ctx->tile_rb == -1) hipLaunchKernelGGL((k_march16<MODE_EVAL, false>), dim3((unsigned)((n + 15) / 16)), dim3(NTHREADS), 0, s, A, ctx->D, ctx->D16);
-  else if (rb_dense == 1) hipLaunchKernelGGL((k_march<MODE_EVAL, 1, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
-  else hipLaunchKernelGGL((k_march<MODE_EVAL, 2, false>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, A, ctx->D);
+  // a point list that fits one wave of 16-ray tiles runs on those (107 us instead of a 380 us 64-ray tile: decode_sdf on a few
+  // thousand points is latency-bound); same values bit for bit
+  if (n <= std::min(ctx->tail16_threshold, ctx->hybrid_threshold))
+    hipLaunchKernelGGL((k_march16<MODE_EVAL, false>), dim3((unsigned)((n + 15) / 16)), dim3(NTHREADS), 0, s, A, ctx->D, ctx->D16);
+  else hipLaunchKernelGGL((k_march<MODE_EVAL, 2, false>), dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, A, ctx->D);
   timer.end();
   LAUNCH_CHECK("k_march<eval>");
   return DISTR_OK;
@@ -802,10 +841,7 @@ int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.n = n; B.xyz = xyz; B.c0c4 = c0c4; B.out_sdf = sdf; B.out_g = grad;
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
-  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, B, ctx->D);
+  hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, B, ctx->D);
   LAUNCH_CHECK("k_bwd<pointgrad>");
   return DISTR_OK;
 }
@@ -834,11 +870,8 @@ int distr_mlp_backward(distr_ctx* ctx, const float* latent, const float* xyz, in
   BwdArgs B;
   memset(&B, 0, sizeof(B));
   B.n = n; B.xyz = xyz; B.c0c4 = c0c4; B.coef = g_sdf; B.clamp = clamp; B.partial = partial; B.out_g = g_xyz;
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
-  if (rb_dense == 1) hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 1>), dim3(tiles), dim3(NTHREADS), 0, s, B, ctx->D);
-  else hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, ctx->D);
+  const unsigned tiles = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL((k_bwd<BWD_POINTGRAD, 2>), dim3(tiles), dim3(NTHREADS), 0, s, B, ctx->D);
   LAUNCH_CHECK("k_bwd<pointgrad+latent>");
   if (g_latent) {
     hipLaunchKernelGGL(k_points_latent_grad, dim3(1), dim3(256), 0, s, (const float*)partial, (int)tiles, ctx->D, g_latent);
@@ -858,10 +891,7 @@ int distr_debug_mlp_layer(distr_ctx* ctx, const float* latent, const float* xyz,
   float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
   LAUNCH_CHECK("k_latent_consts");
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D, (long long*)nullptr);
-  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D, (long long*)nullptr);
+  hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, layer, out, ctx->D, (long long*)nullptr);
   LAUNCH_CHECK("k_debug_layer");
   return DISTR_OK;
 }
@@ -877,10 +907,7 @@ int distr_debug_tile_timing(distr_ctx* ctx, const float* latent, const float* xy
   float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);
   LAUNCH_CHECK("k_latent_consts");
-  const int rb_dense = (ctx->tile_rb == 1) ? 1 : 2;
-  const int TILE = 32 * rb_dense;
-  if (rb_dense == 1) hipLaunchKernelGGL((k_debug_layer<1>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, 8, sdf_out, ctx->D, ts_out);
-  else hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, 8, sdf_out, ctx->D, ts_out);
+  hipLaunchKernelGGL((k_debug_layer<2>), dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, 8, sdf_out, ctx->D, ts_out);
   LAUNCH_CHECK("k_debug_layer<timing>");
   return DISTR_OK;
 }

@@ -24,6 +24,7 @@ struct Consts {
   float latent[LAT];
   float R[9], T[3], c[3];
   float cdist;
+  int32_t vflags;         // per-view gradient switches (VF_*): a batch renders views with different no_grad_* options in one launch
   int32_t xchg_err;       // cluster tiles that fell back to the single-workgroup path (not assembled in time / barrier timeout); results stay exact
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
   uint32_t maxinit_bits[3];
@@ -71,7 +72,84 @@ struct View {
   uint8_t* mask_s;
   int32_t* nlist;
   float *n_sdf, *n_g;
+  // Batch of views (distr_render_forward_batch): `nviews` independent views (own camera, own latent constants, own live lists
+  // and counters) share every launch. View b's workspace is this one shifted by b * vstride bytes (view_at); a march tile never
+  // mixes views, so per-tile state (camera, c0 / c4 staged in LDS) stays uniform and every ray's arithmetic is exactly the
+  // single-view one.
+  int32_t nviews;
+  int64_t vstride;
 };
+
+enum { VF_GRAD_DEPTH = 1, VF_GRAD_MASK = 2, VF_GRAD_CAMERA = 4 };
+
+template <typename T>
+__device__ __forceinline__ void adv(T*& p, int64_t d) { if (p) p = reinterpret_cast<T*>(reinterpret_cast<char*>(p) + d); }
+
+// workspace of view b of a batch (b uniform over the workgroup: pure SALU pointer arithmetic, only the members a kernel
+// touches are materialised)
+__device__ __forceinline__ View view_at(const View& V0, int b) {
+  View V = V0;
+  if (V0.nviews <= 1) return V;
+  const int64_t d = (int64_t)b * V0.vstride;
+  adv(V.C, d);
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    adv(V.lv[l].valid, d); adv(V.lv[l].list, d); adv(V.lv[l].cinit, d); adv(V.lv[l].cm, d);
+    adv(V.lv[l].rs, d); adv(V.lv[l].rzb, d); adv(V.lv[l].rza, d);
+  }
+  adv(V.live[0], d); adv(V.live[1], d);
+  adv(V.m, d); adv(V.init_now, d); adv(V.maxbound, d); adv(V.minabs, d); adv(V.first_sdf, d);
+  adv(V.tk_s, d); adv(V.tk_zb, d); adv(V.tk_za, d); adv(V.tk_src, d); adv(V.tk_slot, d);
+  adv(V.mstore, d);
+  adv(V.zdepth_s, d); adv(V.depth_pre, d); adv(V.nrm_t, d); adv(V.mask_s, d);
+  adv(V.nlist, d); adv(V.n_sdf, d); adv(V.n_g, d);
+  return V;
+}
+
+// Members of a (rebased, register-resident) View selected by a run-time index: written as selects, never as indexing into the
+// local copy (a dynamically indexed member array would force the whole struct into scratch memory)
+template <typename T>
+__device__ __forceinline__ T sel3(int l, T a0, T a1, T a2) { return l == 2 ? a2 : (l == 1 ? a1 : a0); }   // operands by VALUE (a ternary of lvalues selects addresses)
+__device__ __forceinline__ LevelView level_sel(const View& V, int l) {
+  LevelView L;
+#define DISTR_LSEL(f) L.f = sel3(l, V.lv[0].f, V.lv[1].f, V.lv[2].f)
+  DISTR_LSEL(h); DISTR_LSEL(w); DISTR_LSEL(n); DISTR_LSEL(steps); DISTR_LSEL(y0); DISTR_LSEL(full_h); DISTR_LSEL(scale); DISTR_LSEL(off);
+  DISTR_LSEL(valid); DISTR_LSEL(list); DISTR_LSEL(cinit); DISTR_LSEL(cm); DISTR_LSEL(rs); DISTR_LSEL(rzb); DISTR_LSEL(rza);
+#undef DISTR_LSEL
+  return L;
+}
+__device__ __forceinline__ int64_t moff_sel(const View& V, int l) { return sel3<int64_t>(l, V.moff[0], V.moff[1], V.moff[2]); }
+__device__ __forceinline__ int32_t* live_sel(const View& V, int i) { return sel3<int32_t*>(i & 1, V.live[0], V.live[1], V.live[1]); }
+
+// Virtual concatenation of the views' work lists: view b contributes its count c_b rounded up to a multiple of `g` (so that no
+// tile straddles two views); every wavefront computes the prefix sums redundantly (one load + six shuffles; nviews <= 64 = one
+// lane per view). `p0` = the counter of view 0, the counter of view b lies b * stride bytes further. A single view (B = 1)
+// takes none of the shuffles.
+__device__ __forceinline__ int32_t vload(const int32_t* p0, int64_t stride, int B) {   // lane b: count of view b (0 beyond the batch)
+  if (B <= 1) return *p0;
+  const int lane = threadIdx.x & 63;
+  return (lane < B) ? *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p0) + (int64_t)lane * stride) : 0;
+}
+__device__ __forceinline__ int32_t vpad(int32_t c, int g) { return (c + g - 1) & ~(g - 1); }
+__device__ __forceinline__ int32_t vprefix(int32_t c, int B, int g) {                    // inclusive prefix of the padded counts
+  int32_t v = vpad(c, g);
+  if (B <= 1) return v;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(v, o); if (lane >= o) v += t; }
+  return v;
+}
+__device__ __forceinline__ int32_t vtotal(int32_t incl, int B) { return (B <= 1) ? incl : __shfl(incl, 63); }
+// view that holds virtual index `vidx` (< total): its index, the virtual start of its segment and its real count
+__device__ __forceinline__ void vfind(int32_t c, int32_t incl, int B, int g, int64_t vidx, int& b, int64_t& start, int32_t& cnt) {
+  if (B <= 1) { b = 0; start = 0; cnt = c; return; }
+  const int lane = threadIdx.x & 63;
+  const int32_t excl = incl - vpad(c, g);
+  const unsigned long long hit = __ballot(lane < B && vidx >= excl && vidx < incl);
+  b = __builtin_amdgcn_readfirstlane(hit ? (__ffsll((long long)hit) - 1) : 0);
+  start = __shfl(excl, b);
+  cnt = __shfl(c, b);
+}
 
 struct Sample { int32_t src; float zb; float coef; int32_t flags; float sdf; int32_t mblock; int32_t pad0, pad1; };
 
@@ -175,8 +253,17 @@ __device__ __forceinline__ void wave_atomic_max(uint32_t* dst, uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------ k_prep
-__global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const float* __restrict__ latent,
-                                              const float* __restrict__ R, const float* __restrict__ T) {
+struct ViewFlags { uint8_t f[DISTR_MAX_VIEWS]; };   // VF_* of every view of the batch (host knowledge: the no_grad_* options)
+
+// grid (4, nviews): camera constants, latent constants c0 / c4 and counter reset of every view of the batch; view b reads
+// latent + b * lat_stride (lat_stride = 0: one shape code shared by all views), R + 9 b, T + 3 b
+__global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float* __restrict__ latent0, int64_t lat_stride,
+                                              const float* __restrict__ R0, const float* __restrict__ T0, ViewFlags vf) {
+  const int vb = blockIdx.y;
+  Consts* C = view_at(V0, vb).C;
+  const float* latent = latent0 + (int64_t)vb * lat_stride;
+  const float* R = R0 + 9 * vb;
+  const float* T = T0 + 3 * vb;
   const int gid = blockIdx.x * 256 + threadIdx.x;  // 1024 threads
   {
     const int o = gid & 511;
@@ -203,6 +290,7 @@ __global__ void __launch_bounds__(256) k_prep(Consts* C, DecoderDev D, const flo
       for (int i = 0; i < 3; ++i) { c[i] = -(R[0 * 3 + i] * T[0] + R[1 * 3 + i] * T[1] + R[2 * 3 + i] * T[2]); C->c[i] = c[i]; }
       const float cd = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
       C->cdist = cd;
+      C->vflags = vf.f[vb];
       C->f_origin = 0.f;
       C->xchg_err = 0;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
@@ -224,8 +312,9 @@ __global__ void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, D
 // ------------------------------------------------------------------------------------------ ray setup
 // get_intersections_with_unit_spheres (renderer.py:254-273) for one pyramid level; coarse masks are the OR of the
 // 2x2 children (maxpool_valid_mask_with_index / torch_scatter.scatter_max, renderer.py:668-680).
-__global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
-  const LevelView& L = V.lv[lvl];
+__global__ void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
+  const View V = view_at(V0, blockIdx.y);
+  const LevelView L = level_sel(V, lvl);
   Consts* C = V.C;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const CamRegs cam = load_cam(C);
@@ -240,7 +329,7 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
     if (lvl == 0) {
       valid = s.in;
     } else {
-      const LevelView& F = V.lv[lvl - 1];
+      const LevelView F = level_sel(V, lvl - 1);
       const int y = i / L.w, x = i % L.w;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
@@ -259,8 +348,9 @@ __global__ void __launch_bounds__(256) k_setup_level(View V, int lvl) {
 
 // row band: the fill depth of rays that miss the sphere is the maximum over the FULL image's level grid
 // (renderer.py:268-270), not over the band -> one cheap pass over all of the level's pixel centres
-__global__ void __launch_bounds__(256) k_maxinit_full(View V, int lvl) {
-  const LevelView& L = V.lv[lvl];
+__global__ void __launch_bounds__(256) k_maxinit_full(View V0, int lvl) {
+  const View V = view_at(V0, blockIdx.y);
+  const LevelView L = level_sel(V, lvl);
   const int i = blockIdx.x * 256 + threadIdx.x;
   const CamRegs cam = load_cam(V.C);
   uint32_t mx = 0u;
@@ -274,8 +364,9 @@ __global__ void __launch_bounds__(256) k_maxinit_full(View V, int lvl) {
 }
 
 // start depth of a coarse level: unit-sphere entry (coarsest) or the parent's last marched depth (renderer.py:766-769)
-__global__ void __launch_bounds__(256) k_coarse_init(View V, int lvl) {
-  const LevelView& L = V.lv[lvl];
+__global__ void __launch_bounds__(256) k_coarse_init(View V0, int lvl) {
+  const View V = view_at(V0, blockIdx.y);
+  const LevelView L = level_sel(V, lvl);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L.n) return;
   float init;
@@ -288,7 +379,7 @@ __global__ void __launch_bounds__(256) k_coarse_init(View V, int lvl) {
     const bool inside = cam.cdist < V.cfg.radius;
     init = inside ? 0.f : (s.in ? s.init_raw : __uint_as_float(V.C->maxinit_bits[lvl]));
   } else {
-    const LevelView& Pp = V.lv[lvl + 1];
+    const LevelView Pp = level_sel(V, lvl + 1);
     const int par = ((i / L.w) / 2) * Pp.w + ((i % L.w) / 2);
     init = Pp.rza[(size_t)(Pp.steps - 1) * Pp.n + par];
   }
@@ -380,7 +471,8 @@ __device__ __forceinline__ int topk_insert_pre(const View& V, const RayPre& st, 
 }
 
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
-__global__ void __launch_bounds__(256) k_fine_init(View V) {
+__global__ void __launch_bounds__(256) k_fine_init(View V0) {
+  const View V = view_at(V0, blockIdx.y);
   const LevelView& L0 = V.lv[0];
   Consts* C = V.C;
   const int px = blockIdx.x * 256 + threadIdx.x;
@@ -411,7 +503,7 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
     }
     if (V.pyramid) {
       for (int lvl = V.nlev - 1; lvl >= 1; --lvl) {
-        const LevelView& Lc = V.lv[lvl];
+        const LevelView Lc = level_sel(V, lvl);
         const int par = (y >> lvl) * Lc.w + (x >> lvl);
         for (int st = 0; st < Lc.steps; ++st) {
           const size_t o = (size_t)st * Lc.n + par;
@@ -436,19 +528,23 @@ __global__ void __launch_bounds__(256) k_fine_init(View V) {
 // workgroups beyond the device-side count exit immediately, so the host never synchronises inside the loop.
 enum { MODE_EVAL = 0, MODE_COARSE = 1, MODE_FINE = 2 };
 
-// A march step over `count` live rays is split by tile size so that no launch pays a full 64-ray tile latency for a small
-// remainder: rays [0, full) with full = floor(count / 16384) * 16384 (whole rounds of 256 CUs x 64 rays) go to the 64-ray
-// role; the remainder `rem` goes, by size, to
-//     rem <= t16 (4096)          16-ray tiles          (one wave of 107 us tiles; clusters up to 2048 rays)
+// A march step over the live rays (of all views of the batch) is split by tile size so that no launch pays a full 64-ray tile
+// latency for a small remainder. n16 / n64 = the step's live rays in the virtual concatenation of the views, every view's count
+// rounded up to 16 / 64 (vprefix). If n16 <= t16 (4096) the whole step runs on 16-ray tiles (one wave of 107 us tiles; cluster
+// tiles below 2048 rays), granularity g = 16. Otherwise g = 64: rays [0, full), full = floor(n64 / 16384) * 16384 (whole rounds
+// of 256 CUs x 64 rays), go to the 64-ray role and the remainder `rem`, by size, to
+//     rem <= t16 (4096)          16-ray tiles
 //     rem <= t32 (8192)          32-ray tiles          (203 us)
 //     rem <= t32 + t16 (12288)   32-ray tiles for the first t32 rays + 16-ray tiles for the rest (203 + 111 us on the same CUs:
 //                                the work is MFMA-bound, so 48 rays per CU cost 48/64 of a round whether the two tiles share
 //                                the CU or follow each other)
 //     else                       one more round of 64-ray tiles (362 us).
-// Every role of the step evaluates this on the device-side count; the host never needs to know it.
-__device__ __forceinline__ void fine_range(int64_t count, int t16, int t32, int which, int64_t& lo, int64_t& hi) {
-  if (t32 <= 0) { lo = 0; hi = count; return; }                                   // single kernel per step
-  if (t16 == 0x7fffffff) { lo = 0; hi = (which == 16) ? count : 0; return; }      // tests: everything on 16-ray tiles
+// Every role of the step evaluates this on the device-side counts; the host never needs to know them. (Host invariants,
+// distr_create: 16 <= t16 <= t32, t16 + t32 < 16384, both multiples of 64.)
+__device__ __forceinline__ void fine_split(int64_t n16, int64_t n64, int t16, int t32, int which, int64_t& lo, int64_t& hi, int& g) {
+  if (n16 <= t16) { g = 16; lo = 0; hi = (which == 16) ? n16 : 0; return; }
+  g = 64;
+  const int64_t count = n64;
   const int64_t full = (count / 16384) * 16384, rem = count - full;
   // remainder split point: rays [full, cut) on 32-ray tiles, [cut, count) on 16-ray tiles (either part may be empty)
   int64_t cut;
@@ -465,14 +561,14 @@ __device__ __forceinline__ void fine_range(int64_t count, int t16, int t32, int 
 struct MarchArgs {
   View V;
   int32_t lvl, step;
-  int32_t origin_tile;       // the last workgroup evaluates f(origin) instead of a tile
+  int32_t origin_tile;       // the last nviews workgroups evaluate f(origin) of their view instead of a tile
   const float* xyz;          // MODE_EVAL
   float* sdf_out;
   const float* c0c4;         // MODE_EVAL: latent constants
   int64_t n;
   float clamp;
-  // MODE_FINE tile-size split (see fine_range): t16 / t32 = largest remainder handled by 16- / 32-ray tiles; which = tile
-  // size of THIS launch (16, 32, 64). t32 == 0: no split, the 64-ray (or forced) kernel takes everything.
+  // MODE_FINE tile-size split of the recursive marchers (see fine_split): t16 / t32 = largest remainder handled by 16- /
+  // 32-ray tiles; which = tile size of THIS launch (a plain k_march launch; the roles of k_step pass their own)
   int32_t t16, t32, which;
   Xchg xc;                   // 16-ray launches: exchange region of the cluster tiles (buf == null: single-workgroup tiles only)
 };
@@ -486,27 +582,47 @@ template <int MODE, int RB, bool KEEP>
 __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev& D, Smem<RB>& S, int tile, int ntile_grid, int which,
                                            int origin_tile) {
   constexpr int TILE = 32 * RB;
-  const View& V = A.V;
+  const View& V0 = A.V;
   const int tid = threadIdx.x;
+  const int B = (MODE == MODE_EVAL) ? 1 : V0.nviews;
+  const bool split = MODE == MODE_FINE && V0.cfg.marcher != DISTR_MARCH_TRIVIAL;
   bool origin = false;
-  if (MODE != MODE_EVAL && origin_tile && tile == ntile_grid - 1) origin = true;
-
-  int64_t count;
-  const int32_t* list = nullptr;
+  int vb = 0;
+  int64_t base = (int64_t)tile * TILE, count = 0;
   if (MODE == MODE_EVAL) {
     count = A.n;
-  } else if (MODE == MODE_COARSE) {
-    count = V.C->cnt_level[A.lvl];
-    list = V.lv[A.lvl].list;
+    if (base >= count) return false;
+  } else if (origin_tile && tile >= ntile_grid - B) {
+    origin = true;
+    vb = tile - (ntile_grid - B);
   } else {
-    if (V.cfg.marcher == DISTR_MARCH_TRIVIAL) { count = V.C->cnt_level[0]; list = V.lv[0].list; }
-    else { count = V.C->cnt_live[A.step]; list = V.live[A.step & 1]; }
+    // this tile's view and ray range from the device-side counts of all views (virtual concatenation, see vprefix)
+    const int32_t* p0 = (MODE == MODE_COARSE) ? &V0.C->cnt_level[A.lvl] : split ? &V0.C->cnt_live[A.step] : &V0.C->cnt_level[0];
+    const int32_t c = vload(p0, V0.vstride, B);
+    int64_t lo = 0, hi;
+    int g = TILE;
+    int32_t incl;
+    if (split) {
+      const int32_t i16 = vprefix(c, B, 16), i64 = vprefix(c, B, 64);
+      fine_split(vtotal(i16, B), vtotal(i64, B), A.t16, A.t32, which, lo, hi, g);
+      incl = (g == 16) ? i16 : i64;
+    } else {
+      incl = vprefix(c, B, TILE);
+      hi = vtotal(incl, B);
+    }
+    const int64_t vbase = lo + (int64_t)tile * TILE;
+    if (vbase >= hi) return false;
+    int64_t start;
+    int32_t cnt;
+    vfind(c, incl, B, g, vbase, vb, start, cnt);
+    base = vbase - start;
+    count = cnt;
+    if (base >= count) return true;    // padding behind the view's last ray (tiles smaller than the granularity): nothing to do
   }
-  int64_t lo = 0, hi = count;
-  if (MODE == MODE_FINE && V.cfg.marcher != DISTR_MARCH_TRIVIAL) fine_range(count, A.t16, A.t32, which, lo, hi);
-  const int64_t base = lo + (int64_t)tile * TILE;
-  if (!origin && base >= hi) return false;
-  count = hi;
+  const View V = view_at(V0, vb);
+  const int32_t* list = nullptr;
+  if (MODE == MODE_COARSE) list = level_sel(V, A.lvl).list;
+  else if (MODE == MODE_FINE) list = split ? live_sel(V, A.step) : V.lv[0].list;
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
   stage_bias<RB>(D, c0, c4, S);      // first thing: these loads travel under the prologue's dependent state loads
@@ -526,7 +642,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
           p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
         } else {
           id = list[r];
-          const LevelView& L = V.lv[MODE == MODE_COARSE ? A.lvl : 0];
+          const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
           const CamRegs cam = load_cam(V.C);
           float cx, cy;
           level_center(L, id, cx, cy);
@@ -556,14 +672,14 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
       if (MODE == MODE_COARSE) {
         if (valid) {
-          const LevelView& L = V.lv[A.lvl];
+          const LevelView L = level_sel(V, A.lvl);
           const float mn = L.cm[id] + clampf(s, -cd, cd) * ratio;
           L.cm[id] = mn;
           const size_t o = (size_t)A.step * L.n + id;
           L.rs[o] = s;
           L.rzb[o] = zd;
           L.rza[o] = mn + L.cinit[id];
-          mblock = V.mfine + V.moff[A.lvl] + (int64_t)o;
+          mblock = V.mfine + moff_sel(V, A.lvl) + (int64_t)o;
         }
       } else {  // MODE_FINE
         bool stay = false;
@@ -579,7 +695,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
           stay = (za < st.maxbound) && (a >= V.cfg.threshold);
         }
         if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
-          wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
+          wave_append(stay, id, live_sel(V, A.step + 1), &V.C->cnt_live[A.step + 1]);
       }
     }
   }
@@ -611,46 +727,69 @@ template <int MODE, bool KEEP>
 __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, int bidx,
                                              int origin_tile) {
   constexpr int TILE = 16;
-  const View& V = A.V;
+  const View& V0 = A.V;
   const int tid = threadIdx.x;
-  int64_t count;
-  const int32_t* list = nullptr;
+  const int B = (MODE == MODE_EVAL) ? 1 : V0.nviews;
+  // virtual ray range [lo, hi) of this launch's 16-ray tiles over all views (16-ray tiles exist only for the recursive marchers'
+  // steps, the coarse pyramid levels and explicit point lists)
+  int64_t lo = 0, hi;
+  int gran = TILE;
+  int32_t c = 0, incl = 0;
   if (MODE == MODE_EVAL) {
-    count = A.n;
-  } else if (MODE == MODE_COARSE) {
-    count = V.C->cnt_level[A.lvl];
-    list = V.lv[A.lvl].list;
+    hi = A.n;
   } else {
-    count = V.C->cnt_live[A.step];
-    list = V.live[A.step & 1];
+    const int32_t* p0 = (MODE == MODE_COARSE) ? &V0.C->cnt_level[A.lvl] : &V0.C->cnt_live[A.step];
+    c = vload(p0, V0.vstride, B);
+    if (MODE == MODE_FINE) {
+      const int32_t i16 = vprefix(c, B, 16), i64 = vprefix(c, B, 64);
+      fine_split(vtotal(i16, B), vtotal(i64, B), A.t16, A.t32, 16, lo, hi, gran);
+      incl = (gran == 16) ? i16 : i64;
+    } else {
+      incl = vprefix(c, B, TILE);
+      hi = vtotal(incl, B);
+    }
   }
-  int64_t lo = 0, hi = count;
-  if (MODE == MODE_FINE) fine_range(count, A.t16, A.t32, 16, lo, hi);
   const int64_t n = hi - lo;
-  // Cluster size from the (device-side) number of rays of this launch: with at most 32 / 64 / 128 tiles -- counting the extra
-  // tile for f(origin) on the one launch that carries it, so that the grid stays within 256 workgroups -- 8 / 4 / 2 compute units
+  const int64_t ntiles = (n + TILE - 1) / TILE;
+  // the tiles after the last real one evaluate f(0,0,0) of each view (sample point of padded rows) in the launch that carries
+  // `origin_tile`: on a tail step they ride along for free instead of adding tiles to a full round elsewhere
+  const int norigin = (MODE == MODE_FINE && origin_tile) ? B : 0;
+  // Cluster size from the (device-side) number of tiles of this launch: with at most 32 / 64 / 128 tiles -- counting the extra
+  // tiles for f(origin) on the one launch that carries them, so that the grid stays within 256 workgroups -- 8 / 4 / 2 compute units
   // share each tile. Measured step time (C3 tail, profiles/r02_steps_c3.md): 52 us (8), 64 us (4), 94 us (2), 107 us (single
   // workgroup).
   int cl = 1;
   if (MODE != MODE_EVAL && A.xc.buf) {
-    const int64_t need = (n + TILE - 1) / TILE + ((MODE == MODE_FINE && origin_tile) ? 1 : 0);
+    const int64_t need = ntiles + norigin;
     cl = (need <= 32 && A.xc.max_cl >= 8) ? 8 : (need <= 64 && A.xc.max_cl >= 4) ? 4 : (need <= 128 && A.xc.min_cl <= 2) ? 2 : 1;
   }
   int tile = bidx, member = 0;
   if (cl > 1) {   // members of a cluster = workgroups with equal index mod 8 (same XCD: every role of a launch starts at a multiple of 8).
     // (Measured alternative: member m of every cluster on XCD m, so that an XCD streams only its 1/cl slice of the weights from a
     // warm L2 -- the compute phase did not change, it is not bound by weight latency, and the exchange across XCDs cost 1 us more.)
-    const int g = bidx / (8 * cl), r = bidx % (8 * cl);
-    tile = g * 8 + (r & 7);
+    const int gq = bidx / (8 * cl), r = bidx % (8 * cl);
+    tile = gq * 8 + (r & 7);
     member = r >> 3;
   }
-  // the tile after the last real one evaluates f(0,0,0) (sample point of padded rows) in the launch that carries
-  // `origin_tile`: on a tail step it rides along for free instead of adding a 257th tile to a full round elsewhere
-  const int64_t ntiles = (n + TILE - 1) / TILE;
-  const bool origin = (MODE == MODE_FINE) && origin_tile && tile == ntiles;
-  const int64_t base = lo + (int64_t)tile * TILE;
-  if (!origin && base >= hi) return;
-  count = hi;
+  const bool origin = norigin > 0 && tile >= ntiles && tile < ntiles + norigin;
+  int vb = 0;
+  int64_t base = (int64_t)tile * TILE, count = hi;
+  if (origin) {
+    vb = tile - (int)ntiles;
+  } else {
+    const int64_t vbase = lo + (int64_t)tile * TILE;
+    if (vbase >= hi) return;
+    if (MODE != MODE_EVAL) {
+      int64_t start;
+      int32_t cnt;
+      vfind(c, incl, B, gran, vbase, vb, start, cnt);
+      base = vbase - start;
+      count = cnt;
+      if (base >= count) return;       // padding behind the view's last ray (all members of a cluster agree)
+    }
+  }
+  const View V = view_at(V0, vb);
+  const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, A.step) : nullptr;
 
   int32_t id = -1;
   float zd = 0.f;
@@ -666,7 +805,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
         p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
       } else {
         id = list[r];
-        const LevelView& L = V.lv[MODE == MODE_COARSE ? A.lvl : 0];
+        const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
         const CamRegs cam = load_cam(V.C);
         float cx, cy;
         level_center(L, id, cx, cy);
@@ -711,14 +850,14 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
     } else if (MODE == MODE_COARSE) {
       if (valid) {
-        const LevelView& L = V.lv[A.lvl];
+        const LevelView L = level_sel(V, A.lvl);
         const float mn = L.cm[id] + clampf(s, -V.cfg.clamp_dist, V.cfg.clamp_dist) * V.cfg.ratio;
         L.cm[id] = mn;
         const size_t o = (size_t)A.step * L.n + id;
         L.rs[o] = s;
         L.rzb[o] = zd;
         L.rza[o] = mn + L.cinit[id];
-        mblock = V.mfine + V.moff[A.lvl] + (long long)o;
+        mblock = V.mfine + moff_sel(V, A.lvl) + (long long)o;
       }
     } else {
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
@@ -734,7 +873,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
         if (A.step == 0) V.first_sdf[id] = s;
         stay = (za < st.maxbound) && (a >= V.cfg.threshold);
       }
-      wave_append(stay, id, V.live[(A.step + 1) & 1], &V.C->cnt_live[A.step + 1]);
+      wave_append(stay, id, live_sel(V, A.step + 1), &V.C->cnt_live[A.step + 1]);
     }
   }
   if (KEEP && MODE != MODE_EVAL) {
@@ -893,7 +1032,15 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const fl
 
 // ------------------------------------------------------------------------------------------ finalize
 // render_depth's output assembly (renderer.py:859-878) + depth = Zdepth*calib (renderer.py:967-969)
-__global__ void __launch_bounds__(256) k_finalize(View V, float* zdepth, uint8_t* mask, float* min_sdf, float* depth) {
+__global__ void __launch_bounds__(256) k_finalize(View V0, float* zdepth, uint8_t* mask, float* min_sdf, float* depth) {
+  const View V = view_at(V0, blockIdx.y);
+  {
+    const size_t o = (size_t)blockIdx.y * V.P;         // outputs of a batch: [nviews][P]
+    if (zdepth) zdepth += o;
+    if (mask) mask += o;
+    if (min_sdf) min_sdf += o;
+    if (depth) depth += o;
+  }
   const int px = blockIdx.x * 256 + threadIdx.x;
   Consts* C = V.C;
   bool vout = false;
@@ -917,7 +1064,7 @@ __global__ void __launch_bounds__(256) k_finalize(View V, float* zdepth, uint8_t
       const float za0 = V.tk_za[px];
       const float m_row = V.pyramid ? (za0 - init_orig) : za0;
       float z = m_row + (1.0f - ratio) * clampf(s0, -cd, cd);
-      if (V.cfg.grad_depth) {
+      if (C->vflags & VF_GRAD_DEPTH) {
         for (int k = 0; k < V.cfg.buffer_size; ++k) {
           const float sv = (V.tk_src[k * P + px] < 0) ? C->f_origin : V.tk_s[k * P + px];
           const float sc = clampf(sv, -cd, cd);
@@ -960,7 +1107,10 @@ __device__ __forceinline__ bool d2n_row_inner(const View& V, int y) {
 }
 
 // depth2normal (core/utils/render_utils.py:9-43) incl. its in-place zeroing of the background depth
-__global__ void __launch_bounds__(256) k_depth2normal(View V, float* depth, float* normal) {
+__global__ void __launch_bounds__(256) k_depth2normal(View V0, float* depth, float* normal) {
+  const View V = view_at(V0, blockIdx.y);
+  if (depth) depth += (size_t)blockIdx.y * V.P;
+  if (normal) normal += (size_t)blockIdx.y * V.P * 3;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= V.P) return;
   const int Ww = V.cfg.W;
@@ -988,21 +1138,23 @@ __global__ void __launch_bounds__(256) k_depth2normal(View V, float* depth, floa
 enum { BWD_FULL = 0, BWD_POINTGRAD = 1, BWD_SAVED = 2 };   // SAVED: masks come from View::mstore, no forward recompute
 
 struct BwdArgs {
-  View V;
-  const Sample* samples;     // FULL
-  const int32_t* count_ptr;  // device-side count (FULL / normal pass); null -> n
-  int64_t n;
-  const float* xyz;          // POINTGRAD from explicit points (distr_mlp_grad); else from V.nlist + zdepth
-  const float* zdepth;       // POINTGRAD from pixel list: depth along the level-0 ray
-  const int32_t* pix_list;
+  View V;                    // SAVED / FULL and POINTGRAD over the views' valid-pixel lists (V.nlist, counts V.C->cnt_normal)
+  const Sample* samples;     // SAVED / FULL: view 0's sample list; view b's lies b * bstride bytes further (count: V.C->cnt_samples)
+  float* partial;            // SAVED / FULL: view 0's [tiles][PSTRIDE] (same stride); POINTGRAD explicit with coef: [tiles][PSTRIDE]
+  int64_t bstride;           // bytes between the backward workspaces of consecutive views
+  int64_t n;                 // POINTGRAD explicit: number of points
+  const float* xyz;          // POINTGRAD from explicit points (distr_mlp_grad); null: from the views' pixel lists + zdepth
+  const float* zdepth;       // POINTGRAD from pixel lists: depth along the level-0 ray, view b at zdepth + b * zstride bytes
+  int64_t zstride;
   const float* c0c4;         // POINTGRAD explicit: latent constants; null -> V.C
   const float* coef;         // POINTGRAD explicit: upstream gradient per point (decode_sdf backward); null -> 1
   float clamp;               // POINTGRAD explicit with coef: >= 0 -> zero the gradient where |f| > clamp (decode_sdf's clamp)
   int32_t split;             // SAVED / FULL: 1 = the sample list is split by tile size like a march step (bwd_range)
-  float* partial;            // FULL: [tiles][PSTRIDE]; POINTGRAD with coef: same (delta sums for the latent gradient)
-  float* out_sdf;            // POINTGRAD: [n]
-  float* out_g;              // POINTGRAD: [n][3]
+  float* out_sdf;            // POINTGRAD explicit: [n]   (pixel lists: V.n_sdf)
+  float* out_g;              // POINTGRAD explicit: [n][3] (pixel lists: V.n_g)
 };
+
+__device__ __forceinline__ int32_t vget(int32_t x, int b, int B) { return (B <= 1) ? x : __shfl(x, b); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -1031,19 +1183,54 @@ template <int MODE, int RB>
 __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, DecoderDev D) {
   constexpr int TILE = 32 * RB;
   __shared__ Smem<RB> S;
-  const View& V = A.V;
+  const View& V0 = A.V;
   const int tid = threadIdx.x;
-  int tile = blockIdx.x;
-  int64_t count = A.count_ptr ? (int64_t)(*A.count_ptr) : A.n;
-  int64_t base = (int64_t)tile * TILE;
-  if (MODE != BWD_POINTGRAD && A.split) {
-    int64_t lo, hi; int first, nt;
-    bwd_range(count, 1, TILE, lo, hi, first, nt);
-    base = lo + (int64_t)tile * TILE;
-    count = hi;
-    tile += first;
+  const bool explicit_points = MODE == BWD_POINTGRAD && A.xyz;
+  const int B = explicit_points ? 1 : V0.nviews;
+  int tile = blockIdx.x, vb = 0;
+  int64_t count, base;
+  if (explicit_points) {
+    count = A.n;
+    base = (int64_t)tile * TILE;
+    if (base >= count) return;
+  } else if (MODE == BWD_POINTGRAD) {
+    // valid-pixel lists of all views, each padded to whole tiles
+    const int32_t c = vload(&V0.C->cnt_normal, V0.vstride, B);
+    const int32_t incl = vprefix(c, B, TILE);
+    const int64_t vbase = (int64_t)tile * TILE;
+    if (vbase >= vtotal(incl, B)) return;
+    int64_t start;
+    int32_t cnt;
+    vfind(c, incl, B, TILE, vbase, vb, start, cnt);
+    base = vbase - start;
+    count = cnt;
+    if (base >= count) return;
+  } else {
+    // gradient samples: every view keeps its OWN tile decomposition (bwd_range of its own count: same tiles, same tile sizes,
+    // same partial rows as a stand-alone backward of that view -> bit-identical gradients); this launch walks the
+    // concatenation of the views' TILE-sized tiles
+    const int32_t c = vload(&V0.C->cnt_samples, V0.vstride, B);
+    int64_t lo, hi;
+    int first, nt;
+    bwd_range(c, A.split, TILE, lo, hi, first, nt);
+    const int32_t mine = (int32_t)((hi - lo + TILE - 1) / TILE);      // tiles of this size in this lane's view
+    const int32_t incl = vprefix(mine, B, 1);
+    if (tile >= vtotal(incl, B)) return;
+    int64_t start;
+    int32_t cnt;
+    vfind(mine, incl, B, 1, tile, vb, start, cnt);
+    const int local = tile - (int)start;
+    base = (int64_t)vget((int32_t)lo, vb, B) + (int64_t)local * TILE;
+    count = vget((int32_t)hi, vb, B);
+    tile = vget(first, vb, B) + local;                                 // partial row inside the view's own array
   }
-  if (base >= count) return;
+  const View V = view_at(V0, vb);
+  const Sample* samples = reinterpret_cast<const Sample*>(reinterpret_cast<const char*>(A.samples) + (int64_t)vb * A.bstride);
+  float* partial = A.partial ? reinterpret_cast<float*>(reinterpret_cast<char*>(A.partial) + (int64_t)vb * A.bstride) : nullptr;
+  const float* zdepth = A.zdepth ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(A.zdepth) + (int64_t)vb * A.zstride) : nullptr;
+  const int32_t* pix_list = V.nlist;
+  float* out_sdf = explicit_points ? A.out_sdf : V.n_sdf;
+  float* out_g = explicit_points ? A.out_g : V.n_g;
 
   Sample sm; sm.src = -1; sm.zb = 0.f; sm.coef = 0.f; sm.flags = 0; sm.sdf = 0.f; sm.mblock = -1;
   bool valid = false;
@@ -1056,7 +1243,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     if (tid < TILE) {
       r = base + tid;
       valid = r < count;
-      if (valid) sm = A.samples[r];
+      if (valid) sm = samples[r];
       y = sm.sdf;
       S.aux[tid] = valid ? sm.coef * __builtin_fmaf(-y, y, 1.0f) : 0.f;
       mb[tid] = valid ? (long long)sm.mblock : -1ll;
@@ -1084,13 +1271,13 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
           p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
           sm.coef = A.coef ? A.coef[r] : 1.0f;
         } else {
-          if (MODE == BWD_POINTGRAD) { sm.src = A.pix_list[r]; sm.zb = A.zdepth[sm.src]; sm.coef = 1.0f; }
-          else sm = A.samples[r];
+          if (MODE == BWD_POINTGRAD) { sm.src = pix_list[r]; sm.zb = zdepth[sm.src]; sm.coef = 1.0f; }
+          else sm = samples[r];
           if (sm.src >= 0) {
             const int lvl = src_level(sm.src), ray = src_ray(sm.src);
             const CamRegs cam = load_cam(V.C);
             float cx, cy;
-            level_center(V.lv[lvl], ray, cx, cy);
+            level_center(level_sel(V, lvl), ray, cx, cy);
             const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
             make_point(V.cfg.M, cam.c, g.d, sm.zb, p);
           }
@@ -1109,7 +1296,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     }
     __syncthreads();
   }
-  float* part = (MODE != BWD_POINTGRAD || A.partial) ? A.partial + (size_t)tile * PSTRIDE : nullptr;
+  float* part = (MODE != BWD_POINTGRAD || partial) ? partial + (size_t)tile * PSTRIDE : nullptr;
   mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
 
   if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
@@ -1117,8 +1304,8 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
   const float gp0 = S.aux[TILE + rl], gp1 = S.aux[2 * TILE + rl], gp2 = S.aux[3 * TILE + rl];
   if (MODE == BWD_POINTGRAD) {
     if (valid) {
-      if (A.out_sdf) A.out_sdf[r] = y;
-      if (A.out_g) { A.out_g[r * 3] = gp0; A.out_g[r * 3 + 1] = gp1; A.out_g[r * 3 + 2] = gp2; }
+      if (out_sdf) out_sdf[r] = y;
+      if (out_g) { out_g[r * 3] = gp0; out_g[r * 3 + 1] = gp1; out_g[r * 3 + 2] = gp2; }
     }
     return;
   }
@@ -1130,7 +1317,7 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     const int lvl = src_level(sm.src), ray = src_ray(sm.src);
     const CamRegs cam = load_cam(V.C);
     float cx, cy;
-    level_center(V.lv[lvl], ray, cx, cy);
+    level_center(level_sel(V, lvl), ray, cx, cy);
     const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
     const float* M = V.cfg.M;
     float gq[3], gd[3];
@@ -1159,11 +1346,17 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
 // ------------------------------------------------------------------------------------------ normals (autograd path)
 // render_normal (renderer.py:880-910) epilogue: n = normalize(3 * grad f) (torch-1.1 grad_outputs quirk,
 // decoder_utils.py:84), t = M n; render(): out = flipx(R t) (renderer.py:977-980)
-__global__ void __launch_bounds__(256) k_normal_finish(View V, const int32_t* count_ptr, const int32_t* pix_list,
-                                                       const float* n_sdf, const float* n_g, float* normal_hw3,
-                                                       float* normal_3xP, float* nrm_t) {
+__global__ void __launch_bounds__(256) k_normal_finish(View V0, float* normal_hw3, float* normal_3xP, int write_nrm_t) {
+  const View V = view_at(V0, blockIdx.y);
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= *count_ptr) return;
+  if (r >= V.C->cnt_normal) return;
+  const size_t P = (size_t)V.P;
+  if (normal_hw3) normal_hw3 += (size_t)blockIdx.y * P * 3;      // outputs of a batch: [nviews][...]
+  if (normal_3xP) normal_3xP += (size_t)blockIdx.y * P * 3;
+  const int32_t* pix_list = V.nlist;
+  const float* n_sdf = V.n_sdf;
+  const float* n_g = V.n_g;
+  float* nrm_t = write_nrm_t ? V.nrm_t : nullptr;
   const int px = pix_list[r];
   const bool inclamp = fabsf(n_sdf[r]) <= V.cfg.clamp_dist;
   float g[3];
@@ -1179,10 +1372,7 @@ __global__ void __launch_bounds__(256) k_normal_finish(View V, const int32_t* co
 #pragma unroll
   for (int i = 0; i < 3; ++i) t[i] = M[i * 3] * g[0] + M[i * 3 + 1] * g[1] + M[i * 3 + 2] * g[2];
   if (nrm_t) { nrm_t[px * 3] = t[0]; nrm_t[px * 3 + 1] = t[1]; nrm_t[px * 3 + 2] = t[2]; }
-  if (normal_3xP) {
-    const size_t P = (size_t)V.P;
-    normal_3xP[px] = t[0]; normal_3xP[P + px] = t[1]; normal_3xP[2 * P + px] = t[2];
-  }
+  if (normal_3xP) { normal_3xP[px] = t[0]; normal_3xP[P + px] = t[1]; normal_3xP[2 * P + px] = t[2]; }
   if (normal_hw3) {
     const float* R = V.C->R;
     float o[3];
@@ -1192,9 +1382,11 @@ __global__ void __launch_bounds__(256) k_normal_finish(View V, const int32_t* co
   }
 }
 
-__global__ void __launch_bounds__(256) k_mask_list(int P, const uint8_t* mask, int32_t* list, int32_t* counter) {
+// valid-pixel list of every view from a caller-provided mask [nviews][P] (render_normal)
+__global__ void __launch_bounds__(256) k_mask_list(View V0, const uint8_t* mask) {
+  const View V = view_at(V0, blockIdx.y);
   const int px = blockIdx.x * 256 + threadIdx.x;
-  wave_append(px < P && mask[px] != 0, px, list, counter);
+  wave_append(px < V.P && mask[(size_t)blockIdx.y * V.P + px] != 0, px, V.nlist, &V.C->cnt_normal);
 }
 
 // ------------------------------------------------------------------------------------------ backward: image side
@@ -1235,13 +1427,36 @@ __device__ __forceinline__ void ray_backward_acc(const RayGeo& g, const float* g
 // and every reduction order are reproducible, so gradients are bit-reproducible run to run.
 struct BwdBlocks { int32_t* cnt; int32_t* off; float* acc; };   // [nblk], [nblk], [nblk][16]
 
+// Backward workspace of view 0 of a batch; view b's arrays lie b * bstride bytes further (bws_at).
+struct BwdWs { Sample* samples; float* partial; float* chunk_part; BwdBlocks BB; int64_t bstride; };
+__device__ __forceinline__ BwdWs bws_at(const BwdWs& W0, int b) {
+  BwdWs W = W0;
+  const int64_t d = (int64_t)b * W0.bstride;
+  adv(W.samples, d); adv(W.partial, d); adv(W.chunk_part, d); adv(W.BB.cnt, d); adv(W.BB.off, d); adv(W.BB.acc, d);
+  return W;
+}
+
+// grid (blocks of 256 pixels, nviews); upstream gradient images of a batch are [nviews][P] ([nviews][P][3] for normals)
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth, const float* g_min_sdf,
-                                                  const float* g_depth, const float* g_normal, Sample* samples, BwdBlocks B) {
+__global__ void __launch_bounds__(256) k_bwd_prep(View V0, const float* g_zdepth, const float* g_min_sdf,
+                                                  const float* g_depth, const float* g_normal, BwdWs W0) {
   __shared__ int32_t s_cnt[MAX_BS][4];
   __shared__ float s_acc[4][16];
+  const View V = view_at(V0, blockIdx.y);
+  const BwdWs Wv = bws_at(W0, blockIdx.y);
+  Sample* samples = Wv.samples;
+  const BwdBlocks B = Wv.BB;
+  {
+    const size_t o = (size_t)blockIdx.y * V.P;
+    if (g_zdepth) g_zdepth += o;
+    if (g_min_sdf) g_min_sdf += o;
+    if (g_depth) g_depth += o;
+    if (g_normal) g_normal += 3 * o;
+  }
   const int px = blockIdx.x * 256 + threadIdx.x;
   Consts* C = V.C;
+  const int vflags = C->vflags;
+  const bool grad_depth = (vflags & VF_GRAD_DEPTH) != 0, grad_mask = (vflags & VF_GRAD_MASK) != 0, grad_camera = (vflags & VF_GRAD_CAMERA) != 0;
   const LevelView& L0 = V.lv[0];
   float acc[12];
 #pragma unroll
@@ -1272,7 +1487,7 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
       }
     } else {
       const bool m = V.mask_s[px] != 0;
-      if (V.cfg.grad_depth) {
+      if (grad_depth) {
         if (g_zdepth) gz += g_zdepth[px];
         if (m) {
           float gd_eff = g_depth ? g_depth[px] : 0.f;
@@ -1311,8 +1526,8 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
     src = V.tk_src[k * P + px];
     sv = src < 0 ? C->f_origin : V.tk_s[k * P + px];
     float c = 0.f;
-    if (V.cfg.grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
-    if (k == 0 && V.cfg.grad_mask) c += gq;
+    if (grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
+    if (k == 0 && grad_mask) c += gq;
     return c;
   };
   for (int k = 0; k < bs; ++k) {
@@ -1350,10 +1565,10 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
       if (V.save_masks) {
         const int lv = src_level(src);
         sm.mblock = (lv == 0) ? (int32_t)((int64_t)px * (bs + 1) + V.tk_slot[k * P + px])
-                              : (int32_t)(V.mfine + V.moff[lv] + (int64_t)src_step(src) * V.lv[lv].n + src_ray(src));
+                              : (int32_t)(V.mfine + moff_sel(V, lv) + (int64_t)src_step(src) * level_sel(V, lv).n + src_ray(src));
       }
       const bool fine_row = src_level(src) == 0;
-      sm.flags = (fine_row && !V.cfg.grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
+      sm.flags = (fine_row && !grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
       samples[wbase + __popcll(ball & ((1ull << lane) - 1ull))] = sm;
     }
     base += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
@@ -1361,7 +1576,11 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V, const float* g_zdepth,
 }
 
 // exclusive scan of the per-block sample counts, ordered sum of the per-block partials, pad sample (one block)
-__global__ void __launch_bounds__(256) k_bwd_scan(View V, BwdBlocks B, int nblk, Sample* samples) {
+__global__ void __launch_bounds__(256) k_bwd_scan(View V0, BwdWs W0, int nblk) {   // one block per view
+  const View V = view_at(V0, blockIdx.x);
+  const BwdWs Wv = bws_at(W0, blockIdx.x);
+  const BwdBlocks B = Wv.BB;
+  Sample* samples = Wv.samples;
   __shared__ int32_t s_part[256];
   __shared__ float s_accp[256][13];
   const int t = threadIdx.x;
@@ -1404,7 +1623,11 @@ __global__ void __launch_bounds__(256) k_bwd_scan(View V, BwdBlocks B, int nblk,
 }
 
 // column sums of the tile partials over one chunk of tiles -> chunk_part[chunk][col] (fixed order, no atomics)
-__global__ void __launch_bounds__(256) k_bwd_reduce(View V, const float* partial, float* chunk_part, int chunk, int tile) {
+__global__ void __launch_bounds__(256) k_bwd_reduce(View V0, BwdWs W0, int chunk, int tile) {   // grid (columns, chunks, nviews)
+  const View V = view_at(V0, blockIdx.z);
+  const BwdWs Wv = bws_at(W0, blockIdx.z);
+  const float* partial = Wv.partial;
+  float* chunk_part = Wv.chunk_part;
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= 2 * HID + 12) return;
   int ntiles = (V.C->cnt_samples + tile - 1) / tile;
@@ -1434,8 +1657,13 @@ __global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial
 }
 
 // g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)
-__global__ void __launch_bounds__(256) k_bwd_final(View V, DecoderDev D, const float* chunk_part, int nchunks_max, int chunk, int tile,
-                                                   float* g_latent, float* g_R, float* g_T) {
+__global__ void __launch_bounds__(256) k_bwd_final(View V0, DecoderDev D, BwdWs W0, int nchunks_max, int chunk, int tile,
+                                                   float* g_latent, float* g_R, float* g_T) {   // one block per view; outputs [nviews][256 | 9 | 3]
+  const View V = view_at(V0, blockIdx.x);
+  const float* chunk_part = bws_at(W0, blockIdx.x).chunk_part;
+  if (g_latent) g_latent += (size_t)blockIdx.x * LAT;
+  if (g_R) g_R += (size_t)blockIdx.x * 9;
+  if (g_T) g_T += (size_t)blockIdx.x * 3;
   const int k = threadIdx.x;
   Consts* C = V.C;
   {

@@ -22,7 +22,11 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
            'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward',
-           'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward']
+           'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
+           'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch']
+
+MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
+VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
 
 
 class DistrError(RuntimeError):
@@ -119,6 +123,12 @@ def lib():
             L.distr_render_forward.argtypes = [vp, C.POINTER(RenderCfg), fp, fp, fp, fp, u8p, fp, fp, fp, vp, C.c_size_t, vp]
             L.distr_render_backward.argtypes = [vp, C.POINTER(RenderCfg), vp, C.c_size_t, fp, fp, fp, fp, fp, fp, fp, vp, C.c_size_t, vp]
             L.distr_render_normal.argtypes = [vp, C.POINTER(RenderCfg), fp, fp, fp, fp, u8p, fp, vp, C.c_size_t, vp]
+            L.distr_render_forward_batch.argtypes = [vp, C.POINTER(RenderCfg), C.c_int32, C.POINTER(C.c_int32), fp, C.c_int64, fp, fp,
+                                                     fp, u8p, fp, fp, fp, vp, C.c_size_t, vp]
+            L.distr_render_backward_batch.argtypes = [vp, C.POINTER(RenderCfg), C.c_int32, vp, C.c_size_t, fp, fp, fp, fp, fp, fp, fp,
+                                                      vp, C.c_size_t, vp]
+            L.distr_render_normal_batch.argtypes = [vp, C.POINTER(RenderCfg), C.c_int32, fp, C.c_int64, fp, fp, fp, u8p, fp, vp,
+                                                    C.c_size_t, vp]
             L.distr_mlp_workspace_bytes.argtypes = [C.c_int64]
             L.distr_mlp_workspace_bytes.restype = C.c_size_t
             L.distr_mlp_eval.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]

@@ -228,6 +228,100 @@ def render_call(engine, cfg, latent, R, T):
     return RenderFunction.apply(latent, R, T, engine, cfg)
 
 
+class RenderBatchFunction(torch.autograd.Function):
+    """Several views in one launch sequence (distr_render_forward_batch): (latent (1,256) shared by all views or (B,256), R (B,3,3),
+    T (B,3)) -> (zdepth (B,P), mask (B,P) uint8, min_sdf (B,P), depth (B,H,W), normal (B,H,W,3)). Every view's values and
+    gradients are bit-identical to its own RenderFunction call; what changes is the schedule (one march launch per step for all
+    views: the views' latency-bound tails overlap). `view_flags`: per-view DISTR_VIEW_GRAD_* (the no_grad_* options of each view)."""
+
+    @staticmethod
+    def forward(ctx, latent, R, T, engine, cfg, view_flags):
+        dev = engine.device
+        H, W = cfg.band_rows, cfg.W
+        P = H * W
+        Rc, Tc = _f32c(R, dev).reshape(-1, 9), _f32c(T, dev).reshape(-1, 3)
+        B = Rc.shape[0]
+        lat = _f32c(latent, dev).reshape(-1, 256)
+        if Tc.shape[0] != B or lat.shape[0] not in (1, B) or not (1 <= B <= binding.MAX_VIEWS):
+            raise ValueError('expected latent (1,256) or (B,256), R (B,3,3), T (B,3) with 1 <= B <= %d' % binding.MAX_VIEWS)
+        shared = lat.shape[0] == 1
+        fwd_bytes, bwd_bytes = engine.ctx.workspace_bytes(cfg)
+        ws = torch.empty(B * fwd_bytes, dtype=torch.uint8, device=dev)
+        zdepth = torch.empty(B, P, dtype=torch.float32, device=dev)
+        mask = torch.empty(B, P, dtype=torch.uint8, device=dev)
+        min_sdf = torch.empty(B, P, dtype=torch.float32, device=dev)
+        if cfg.want_normal:
+            depth = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+            normal = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
+        else:
+            depth = torch.empty(0, dtype=torch.float32, device=dev)
+            normal = torch.empty(0, dtype=torch.float32, device=dev)
+        flags = None if view_flags is None else (C.c_int32 * B)(*[int(f) for f in view_flags])
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_render_forward_batch(
+            engine.ctx.h, C.byref(cfg), B, flags, p(lat), 0 if shared else 256, p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
+            p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None, p(ws), ws.numel(), engine.ctx.stream()))
+        ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes, ctx.B, ctx.shared = engine, cfg, ws, bwd_bytes, B, shared
+        ctx.shapes = (latent.shape, R.shape, T.shape)
+        ctx.in_meta = tuple((t.device, t.dtype) for t in (latent, R, T))
+        ctx.view_bytes = fwd_bytes
+        ctx.mark_non_differentiable(mask)
+        return zdepth, mask, min_sdf, depth, normal
+
+    @staticmethod
+    def backward(ctx, g_zdepth, g_mask, g_min_sdf, g_depth, g_normal):
+        engine, cfg, ws, B = ctx.engine, ctx.cfg, ctx.ws, ctx.B
+        dev = engine.device
+
+        def prep(g, n):
+            if g is None or g.numel() != n:
+                return None
+            return g.to(dtype=torch.float32).contiguous()
+        P = cfg.band_rows * cfg.W
+        gz, gq = prep(g_zdepth, B * P), prep(g_min_sdf, B * P)
+        gd, gn = (prep(g_depth, B * P), prep(g_normal, 3 * B * P)) if cfg.want_normal else (None, None)
+        g_lat = torch.empty(B, 256, dtype=torch.float32, device=dev)
+        g_R = torch.empty(B, 9, dtype=torch.float32, device=dev)
+        g_T = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        ws_b = torch.empty(B * ctx.bwd_bytes, dtype=torch.uint8, device=dev)
+        p = binding.ptr
+        engine.ctx.check(engine.ctx.L.distr_render_backward_batch(
+            engine.ctx.h, C.byref(cfg), B, p(ws), ws.numel(), p(gz), p(gq), p(gd), p(gn), p(g_lat), p(g_R), p(g_T),
+            p(ws_b), ws_b.numel(), engine.ctx.stream()))
+        ls, rs, ts = ctx.shapes
+        if ctx.shared:
+            g_lat = g_lat.sum(0)                   # one shape code rendered from B cameras: the views' gradients add up (fixed order)
+        return tuple(g.reshape(sh).to(device=d, dtype=dt) for g, sh, (d, dt) in zip((g_lat, g_R, g_T), (ls, rs, ts), ctx.in_meta)) + (None, None, None)
+
+
+def render_batch_call(engine, cfg, latent, R, T, view_flags=None):
+    """Batched render_call: R (B,3,3), T (B,3), latent (1,256) (shared) or (B,256)."""
+    need_bwd = torch.is_grad_enabled() and any(getattr(t, 'requires_grad', False) for t in (latent, R, T))
+    cfg = cfg.clone()
+    cfg.save_for_backward = 1 if need_bwd else 0
+    return RenderBatchFunction.apply(latent, R, T, engine, cfg, view_flags)
+
+
+def render_normal_batch_call(engine, cfg, latent, R, T, zdepth, mask):
+    """Batched render_normal_call: R (B,3,3), T (B,3), zdepth / mask (B,P) -> (B,3,P)."""
+    dev = engine.device
+    P = cfg.band_rows * cfg.W
+    Rc, Tc = _f32c(R, dev).reshape(-1, 9), _f32c(T, dev).reshape(-1, 3)
+    B = Rc.shape[0]
+    lat = _f32c(latent, dev).reshape(-1, 256)
+    if lat.shape[0] not in (1, B) or not (1 <= B <= binding.MAX_VIEWS):
+        raise ValueError('expected latent (1,256) or (B,256), R (B,3,3), T (B,3) with 1 <= B <= %d' % binding.MAX_VIEWS)
+    z = _f32c(zdepth, dev).reshape(B, P)
+    m = mask.detach().to(device=dev).reshape(B, P).to(torch.uint8).contiguous()
+    fwd_bytes, _ = engine.ctx.workspace_bytes(cfg)
+    ws = torch.empty(B * fwd_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, 3, P, dtype=torch.float32, device=dev)
+    p = binding.ptr
+    engine.ctx.check(engine.ctx.L.distr_render_normal_batch(engine.ctx.h, C.byref(cfg), B, p(lat), 0 if lat.shape[0] == 1 else 256, p(Rc), p(Tc),
+                                                            p(z), p(m), p(out), p(ws), ws.numel(), engine.ctx.stream()))
+    return out
+
+
 HALO = 4   # rows; depth2normal needs 1, the 4x4 pyramid parents need the band aligned to 4
 
 

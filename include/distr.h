@@ -37,6 +37,14 @@ extern "C" {
 #define DISTR_MARCH_PYRAMID_RECURSIVE 2 /* SDFRenderer.ray_marching_pyramid_recursive  renderer.py:713 */
 
 #define DISTR_MAX_BUFFER_SIZE 8
+#define DISTR_MAX_VIEWS 64 /* views per batched render (distr_render_forward_batch) */
+
+/* per-view gradient switches of a batched render (view_flags[]): the no_grad_* keyword arguments of render_depth / render
+ * (renderer.py:836, 943) may differ between the views of one batch (render_warp renders view 2 with no_grad_depth,
+ * renderer_warp.py:108-109) */
+#define DISTR_VIEW_GRAD_DEPTH 1
+#define DISTR_VIEW_GRAD_MASK 2
+#define DISTR_VIEW_GRAD_CAMERA 4
 
 typedef struct distr_ctx distr_ctx;
 
@@ -131,11 +139,40 @@ int distr_render_backward(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
                           const float* g_normal_dev, float* g_latent_dev, float* g_R_dev, float* g_T_dev,
                           void* ws_bwd_dev, size_t ws_bwd_bytes, void* stream);
 
+/* Several views in ONE launch sequence: what the reference does view by view in the multi-view round (16 render_depth calls with the
+ * same shape code before a single backward(), core/inv_optimizer/optimize_multi.py:62-81, renderer_warp.py:108-109) and shape by
+ * shape for a batch of shapes. All `nviews` views share cfg (image size, intrinsics, marcher, steps); each has its own camera
+ * R_dev[v][9], T_dev[v][3] and shape code latent_dev + v * latent_stride (floats; 0 = one code shared by all views). Every march
+ * step is one launch over the live rays of all views (no tile mixes two views, so every ray's arithmetic -- and every output
+ * byte -- is exactly that of a stand-alone distr_render_forward of its view); the latency-bound tail steps of the views overlap
+ * instead of queueing behind each other.
+ *   outputs     [nviews][H*W] (normal: [nviews][H*W][3]), same meaning as distr_render_forward
+ *   view_flags  HOST array [nviews] of DISTR_VIEW_GRAD_* (may only clear bits that cfg's grad_* fields have set), or NULL = cfg's
+ *   ws_dev      nviews x forward_bytes of distr_workspace_bytes(cfg); view v's workspace (distr_get_render_stats,
+ *               distr_get_live_counts) starts at ws_dev + v * forward_bytes
+ * distr_render_backward_batch: upstream gradients [nviews][H*W] (g_normal [nviews][H*W][3], any may be NULL) -> g_latent
+ * [nviews][256], g_R [nviews][9], g_T [nviews][3] (per view: a shared shape code's gradient is the sum over v, left to the caller
+ * like the reference leaves it to autograd); ws_bwd_dev = nviews x backward_bytes. Every view's gradients are bit-identical to a
+ * stand-alone distr_render_backward of that view (each view keeps its own tile decomposition and reduction order). */
+int distr_render_forward_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const int32_t* view_flags,
+                               const float* latent_dev, int64_t latent_stride, const float* R_dev, const float* T_dev,
+                               float* zdepth_dev, uint8_t* mask_dev, float* min_sdf_dev, float* depth_dev, float* normal_dev,
+                               void* ws_dev, size_t ws_bytes, void* stream);
+int distr_render_backward_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const void* ws_dev, size_t ws_bytes,
+                                const float* g_zdepth_dev, const float* g_min_sdf_dev, const float* g_depth_dev,
+                                const float* g_normal_dev, float* g_latent_dev, float* g_R_dev, float* g_T_dev,
+                                void* ws_bwd_dev, size_t ws_bwd_bytes, void* stream);
+
 /* SDFRenderer.render_normal (renderer.py:880-910) for caller-provided Zdepth/mask: writes (3, H*W) like the
  * reference (untransformed by R; render() applies R and the x-flip itself). */
 int distr_render_normal(distr_ctx* ctx, const distr_render_cfg* cfg, const float* latent_dev, const float* R_dev,
                         const float* T_dev, const float* zdepth_dev, const uint8_t* mask_dev, float* normal3xP_dev,
                         void* ws_dev, size_t ws_bytes, void* stream);
+/* The same for nviews views in one launch sequence (zdepth / mask [nviews][H*W] -> normal [nviews][3][H*W]; cameras, shape codes
+ * and workspace as in distr_render_forward_batch). */
+int distr_render_normal_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32_t nviews, const float* latent_dev,
+                              int64_t latent_stride, const float* R_dev, const float* T_dev, const float* zdepth_dev,
+                              const uint8_t* mask_dev, float* normal3xP_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* decode_sdf (core/utils/decoder_utils.py:53-74): n points xyz_dev[n][3] -> sdf_dev[n]; clamp_dist < 0 = no clamp.
  * decode_sdf_gradient (decoder_utils.py:76-92) without the 3x of the torch-1.1 grad_outputs quirk:

@@ -3,6 +3,7 @@
  * GPU are exercised (distr_version, workspace-size helpers, distr_create on a machine without a device -> error string).
  * Build + run: see tests/test_host_logic.py::test_c_abi_from_plain_c. */
 #include <dlfcn.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include "distr.h"
@@ -21,6 +22,7 @@ int main(int argc, char** argv) {
   RESOLVE(distr_loss_workspace_bytes); RESOLVE(distr_single_loss_forward); RESOLVE(distr_single_loss_backward);
   RESOLVE(distr_warp_loss_forward); RESOLVE(distr_warp_loss_backward); RESOLVE(distr_set_color_decoder); RESOLVE(distr_color_eval); RESOLVE(distr_color_backward);
   RESOLVE(distr_debug_mlp_layer); RESOLVE(distr_debug_tile_timing); RESOLVE(distr_debug_xchg_ts);
+  RESOLVE(distr_render_forward_batch); RESOLVE(distr_render_backward_batch); RESOLVE(distr_render_normal_batch);
   const char* (*version)(void);
   size_t (*mlp_ws)(int64_t);
   size_t (*loss_ws)(int32_t, int32_t);
@@ -39,6 +41,20 @@ int main(int argc, char** argv) {
   const int rc = create(&ctx, 0);
   printf("symbols=%d version=\"%s\" sizeof(cfg)=%zu mlp_ws=%zu loss_ws=%zu create_rc=%d err=\"%s\"\n", n, version(), sizeof(cfg),
          mlp_ws(1000), loss_ws(64, 64), rc, rc ? last_error(ctx) : "");
+  /* struct layouts, field by field, for the ctypes mirror to be compared with (tests/test_host_logic.py) */
+#define OFF(T, f) printf("offset %s.%s %zu %zu\n", #T, #f, offsetof(T, f), sizeof(((T*)0)->f))
+  OFF(distr_render_cfg, H); OFF(distr_render_cfg, W); OFF(distr_render_cfg, K_inv); OFF(distr_render_cfg, fx); OFF(distr_render_cfg, fy);
+  OFF(distr_render_cfg, M); OFF(distr_render_cfg, march_step); OFF(distr_render_cfg, buffer_size); OFF(distr_render_cfg, ratio);
+  OFF(distr_render_cfg, threshold); OFF(distr_render_cfg, radius); OFF(distr_render_cfg, clamp_dist); OFF(distr_render_cfg, marcher);
+  OFF(distr_render_cfg, coarse_steps); OFF(distr_render_cfg, use_depth2normal); OFF(distr_render_cfg, normalize_normal);
+  OFF(distr_render_cfg, want_normal); OFF(distr_render_cfg, grad_depth); OFF(distr_render_cfg, grad_mask); OFF(distr_render_cfg, grad_camera);
+  OFF(distr_render_cfg, save_for_backward); OFF(distr_render_cfg, row0); OFF(distr_render_cfg, rows);
+  OFF(distr_decoder_desc, latent_size); OFF(distr_decoder_desc, hidden); OFF(distr_decoder_desc, num_linear); OFF(distr_decoder_desc, latent_in);
+  OFF(distr_render_stats, num_in_sphere); OFF(distr_render_stats, num_march_launches); OFF(distr_render_stats, num_point_evals);
+  OFF(distr_render_stats, num_valid); OFF(distr_render_stats, num_grad_samples); OFF(distr_render_stats, cluster_fallbacks);
+  OFF(distr_warp_cfg, H); OFF(distr_warp_cfg, W); OFF(distr_warp_cfg, K); OFF(distr_warp_cfg, K_inv); OFF(distr_warp_cfg, thres_depth);
+  printf("sizeof distr_decoder_desc %zu\nsizeof distr_render_stats %zu\nsizeof distr_warp_cfg %zu\n", sizeof(distr_decoder_desc),
+         sizeof(distr_render_stats), sizeof(distr_warp_cfg));
   if (ctx) destroy(ctx);
   dlclose(h);
   return 0;

@@ -149,7 +149,7 @@ def main():
     @stage('in-kernel phase timing of the decoder tile (wave 0 of each workgroup)')
     def phases():
         import os as _os
-        tile = 32 if _os.environ.get('DISTR_TILE_RB') == '1' else 64
+        tile = 64
         for n, label in ((512 * 512, 'dense: 4096 tiles of 64'), (tile * 200, '200 tiles (chip mostly idle)')):
             p = torch.rand(n, 3, device='cuda') * 1.6 - 0.8
             functions.debug_tile_timing(eng, lat_t, p, tile)

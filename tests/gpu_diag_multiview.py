@@ -41,17 +41,18 @@ def main():
     opt = torch.optim.Adam([lat], lr=1e-3)
     pairs = [pair_indices(0, i, n_img / 8, 1, n_img) for i in range(8)]
     w = {'color': 5.0, 'l2reg': 1.0}
-    for ns in (0, 1, 2, 4, 8):
-        pool = _StreamPool(ns, lat.device)
+    for ns in (-1, 0, 2, 4, 8):                 # -1: the batched round (all 16 depth renders in one launch sequence)
+        pool = _StreamPool(max(ns, 0), lat.device)
         for it in range(8):
             if it == 3:
                 torch.cuda.synchronize(); t0 = time.perf_counter()
             opt.zero_grad()
-            total, _ = multi_view_round(r, lat, imgs, cams, pairs, w, pool=pool)
+            total, _ = multi_view_round(r, lat, imgs, cams, pairs, w, pool=pool, batched=(ns < 0))
             total.backward()
             opt.step()
         torch.cuda.synchronize()
-        print('%dx%d, 8 view pairs, streams=%d: %.2f ms per round (fwd+bwd+Adam), loss %.5f' % (size, size, ns, (time.perf_counter() - t0) * 1e3 / 5, float(total)))
+        print('%dx%d, 8 view pairs, %s: %.2f ms per round (fwd+bwd+Adam), loss %.5f'
+              % (size, size, 'batched' if ns < 0 else 'streams=%d' % ns, (time.perf_counter() - t0) * 1e3 / 5, float(total)))
 
 
 if __name__ == '__main__':

@@ -356,8 +356,10 @@ def test_optimize_multi_view_distributed_on_hip_path():
     import torch.multiprocessing as mp
     serial, g = _g9_round_hip(False)
     assert abs(serial[0] - float(g['loss_total'])) <= 2e-4 * abs(float(g['loss_total']))
+    fl = {k: float(v) for k, v in np.load(os.path.join(GOLDEN, 'noise_floor_g4_g5_g9_g11.npz')).items()}
     for a, name in zip(serial[1:], ('g_latent', 'g_rot', 'g_scale', 'g_trans')):
-        assert np.abs(a - g[name]).max() <= 1e-2 * np.abs(g[name]).max(), name
+        # same bar as test_multi_view_round_matches_reference_golden: 2 x the reference's own noise floor (not below 5e-5)
+        assert np.abs(a - g[name]).max() <= max(2.0 * fl['g9_%s_rel' % name], 5e-5) * np.abs(g[name]).max(), name
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29800 + (os.getpid() % 90)
@@ -429,11 +431,17 @@ def test_bench_rccl_multi_gpu():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                '--master-port', str(29790 + (os.getpid() % 40) + len(outs)), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
                '--warmup', '5'] + extra
+        if not extra[2:]:
+            # the balanced run without a launcher and without the IPC variable: bench.py spawns its ranks and sets it itself
+            cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '5'] + extra
+            env = {k: v for k, v in env.items() if k not in ('HSA_ENABLE_IPC_MODE_LEGACY', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
     plain, bal = outs
     assert plain['n_gpus'] == 2 and plain['scaling'] == 'weak' and plain['config']['cluster_fallbacks'] == 0
+    for j in outs:
+        assert j['config']['rccl']['backend'] == 'nccl' and j['config']['rccl']['world_size'] == 2, j['config']['rccl']
     assert abs(plain['value'] - 2 * 512 * 512 / (plain['ms_per_step'] * 1e-3)) <= 1e-6 * plain['value']
     plan = bal['config']['balance_plan']
     assert plan is not None and plan[1][0][2] < 512, plan              # view 7 (rank 1) hands rows to rank 0

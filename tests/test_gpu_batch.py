@@ -1,0 +1,206 @@
+"""Batched render (distr_render_forward_batch / _backward_batch / distr_render_normal_batch): several views -- same or different
+shape codes, per-view no_grad_* options -- in ONE launch sequence. The contract under test: every view of a batch is
+BYTE-IDENTICAL, outputs and gradients, to a stand-alone render of that view through the single-view entry points (which the
+oracle / golden tests pin). Reference behaviour being batched: the 16 render_depth calls of a multi-view round,
+core/inv_optimizer/optimize_multi.py:62-81 + core/sdfrenderer/renderer_warp.py:108-109."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine(fixture_decoder):
+    from distr import functions
+    Ws, bs, _ = fixture_decoder
+    return functions.engine_from_weights(Ws, bs, 0)
+
+
+def _cams(n, elev=20.0):
+    from distr import fixture
+    return [fixture.make_camera(360.0 / n * i + 7.0, elev if i % 3 else -15.0, 1.6 if i % 4 else 1.45, 5.0 * i) for i in range(n)]
+
+
+def _raw_single(engine, cfg, lat, R, T, gz, gq, gd, gn):
+    """One view through distr_render_forward / distr_render_backward. Returns dict of numpy arrays."""
+    import torch
+    from distr import binding
+    p = binding.ptr
+    ctx = engine.ctx
+    P = cfg.band_rows * cfg.W
+    fwd, bwd = ctx.workspace_bytes(cfg)
+    dev = engine.device
+    ws = torch.empty(fwd, dtype=torch.uint8, device=dev)
+    z, m, q = torch.empty(P, device=dev), torch.empty(P, dtype=torch.uint8, device=dev), torch.empty(P, device=dev)
+    d, nm = (torch.empty(P, device=dev), torch.empty(P, 3, device=dev)) if cfg.want_normal else (None, None)
+    ctx.check(ctx.L.distr_render_forward(ctx.h, C.byref(cfg), p(lat), p(R), p(T), p(z), p(m), p(q), p(d), p(nm), p(ws), ws.numel(), ctx.stream()))
+    gl, gR, gT = torch.empty(256, device=dev), torch.empty(9, device=dev), torch.empty(3, device=dev)
+    wsb = torch.empty(bwd, dtype=torch.uint8, device=dev)
+    ctx.check(ctx.L.distr_render_backward(ctx.h, C.byref(cfg), p(ws), ws.numel(), p(gz), p(gq), p(gd), p(gn), p(gl), p(gR), p(gT),
+                                          p(wsb), wsb.numel(), ctx.stream()))
+    st = ctx.render_stats(cfg, ws)
+    torch.cuda.synchronize()
+    out = dict(z=z, m=m, q=q, gl=gl, gR=gR, gT=gT)
+    if cfg.want_normal:
+        out.update(d=d, n=nm)
+    return {k: v.cpu().numpy() for k, v in out.items()}, st
+
+
+def _raw_batch(engine, cfg, lats, Rs, Ts, flags, gz, gq, gd, gn):
+    import torch
+    from distr import binding
+    p = binding.ptr
+    ctx = engine.ctx
+    B = Rs.shape[0]
+    P = cfg.band_rows * cfg.W
+    fwd, bwd = ctx.workspace_bytes(cfg)
+    dev = engine.device
+    ws = torch.empty(B * fwd, dtype=torch.uint8, device=dev)
+    z, m, q = torch.empty(B, P, device=dev), torch.empty(B, P, dtype=torch.uint8, device=dev), torch.empty(B, P, device=dev)
+    d, nm = (torch.empty(B, P, device=dev), torch.empty(B, P, 3, device=dev)) if cfg.want_normal else (None, None)
+    fl = None if flags is None else (C.c_int32 * B)(*flags)
+    ctx.check(ctx.L.distr_render_forward_batch(ctx.h, C.byref(cfg), B, fl, p(lats), 0 if lats.shape[0] == 1 else 256, p(Rs), p(Ts),
+                                               p(z), p(m), p(q), p(d), p(nm), p(ws), ws.numel(), ctx.stream()))
+    gl, gR, gT = torch.empty(B, 256, device=dev), torch.empty(B, 9, device=dev), torch.empty(B, 3, device=dev)
+    wsb = torch.empty(B * bwd, dtype=torch.uint8, device=dev)
+    ctx.check(ctx.L.distr_render_backward_batch(ctx.h, C.byref(cfg), B, p(ws), ws.numel(), p(gz), p(gq), p(gd), p(gn), p(gl), p(gR), p(gT),
+                                                p(wsb), wsb.numel(), ctx.stream()))
+    stats = [ctx.render_stats(cfg, ws[b * fwd:(b + 1) * fwd]) for b in range(B)]
+    torch.cuda.synchronize()
+    out = dict(z=z, m=m, q=q, gl=gl, gR=gR, gT=gT)
+    if cfg.want_normal:
+        out.update(d=d, n=nm)
+    return {k: v.cpu().numpy() for k, v in out.items()}, stats
+
+
+def _check_batch(engine, fixture_decoder, H, W, B, shared, flags, band=None, **kw):
+    import torch
+    from distr import binding, fixture
+    _, _, latent = fixture_decoder
+    dev = engine.device
+    K = fixture.make_intrinsic(H, W)
+    cfg = binding.make_cfg((H, W), K, band=band, **kw)
+    P = cfg.band_rows * W
+    lat_np = [latent] + [fixture.make_latent(1300 + i) for i in range(1, B)]
+    lats = torch.from_numpy(np.concatenate(lat_np[:1 if shared else B], 0)).to(dev).contiguous()
+    cams = _cams(B)
+    Rs = torch.from_numpy(np.stack([c[0] for c in cams]).astype(np.float32)).to(dev).reshape(B, 9).contiguous()
+    Ts = torch.from_numpy(np.stack([c[1] for c in cams]).astype(np.float32)).to(dev).contiguous()
+    rs = np.random.RandomState(11)
+    gz, gq, gd = (torch.from_numpy(rs.randn(B, P).astype(np.float32)).to(dev) for _ in range(3))
+    gn = torch.from_numpy(rs.randn(B, P, 3).astype(np.float32)).to(dev)
+    if not cfg.want_normal:
+        gd = gn = None
+    got, stats = _raw_batch(engine, cfg, lats, Rs, Ts, flags, gz, gq, gd, gn)
+    evals = 0
+    for b in range(B):
+        c1 = cfg.clone()
+        if flags is not None:
+            c1.grad_depth, c1.grad_mask, c1.grad_camera = int(bool(flags[b] & 1)), int(bool(flags[b] & 2)), int(bool(flags[b] & 4))
+            # the workspace layout of a stand-alone render follows ITS cfg; the batch's follows the union -> same values either way
+        ref, st = _raw_single(engine, c1, lats[0 if shared else b], Rs[b], Ts[b], gz[b], gq[b], None if gd is None else gd[b],
+                              None if gn is None else gn[b])
+        for k in ref:
+            assert got[k][b].tobytes() == ref[k].tobytes(), (b, k, np.abs(got[k][b].astype(np.float64) - ref[k]).max())
+        for k in ('num_in_sphere', 'num_point_evals', 'num_valid', 'num_grad_samples'):
+            assert stats[b][k] == st[k], (b, k, stats[b][k], st[k])
+        assert stats[b]['num_valid'] > 0 or b > 0
+        evals += st['num_point_evals']
+    return evals
+
+
+def test_batch_16_views_of_137_equals_per_view(engine, fixture_decoder):
+    """The multi-view round's shape: 16 views of 137 x 137 with ONE shape code, march_step 100, buffer_size 1, 'recursive'
+    (run_multi_pmodata.py:92), every second view rendered with no_grad_depth (renderer_warp.py:109)."""
+    flags = [7, 6] * 8
+    _check_batch(engine, fixture_decoder, 137, 137, 16, True, flags, march_step=100, buffer_size=1, marcher='recursive', want_normal=False)
+
+
+@pytest.mark.parametrize('case', [
+    dict(H=96, W=80, B=4, shared=False, flags=None, kw=dict(march_step=40, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)),
+    dict(H=64, W=72, B=3, shared=False, flags=[7, 3, 5], kw=dict(march_step=30, buffer_size=2, marcher='pyramid_recursive', use_depth2normal=False)),
+    dict(H=40, W=40, B=3, shared=True, flags=None, kw=dict(march_step=12, buffer_size=3, marcher='trivial', use_depth2normal=True)),
+    dict(H=256, W=256, B=5, shared=False, flags=None, kw=dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)),
+    dict(H=33, W=47, B=64, shared=True, flags=None, kw=dict(march_step=25, buffer_size=1, marcher='recursive', want_normal=False)),
+    dict(H=128, W=96, B=2, shared=False, flags=None, band=(32, 64), kw=dict(march_step=30, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)),
+], ids=['shapes4-pyramid-d2n', 'autograd-normals-flags', 'trivial', 'c2-size-5-shapes', 'max-batch-64', 'row-band'])
+def test_batch_equals_per_view(engine, fixture_decoder, case):
+    """Different shape codes per view (a batch of shapes, BASELINE.json configs[4]), all marchers, both normal modes, per-view
+    flags, ragged sizes, the largest batch, a row band: byte equality with the stand-alone renders, forward and backward."""
+    _check_batch(engine, fixture_decoder, case['H'], case['W'], case['B'], case['shared'], case['flags'], band=case.get('band'), **case['kw'])
+
+
+def test_batch_argument_checks(engine, fixture_decoder):
+    import torch
+    from distr import binding, fixture
+    p = binding.ptr
+    ctx = engine.ctx
+    cfg = binding.make_cfg((32, 32), fixture.make_intrinsic(32, 32), march_step=10, buffer_size=1, marcher='recursive', want_normal=False,
+                           grad_depth=False)
+    fwd, _ = ctx.workspace_bytes(cfg)
+    t = torch.zeros(4 * 32 * 32 * 4, device='cuda')
+    ws = torch.empty(2 * fwd, dtype=torch.uint8, device='cuda')
+
+    def call(n, flags, wsb, stride=0):
+        fl = None if flags is None else (C.c_int32 * len(flags))(*flags)
+        return ctx.L.distr_render_forward_batch(ctx.h, C.byref(cfg), n, fl, p(t), stride, p(t), p(t), p(t), p(t), p(t), None, None, p(ws), wsb, ctx.stream())
+    assert call(0, None, ws.numel()) == -1 and call(65, None, ws.numel()) == -1
+    assert call(3, None, ws.numel()) == -4                       # workspace holds two views
+    assert call(2, [6, 7], ws.numel()) == -1                     # view 1 asks for the depth gradient cfg has switched off
+    assert b'view_flags[1]' in ctx.L.distr_last_error(ctx.h)
+    assert call(2, None, ws.numel(), stride=100) == -1           # stride shorter than a shape code
+    assert call(2, [6, 2], ws.numel()) == 0
+    torch.cuda.synchronize()
+
+
+def test_batch_autograd_function_and_warp_round(fixture_decoder):
+    """The product path: SDFRenderer_warp.render_warp_batch vs render_warp pair by pair (identical outputs), and one round of
+    multi_view_round batched vs on the stream pool (same loss; gradients equal up to the order in which the views' shape-code
+    gradients are added)."""
+    import torch
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.inv_optimizer import multi_view_round
+    from core.inv_optimizer.optimize_multi import _StreamPool, pair_indices
+    from core.sdfrenderer import SDFRenderer_warp
+    from distr import fixture
+    from oracle.gen_synth import procedural_images
+    Ws, bs, latent = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W), ('bias', b))})
+    size = 72
+    K = fixture.make_intrinsic(size, size)
+    r = SDFRenderer_warp(dec.cuda(), K, img_hw=(size, size), march_step=60, buffer_size=1)
+
+    class Cam(object):
+        def __init__(self, R, T):
+            self.extrinsic = np.concatenate([R, T[:, None]], 1).astype(np.float32)
+    n_img = 12
+    cams = [Cam(*fixture.make_camera(30.0 * i, 20.0, 1.6, 0.0)) for i in range(n_img)]
+    a, b = procedural_images(size, size)
+    imgs = [torch.from_numpy(np.roll(a if i % 2 else b, 3 * i, axis=1).copy()).cuda() for i in range(n_img)]
+    pairs = [pair_indices(0, i, n_img / 4, 1, n_img) for i in range(4)]
+    w = {'color': 5.0, 'l2reg': 1.0}
+    res = {}
+    for mode in ('batched', 'pool'):
+        lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+        total, pack = multi_view_round(r, lat, imgs, cams, pairs, w, pool=_StreamPool(2, lat.device), batched=(mode == 'batched'))
+        total.backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(total), lat.grad.cpu().numpy(), float(pack['color']))
+    assert res['batched'][0] == res['pool'][0] and res['batched'][2] == res['pool'][2]
+    ga, gb = res['batched'][1], res['pool'][1]
+    assert np.abs(ga - gb).max() <= 2e-6 * np.abs(gb).max()
+    # pair by pair: every element of the 9-tuple
+    from core.inv_optimizer.loss_multi import pair_cameras
+    lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+    args = []
+    for (i1, i2) in pairs:
+        (R1, T1), (R2, T2) = pair_cameras(cams, i1, i2, lat.device)
+        args.append((R1, T1, R2, T2, imgs[i1], imgs[i2]))
+    outs = r.render_warp_batch(lat, args)
+    for arg, out in zip(args, outs):
+        ref = r.render_warp(lat, *arg, no_grad_normal=True)
+        for x, y in zip(out, ref):
+            assert torch.equal(x.detach(), y.detach())

@@ -171,8 +171,24 @@ def test_c_abi_from_plain_c(libdistr, tmp_path):
     subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-o', exe, src, '-ldl'])
     out = subprocess.run([exe, binding.LIB_PATH], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert 'symbols=30' in out.stdout and 'version="distr' in out.stdout
+    assert ('symbols=%d' % len(binding.EXPORTS)) in out.stdout and 'version="distr' in out.stdout
     assert ('sizeof(cfg)=%d' % C.sizeof(binding.RenderCfg)) in out.stdout
+    # the ctypes mirrors against the C structs, field by field: name, offset, size (a drift here corrupts arguments silently)
+    mirrors = {'distr_render_cfg': binding.RenderCfg, 'distr_decoder_desc': binding.DecoderDesc, 'distr_render_stats': binding.RenderStats,
+               'distr_warp_cfg': binding.WarpCfg}
+    seen = {k: [] for k in mirrors}
+    for line in out.stdout.splitlines():
+        if line.startswith('offset '):
+            _, name, off, size = line.split()
+            st, field = name.split('.')
+            seen[st].append(field)
+            fd = getattr(mirrors[st], field)
+            assert (fd.offset, fd.size) == (int(off), int(size)), (name, fd.offset, fd.size, off, size)
+        elif line.startswith('sizeof distr_'):
+            _, st, size = line.split()
+            assert C.sizeof(mirrors[st]) == int(size), st
+    for st, cls in mirrors.items():
+        assert seen[st] == [f for f, _ in cls._fields_], (st, seen[st])          # same fields, same order, none missing
     import torch
     if not torch.cuda.is_available():
         assert 'create_rc=0' not in out.stdout and 'device' in out.stdout
