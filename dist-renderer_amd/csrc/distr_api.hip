@@ -45,6 +45,7 @@ struct distr_ctx {
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
   int min_cl = 2;               // smallest cluster: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032 (DISTR_CLUSTER_MIN=4: off)
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
+  bool sticky = true;           // DISTR_STICKY=0: cluster tiles never keep their rays across march steps (sticky_tile16)
 };
 
 namespace {
@@ -192,10 +193,20 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   return free_slot;
 }
 
-inline Xchg next_xchg(distr_ctx::XRegion* r, bool ts = false, int max_cl = 8, int test_abort = 0, int min_cl = 2) {
-  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr};
+// Exchange parameters of the next launch on region `r`. `epochs` = barrier epochs the launch may use (1; a step launch whose
+// cluster tiles may go sticky uses one per remaining march step). The epoch counter wraps after ~4e9: before it does, the flag
+// words are cleared on the stream (no stale word may equal a future epoch) and counting restarts at 1.
+inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl, int test_abort, int min_cl, uint32_t epochs = 1, bool sticky = false) {
+  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
-  if (r) { if (++r->epoch == 0) ++r->epoch; x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch; }
+  if (r) {
+    if (r->epoch > 0xffffffffu - epochs - 1) {
+      (void)hipMemsetAsync(r->flags, 0, (size_t)256 * 128 * sizeof(uint32_t), s);
+      r->epoch = 0;
+    }
+    x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch + 1; x.epochs = epochs; x.sticky = sticky ? 1 : 0;
+    r->epoch += epochs;
+  }
   return x;
 }
 
@@ -313,6 +324,7 @@ int distr_create(distr_ctx** out, int hip_device) {
   if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
   if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e) != 0;
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_STICKY")) ctx->sticky = atoi(e) != 0;
   {
     // invariants of the tile-size split (fine_split and the host-side grid sizes rely on them): multiples of 64,
     // 64 <= t16 <= t32, and t16 + t32 below one full round (16384 rays) so that "remainder" ranges never reach a round
@@ -580,7 +592,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       const int crb = (nviews * pad_to(ln, 32) <= t32) ? 1 : 2;
       const int ctile = c16 ? 16 : 32 * crb;
       unsigned tiles = NV * (unsigned)((ln + ctile - 1) / ctile);
-      A.xc = next_xchg(c16 ? xr : nullptr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
+      A.xc = next_xchg(c16 ? xr : nullptr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
       if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
       if (c16) {
@@ -624,7 +636,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
     G.n64 = skip64 ? 0 : std::min(up8(N64 / 64), 256);            // persistent: at most one 64-ray workgroup per CU
     G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
     A.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
-    A.xc = next_xchg(xr, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
+    A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky);
     unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
     if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
     G.n16 = up8(n16);
@@ -930,7 +942,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   int64_t ev = 0, launches = 0;
   for (int l = 1; l < V.nlev; ++l) { ev += (int64_t)V.lv[l].steps * C->cnt_level[l]; launches += V.lv[l].steps; }
   if (cfg->marcher == DISTR_MARCH_TRIVIAL) ev += (int64_t)V.fine_steps * C->cnt_level[0];
-  else for (int t = 0; t < V.fine_steps; ++t) ev += C->cnt_live[t];
+  else for (int t = 0; t < V.fine_steps; ++t) ev += C->cnt_live[t] + C->cnt_sticky[t];
   launches += V.fine_steps;
   out->num_point_evals = ev;
   out->num_march_launches = launches;
@@ -991,7 +1003,7 @@ int distr_get_live_counts(distr_ctx* ctx, const distr_render_cfg* cfg, const voi
   int k = 0;
   for (int l = V.nlev - 1; l >= 1; --l)
     for (int st = 0; st < V.lv[l].steps; ++st) { if (k < cap) out[k] = C->cnt_level[l]; ++k; }
-  for (int t = 0; t < V.fine_steps; ++t) { if (k < cap) out[k] = (cfg->marcher == DISTR_MARCH_TRIVIAL) ? C->cnt_level[0] : C->cnt_live[t]; ++k; }
+  for (int t = 0; t < V.fine_steps; ++t) { if (k < cap) out[k] = (cfg->marcher == DISTR_MARCH_TRIVIAL) ? C->cnt_level[0] : C->cnt_live[t] + C->cnt_sticky[t]; ++k; }
   *n = k;
   return DISTR_OK;
 }

@@ -35,7 +35,8 @@ struct Consts {
   float pad_coef;
   float cam_acc[12];      // backward: gR[9] + g_campos[3] from non-MLP terms
   float red[PSTRIDE];     // backward: reduced tile partials
-  int32_t cnt_live[MAX_STEPS + 2];  // live rays entering fine step t
+  int32_t cnt_live[MAX_STEPS + 2];  // live rays entering fine step t (compacted list of that step's launch)
+  int32_t cnt_sticky[MAX_STEPS + 2]; // rays evaluated at fine step t by sticky tiles (no list: sticky_tile16); statistics only
 };
 
 struct LevelView {
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float
   if (blockIdx.x == 0) {
     const int t = threadIdx.x;
     C->latent[t] = latent[t];
-    for (int i = t; i < MAX_STEPS + 2; i += 256) C->cnt_live[i] = 0;
+    for (int i = t; i < MAX_STEPS + 2; i += 256) { C->cnt_live[i] = 0; C->cnt_sticky[i] = 0; }
     for (int i = t; i < PSTRIDE; i += 256) C->red[i] = 0.f;
     if (t < 12) C->cam_acc[t] = 0.f;
     if (t < 3) { C->maxinit_bits[t] = 0u; C->cnt_level[t] = 0; }
@@ -721,6 +722,145 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
   (void)march_tile<MODE, RB, KEEP>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
 }
 
+// Sticky tail tile (renderer.py:528-567 from the point where few rays are left): once ALL live rays of a step fit the cluster
+// tiles of one launch (<= 32 tiles of 16 rays, 8 compute units each), every tile marches ITS 16 rays through all remaining steps
+// inside that launch -- no compaction, no launch boundary, no device-wide barrier: tiles never exchange anything. The ray state
+// (march depth, bounds, selected-row keys) lives in registers of wave 0; after the layer-7 exchange every member holds h7, so
+// every member computes lin8 and mirrors the depth update and the live test itself (identical arithmetic, nothing to
+// broadcast); only the lead member writes to memory. Finished rays stay in the tile as dead lanes; the tile ends when none is
+// live. A ray's arithmetic is exactly the per-step one (same points, same k-ordered chains) -> bit-identical outputs. The step
+// launches the host still issues find empty live lists and exit in a few microseconds. If a barrier times out (compute units
+// taken by another stream) the lead member finishes the tile alone on the single-workgroup path, like a non-sticky cluster tile.
+template <bool KEEP>
+__device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, const View& V,
+                                              int tile, int member, int64_t base, int64_t count) {
+  constexpr int TILE = 16;
+  const int tid = threadIdx.x;
+  const bool lead = member == 0;
+  const int32_t* list = live_sel(V, A.step);
+  const float* c0 = V.C->c0;
+  const float* c4 = V.C->c4;
+  int32_t id = -1;
+  bool live = false;
+  float m = 0.f, init_now = 0.f, maxbound = 0.f, minabs = 0.f;      // march state of this lane's ray, in registers across steps
+  if (tid < TILE && base + tid < count) {
+    id = list[base + tid];
+    live = true;
+    RayPre st;
+    raypre_load(V, id, st);
+    m = st.m; init_now = st.init_now; maxbound = st.maxbound; minabs = st.minabs;
+#pragma unroll
+    for (int k = 0; k < MAX_BS; ++k) { S.sk[k][tid] = st.ks[k]; S.ssl[k][tid] = st.sl[k]; }   // selected-row keys / slots: LDS between steps
+  }
+  const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+  bool solo = false;                  // the cluster broke up: the lead member finishes the tile alone
+  for (int step = A.step, k = 0;; ++step, ++k) {
+    if (tid < TILE) {
+      float p[3] = {0.f, 0.f, 0.f};
+      if (live) {        // (the ray direction is recomputed from the pixel id every step, like the per-step kernels do: ~40 flops
+        const CamRegs cam = load_cam(V.C);     // against three registers held across the decoder evaluation)
+        float cx, cy;
+        level_center(V.lv[0], id, cx, cy);
+        const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+        make_point(V.cfg.M, cam.c, g.d, init_now + m, p);
+      }
+      S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+    }
+    __syncthreads();
+    uint32_t nib[8];
+    float pre = 0.f;
+    bool clustered = false;
+    // a zero the optimiser cannot see through, added to the tile / member index: the weight-stream addresses of the decoder
+    // evaluation then depend on the loop iteration and are NOT hoisted out of the step loop (hoisted, they stay live across
+    // the whole loop body next to the 128-register weight ring and push the kernel into scratch)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    if (!solo) {
+      Xchg xs = A.xc;
+      xs.epoch = A.xc.epoch + (uint32_t)k;          // one epoch per march step (the host reserved them: Xchg::epochs)
+      xs.par = k & 1;                                // alternate the exchange slots: layer 1 of step k+1 must not reuse layer 7's
+      pre = mlp_forward16_cl<8, KEEP, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0);
+      clustered = S.fail == 0;
+      if (!clustered) {
+        if (!lead) return;
+        solo = true;
+        if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
+        __syncthreads();
+      }
+    }
+    if (solo) pre = mlp_forward16<KEEP>(D, D16, c0 + zero, c4 + zero, S, nib);
+
+    long long mblock = -1;
+    if (tid < 64) {
+      const float s = tanh_spec(pre);            // (lane l holds ray l & 15)
+      const float zd = init_now + m;              // depth of this step's sample (as computed before the evaluation)
+      const unsigned long long was = __ballot(tid < TILE && live);
+      bool stay = false;
+      if (tid < TILE && live) {
+        const float mn = m + clampf(s, -cd, cd) * ratio;
+        const float za = mn + init_now;
+        const float a = fabsf(s);
+        if (lead) {
+          V.m[id] = mn;
+          RayPre st;                   // this step's view of the selected rows (only the keys and slots are read)
+          st.m = m; st.init_now = init_now; st.maxbound = maxbound; st.minabs = minabs;
+#pragma unroll
+          for (int k = 0; k < MAX_BS; ++k) { st.ks[k] = S.sk[k][tid]; st.sl[k] = S.ssl[k][tid]; }
+          const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);
+          if (slot >= 0) {
+            mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+            // the same insertion on the LDS copy: rows behind the new one move down, the new row takes its place
+            const int bs = V.cfg.buffer_size;
+            int pos = bs;
+            bool open = true;
+#pragma unroll
+            for (int k = MAX_BS - 1; k >= 0; --k) {
+              if (k < bs && open) { if (a < fabsf(st.ks[k])) pos = k; else open = false; }
+            }
+#pragma unroll
+            for (int k = MAX_BS - 1; k >= 1; --k) {
+              if (k < bs && k > pos) { S.sk[k][tid] = st.ks[k - 1]; S.ssl[k][tid] = st.sl[k - 1]; }
+            }
+#pragma unroll
+            for (int k = 0; k < MAX_BS; ++k) {
+              if (k == pos) { S.sk[k][tid] = s; S.ssl[k][tid] = slot; }
+            }
+          }
+          if (a < minabs) V.minabs[id] = a;
+          if (step == 0) V.first_sdf[id] = s;
+        }
+        if (a < minabs) minabs = a;
+        m = mn;
+        stay = (za < maxbound) && (a >= V.cfg.threshold);
+      }
+      live = stay;
+      const unsigned long long now = __ballot(tid < TILE && live);
+      if (tid == 0) {
+        S.cont = now != 0ull;
+        if (lead) atomicAdd(&V.C->cnt_sticky[step], __popcll(was));
+      }
+    }
+    if (KEEP && lead) {
+      if (tid < TILE) S.mb[tid] = mblock;
+      __syncthreads();
+      if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (mask_nibble_or)
+        const int j = tid >> 4, q = tid & 15;
+        const long long b = S.mb[j];
+        if (b >= 0) {
+          const uint4* src = reinterpret_cast<const uint4*>(&S.mk[j][0]);
+          uint4* dst = V.mstore + (size_t)b * 32;
+          dst[q] = src[q];
+          dst[q + 16] = src[q + 16];
+        }
+      } else {
+        store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+      }
+    }
+    __syncthreads();                   // S.cont visible; this step's LDS reads are done before the next step's points land
+    if (!S.cont || step + 1 >= V.fine_steps) break;
+  }
+}
+
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
 // MODE_FINE (recursive marchers), MODE_COARSE (pyramid levels of small images) and MODE_EVAL.
 template <int MODE, bool KEEP>
@@ -789,6 +929,12 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
     }
   }
   const View V = view_at(V0, vb);
+  if (MODE == MODE_FINE && cl == 8 && A.xc.sticky && !origin && A.step + 1 < V.fine_steps && ntiles + norigin <= 32) {
+    // the whole step fits one launch of 8-CU cluster tiles (every workgroup of the launch takes the same decision from the
+    // same counts): the tiles keep their rays to the end of the march
+    sticky_tile16<KEEP>(A, D, D16, S, V, tile, member, base, count);
+    return;
+  }
   const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, A.step) : nullptr;
 
   int32_t id = -1;

@@ -756,6 +756,9 @@ struct Smem16 {
 struct Smem16CL : Smem16 {
   uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
   int32_t fail;           // != 0: this member gave up on the cluster (assembly or barrier timed out / aborted)
+  int32_t cont;           // sticky tiles: any ray of the tile still live after this step
+  float sk[8][16];        // sticky tiles: the rays' selected-row keys (sdf, |.| ascending) and mask slots between steps
+  int32_t ssl[8][16];     // (DISTR_MAX_BUFFER_SIZE rows; kept here, not in registers, across the decoder evaluation)
 };
 
 struct DecoderDev16 {
@@ -971,6 +974,9 @@ struct Xchg {
   int32_t min_cl;      // smallest cluster size to use (2 = pair tiles up to 2032 rays; DISTR_CLUSTER_MIN=4 turns them off)
   int32_t test_abort;  // tests (DISTR_CLUSTER_TEST_ABORT=1): every lead member behaves as if its cluster had not assembled
   long long* ts;       // debug (DISTR_XCHG_TS=1): wall-clock stamps of cluster 0 / member 0 at phase boundaries, else null
+  int32_t par;         // parity of the exchange slots (sticky tiles alternate it per march step, see sticky_tile16)
+  int32_t sticky;      // 1: a launch whose clusters (8 CUs per tile) all fit may march its tiles to the end (DISTR_STICKY=0: off)
+  uint32_t epochs;     // epochs this launch may use: epoch .. epoch + epochs - 1 (one per march step of a sticky tile)
 };
 // Wall-clock budgets (100 MHz ticks) of the cluster protocol. Co-residency of a cluster's workgroups is NOT guaranteed by the
 // hardware (other streams / ranks may hold the compute units), so a cluster first ASSEMBLES: every member posts an arrival
@@ -1127,7 +1133,7 @@ __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const flo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, kq = lane >> 4, j = lane & 15;
   float* X = S.X;
-  float* slot = xbase + (layer & 1) * 8192;
+  float* slot = xbase + ((layer + xc.par) & 1) * 8192;
   f32x4 acc[NBL];
   const int rb0 = member * PER + wave * NBL;
   if (wave < ACT) {   // start values (bias / latent constants): requested by the previous layer before its exchange (cl_load_start)
@@ -1235,9 +1241,13 @@ __device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const flo
 // and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0. On return S.fail != 0 (uniform over the
 // workgroup) means this member gave up (cluster not assembled in time / a barrier timed out): the lead member's caller then
 // evaluates the tile with mlp_forward16 (S.xyz is untouched), the other members simply leave.
-template <int CL, bool KEEP>
+// ALL_LIN8 (sticky tiles): every member computes lin8 from its own copy of h7 and returns the pre-tanh value (all members then
+// mirror the march update in registers, no broadcast needed). assemble = false: the members are known to be resident (a later
+// march step of the same launch), no arrival / go handshake.
+template <int CL, bool KEEP, bool ALL_LIN8 = false>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
-                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member) {
+                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member,
+                                                  bool assemble = true) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -1251,7 +1261,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   DISTR_XTS(0);
   if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
     S.fail = 0;
-    __hip_atomic_store(flags + member, xc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (assemble) __hip_atomic_store(flags + member, xc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int c = 0; c < CL_AHEAD; ++c) cl_load_chunk<512, 512, CL>(D16.Wf[1], w[c], c, member, wave, lane);   // lin1's first weights travel while lin0 runs
@@ -1277,8 +1287,10 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     __syncthreads();
   }
   DISTR_XTS(1);
-  cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, xc.test_abort);
-  if (S.fail) return 0.f;
+  if (assemble) {
+    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, xc.test_abort);
+    if (S.fail) return 0.f;
+  }
   // position of every layer's chunk 0 in the network-wide chunk sequence (see layer_cl)
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
   static_assert(N1 >= CL_AHEAD, "the initial requests cover lin1's first chunks");
@@ -1300,7 +1312,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   if (S.fail) return 0.f;
   layer_cl<512, 512, CL, G7, GT, 0, 0, 0, 0>(D16.Wf[7], nullptr, nullptr, w, sa, nullptr, S, xc, xbase, flags, 7, member, KEEP && lead);
   if (S.fail) return 0.f;
-  if (!lead) return 0.f;
+  if (!lead && !ALL_LIN8) return 0.f;
   DISTR_XTS(32);
   {
     float p = 0.f;

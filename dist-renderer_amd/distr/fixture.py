@@ -110,6 +110,23 @@ def make_latent(seed):
     return (0.1 * rs.standard_normal((1, LATENT_SIZE))).astype(np.float32)
 
 
+def load_fixture_f2(path=None):
+    """Fixture "F2": a DeepSDF 8x512 decoder fitted to a NON-CONVEX analytic shape (a torus pierced by a thin plate: thin parts,
+    concavities, several surface crossings along a ray; oracle/fit_fixture_f2.py). Unlike F1 it cannot be regenerated from a seed
+    (a CPU Adam fit is not bit-reproducible), so the weights are data: every weight is a bf16-representable f32 value stored as its
+    upper 16 bits in tests/golden/fixture_f2.npz. Returns (weights, biases, latent) like make_decoder_weights."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'tests', 'golden', 'fixture_f2.npz')
+    z = np.load(path)
+    expand = lambda b: np.ascontiguousarray((b.astype(np.uint32) << 16).view(np.float32))
+    Ws = [expand(z['W%d' % l]) for l in range(NUM_LINEAR)]
+    bs = [expand(z['b%d' % l]) for l in range(NUM_LINEAR)]
+    for W, (o, i) in zip(Ws, layer_shapes()):
+        assert W.shape == (o, i), (W.shape, o, i)
+    return Ws, bs, np.ascontiguousarray(z['latent'], dtype=np.float32).reshape(1, LATENT_SIZE)
+
+
 def make_intrinsic(h, w):
     """K = [[w,0,w/2],[0,h,h/2],[0,0,1]]  (SURVEY 8d synthetic camera, ~53 deg FOV)."""
     return np.array([[float(w), 0.0, w / 2.0], [0.0, float(h), h / 2.0], [0.0, 0.0, 1.0]], dtype=np.float64)

@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE -- golden vectors of the REFERENCE itself on fixture F2 (the non-convex torus + thin-plate decoder of
+oracle/fit_fixture_f2.py, tests/golden/fixture_f2.npz). Runs only in the build container (imports /root/reference through
+oracle/ref_harness.py); the outputs are data.
+
+    python oracle/gen_golden_f2.py     # writes tests/golden/g1f2_*.npz, g3f2_*.npz, noise_floor_f2.npz
+
+G1-F2: C1 (64 x 64, 20 steps, buffer_size 3, rotated camera) x {trivial, recursive, pyramid_recursive} with depth2normal + the
+pyramid marcher with autograd normals. G3-F2: C2 (256 x 256, 50 steps, pyramid_recursive, depth2normal): 32 x 32 crop over the
+plate / ring crossing + whole-image summaries + gradients. Noise floors: the reference against itself under 1e-7 relative weight
+noise, for the gradient bars (thin parts and grazing rays make this fixture more sensitive than the blob of F1)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, '..', 'dist-renderer_amd'))
+sys.path.insert(0, _HERE)
+from distr import fixture  # noqa: E402
+import ref_harness as rh  # noqa: E402
+from gen_golden import render_case  # noqa: E402
+
+OUT = os.path.join(_HERE, '..', 'tests', 'golden')
+
+
+def meta(Ws, bs, latent, K, R, T, H, W, march_step, bsz, marcher, d2n, loss_seed=5, ratio=1.5):
+    return dict(weights_sha256=fixture.weights_sha256(Ws, bs), fixture='f2', latent=latent, K=K, R=R, T=T, H=H, W=W,
+                march_step=march_step, buffer_size=bsz, marcher=marcher, use_depth2normal=d2n, loss_seed=loss_seed, ratio=ratio,
+                weight_norm=False)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Ws, bs, latent = fixture.load_fixture_f2()
+    dec = rh.build_reference_decoder(Ws, bs, weight_norm=False)
+    rsn = np.random.RandomState(99)
+    Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
+    dec_n = rh.build_reference_decoder(Wn, bs, weight_norm=False)
+    floor = {}
+
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(35, 30, 1.6, 10)
+    for marcher, d2n in (('trivial', True), ('recursive', True), ('pyramid_recursive', True), ('pyramid_recursive', False)):
+        out = render_case(dec, latent, K, R, T, H, W, 20, 3, marcher, d2n)
+        out.update(meta(Ws, bs, latent, K, R, T, H, W, 20, 3, marcher, d2n))
+        name = 'g1f2_c1_%s_%s.npz' % (marcher, 'd2n' if d2n else 'agn')
+        np.savez_compressed(os.path.join(OUT, name), **out)
+        print(name, 'valid', int(out['mask'].sum()), 'glat', float(np.linalg.norm(out['g_latent'])), flush=True)
+        if marcher != 'trivial':
+            b = render_case(dec_n, latent, K, R, T, H, W, 20, 3, marcher, d2n)
+            key = 'c1_%s_%s' % (marcher, 'd2n' if d2n else 'agn')
+            both = out['mask'].astype(bool) & b['mask'].astype(bool)
+            floor[key + '_flips'] = int((out['mask'] != b['mask']).sum())
+            floor[key + '_depth'] = float(np.abs(out['depth'] - b['depth'])[both].max())
+            floor[key + '_min_sdf'] = float(np.abs(out['min_abs_query'] - b['min_abs_query']).max())
+            for k in ('g_latent', 'g_R', 'g_T'):
+                floor[key + '_' + k + '_rel'] = float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max())
+
+    H = W = 256
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-40, 35, 1.6, 0)
+    out = render_case(dec, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
+    full = out['mask'].astype(bool)
+    ys, xs = np.nonzero(full)
+    y0 = int(np.clip(int(np.median(ys)) - 16, 0, H - 32))
+    x0 = int(np.clip(int(np.median(xs)) - 16, 0, W - 32))
+    summ = dict(valid_count=int(full.sum()), sum_depth=float(out['depth'][full].sum()), sum_q=float(out['min_abs_query'].sum()))
+    crop = {k: out[k][y0:y0 + 32, x0:x0 + 32] for k in ['depth', 'normal', 'mask', 'min_abs_query']}
+    crop['zdepth'] = out['zdepth'].reshape(H, W)[y0:y0 + 32, x0:x0 + 32]
+    crop['mask_full'] = np.packbits(out['mask'].astype(np.uint8))
+    crop.update(g_latent=out['g_latent'], g_R=out['g_R'], g_T=out['g_T'], loss=out['loss'], crop_y0=y0, crop_x0=x0, **summ)
+    crop.update(meta(Ws, bs, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True))
+    np.savez_compressed(os.path.join(OUT, 'g3f2_c2_pyramid_recursive_d2n.npz'), **crop)
+    print('g3f2', summ, 'crop', y0, x0, 'crop valid', int(crop['mask'].sum()), flush=True)
+    b = render_case(dec_n, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
+    floor['c2_flips'] = int((out['mask'] != b['mask']).sum())
+    both = full & b['mask'].astype(bool)
+    floor['c2_depth'] = float(np.abs(out['depth'] - b['depth'])[both].max())
+    for k in ('g_latent', 'g_R', 'g_T'):
+        floor['c2_' + k + '_rel'] = float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max())
+    np.savez_compressed(os.path.join(OUT, 'noise_floor_f2.npz'), **floor)
+    print('noise floors', floor)
+
+
+if __name__ == '__main__':
+    main()

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 KNOBS = [
     {},                                                                     # the default configuration through the same script
     {'DISTR_SAVE_MASKS': '0'},                                              # backward recomputes the decoder forward (k_bwd<BWD_FULL>)
+    {'DISTR_STICKY': '0'},                                                  # cluster tiles re-compacted every step (no sticky tail)
     {'DISTR_CLUSTER': '0'},                                                 # single-workgroup 16-ray tiles only
     {'DISTR_CLUSTER': '4'},                                                 # clusters of at most 4 compute units
     {'DISTR_CLUSTER_MIN': '4'},                                             # no pair tiles

@@ -836,18 +836,21 @@ def test_color_render_matches_reference_golden(fixture_decoder):
 @pytest.mark.gpu
 def test_cluster_tiles_bit_identical_to_single_workgroup_tiles(fixture_decoder):
     """The deep tail of the march runs on cluster tiles (one 16-ray tile split over 8 / 4 workgroups on as many CUs,
-    slices exchanged through uncached memory, csrc/distr_mlp.hpp). Every output row is still one k-ordered chain, so a
-    render must be bit-identical with the cluster tiles switched off, forward and backward; no barrier may time out."""
+    slices exchanged through uncached memory, csrc/distr_mlp.hpp), and once a whole step fits one launch of 8-CU clusters the
+    tiles turn sticky (they keep their 16 rays to the end of the march inside that launch, sticky_tile16). Every output row is
+    still one k-ordered chain, so a render must be bit-identical with sticky tiles off, with smaller clusters and with the
+    cluster tiles switched off, forward and backward, with the same number of decoder evaluations; no barrier may time out."""
     import torch
     from distr import binding, fixture, functions
     Ws, bs, latent = fixture_decoder
-    outs = []
-    for env in ('8', '4', '0'):
-        os.environ['DISTR_CLUSTER'] = env
+    outs, stats, lives = [], [], []
+    for env in ({}, {'DISTR_STICKY': '0'}, {'DISTR_CLUSTER': '4'}, {'DISTR_CLUSTER': '0'}):
+        os.environ.update(env)
         try:
-            eng = functions.engine_from_weights(Ws, bs, 0)       # the knob is read at distr_create
+            eng = functions.engine_from_weights(Ws, bs, 0)       # the knobs are read at distr_create
         finally:
-            del os.environ['DISTR_CLUSTER']
+            for k_ in env:
+                del os.environ[k_]
         H = W = 96
         K = fixture.make_intrinsic(H, W)
         R, T = fixture.make_camera(35.0, 25.0, 1.6, 10.0)
@@ -867,9 +870,14 @@ def test_cluster_tiles_bit_identical_to_single_workgroup_tiles(fixture_decoder):
         st = eng.ctx.render_stats(cfg, ws)
         assert st['cluster_fallbacks'] == 0 and st['num_valid'] > 300
         outs.append(res)
+        stats.append(st)
+        lives.append(eng.ctx.live_counts(cfg, ws))
+    for i in (1, 2, 3):
+        assert stats[i]['num_point_evals'] == stats[0]['num_point_evals'] and lives[i] == lives[0], i    # same live-ray profile
+    assert 0 < sum(lives[0][-20:]) and max(lives[0][-20:]) <= 496                                          # the tail really ran sticky
     for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
-        assert outs[0][k].tobytes() == outs[2][k].tobytes(), k
-        assert outs[1][k].tobytes() == outs[2][k].tobytes(), k
+        for i in (1, 2, 3):
+            assert outs[i][k].tobytes() == outs[0][k].tobytes(), (i, k)
 
 
 @pytest.mark.gpu
