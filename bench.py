@@ -174,6 +174,10 @@ def main():
                     help='c3 at N > 1: keep exactly one whole view per GPU (default: five untimed calibration steps before the warm-up, in which the '
                          'ranks exchange step times and row cost profiles and the slowest views hand row bands to the fastest ranks, '
                          'distr.parallel.balance_views)')
+    ap.add_argument('--fixture', default='f1', choices=['f1', 'f2'],
+                    help='f1 (default, the headline): the seed-defined geometric-init decoder (a smooth blob); f2: the decoder fitted to a '
+                         'non-convex shape (torus pierced by a thin plate, tests/golden/fixture_f2.npz) -- a second data point for '
+                         'evaluations per ray and the roofline fraction, not the headline metric')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
@@ -202,7 +206,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    Ws, bs, latent_np = fixture.make_decoder_weights()
+    Ws, bs, latent_np = fixture.make_decoder_weights() if args.fixture == 'f1' else fixture.load_fixture_f2()
     eng = functions.engine_from_weights(Ws, bs, local)
     K = fixture.make_intrinsic(H, W)
     cfg = binding.make_cfg((H, W), K, march_step=MARCH_STEP, buffer_size=BUFFER_SIZE, ratio=RATIO, marcher=args.marcher,
@@ -433,7 +437,8 @@ def main():
             'value': rays / elapsed, 'unit': 'rays/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'median_ms_per_step': 1e3 * median_s,
             'value_at_median': rays / args.steps / median_s, 'higher_is_better': True, 'scaling': 'strong' if c5 else 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)',
+            'dtype': 'f32', 'data': 'synthetic (seed-defined geometric-init DeepSDF 8x512 weights, latent seed 1234, synthetic cameras)' if args.fixture == 'f1' else
+                                    'synthetic (fixture F2: DeepSDF 8x512 decoder fitted to an analytic torus + thin plate, synthetic cameras)',
             'config': {'workload': '%s%dx%d, %d march steps, %s marcher, buffer_size %d, ratio %.1f, depth2normal normals, '
                                    '%s loss, fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
                                                          args.marcher, BUFFER_SIZE, RATIO,
@@ -445,7 +450,8 @@ def main():
                        'rccl': collective_info(world),
                        'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'calibration_steps_before_warmup': calibration_steps, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
-                       'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'],
+                       'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'], 'fixture': args.fixture,
+                       'decoder_evals_per_image_ray': stats['num_point_evals'] / float(len(items) * H * W) if not c5 else None,
                        'decoder_evals_per_step_rank0': stats['num_point_evals'],
                        'march_launches_per_step_rank0': stats['num_march_launches'],
                        'forward_ms_one_item': fwd_ms, 'backward_ms_one_item': bwd_ms, 'cluster_fallbacks': stats['cluster_fallbacks'],

@@ -27,6 +27,7 @@ struct Consts {
   int32_t vflags;         // per-view gradient switches (VF_*): a batch renders views with different no_grad_* options in one launch
   int32_t xchg_err;       // cluster tiles that fell back to the single-workgroup path (not assembled in time / barrier timeout); results stay exact
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
+  int32_t origin_done;    // f_origin has been evaluated (by the launch that turned sticky; else the last step evaluates it)
   uint32_t maxinit_bits[3];
   int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
   int32_t cnt_valid;
@@ -293,6 +294,7 @@ __global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float
       C->cdist = cd;
       C->vflags = vf.f[vb];
       C->f_origin = 0.f;
+      C->origin_done = 0;
       C->xchg_err = 0;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
     }
@@ -837,7 +839,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       const unsigned long long now = __ballot(tid < TILE && live);
       if (tid == 0) {
         S.cont = now != 0ull;
-        if (lead) atomicAdd(&V.C->cnt_sticky[step], __popcll(was));
+        if (lead && k > 0) atomicAdd(&V.C->cnt_sticky[step], __popcll(was));   // (step A.step itself is counted in cnt_live)
       }
     }
     if (KEEP && lead) {
@@ -892,8 +894,18 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   const int64_t n = hi - lo;
   const int64_t ntiles = (n + TILE - 1) / TILE;
   // the tiles after the last real one evaluate f(0,0,0) of each view (sample point of padded rows) in the launch that carries
-  // `origin_tile`: on a tail step they ride along for free instead of adding tiles to a full round elsewhere
-  const int norigin = (MODE == MODE_FINE && origin_tile) ? B : 0;
+  // `origin_tile` (the last step): on a tail step they ride along for free instead of adding tiles to a full round elsewhere
+  int norigin = (MODE == MODE_FINE && origin_tile) ? B : 0;
+  // Sticky launch: ALL live rays of the step (granularity 16: nothing went to the 32- / 64-ray roles) and the views' origin tiles
+  // fit one launch of 8-CU cluster tiles -- every workgroup of the launch takes the same decision from the same counts. The
+  // tiles then keep their rays to the end of the march (sticky_tile16) and the origin tiles ride on THIS launch (the last
+  // step's launch would otherwise be a whole cluster-tile latency for them alone). A small remainder next to whole 64-ray
+  // rounds must NOT go sticky: its rays would finish their march inside a launch whose other rays move on step by step.
+  bool sticky_launch = false;
+  if (MODE == MODE_FINE && A.xc.buf && A.xc.sticky && A.xc.max_cl >= 8 && gran == 16 && A.step + 1 < V0.fine_steps && ntiles + B <= 32) {
+    sticky_launch = true;
+    norigin = B;
+  }
   // Cluster size from the (device-side) number of tiles of this launch: with at most 32 / 64 / 128 tiles -- counting the extra
   // tiles for f(origin) on the one launch that carries them, so that the grid stays within 256 workgroups -- 8 / 4 / 2 compute units
   // share each tile. Measured step time (C3 tail, profiles/r02_steps_c3.md): 52 us (8), 64 us (4), 94 us (2), 107 us (single
@@ -929,12 +941,11 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
     }
   }
   const View V = view_at(V0, vb);
-  if (MODE == MODE_FINE && cl == 8 && A.xc.sticky && !origin && A.step + 1 < V.fine_steps && ntiles + norigin <= 32) {
-    // the whole step fits one launch of 8-CU cluster tiles (every workgroup of the launch takes the same decision from the
-    // same counts): the tiles keep their rays to the end of the march
+  if (sticky_launch && !origin) {
     sticky_tile16<KEEP>(A, D, D16, S, V, tile, member, base, count);
     return;
   }
+  if (origin && V.C->origin_done) return;   // f(origin) was evaluated by an earlier launch (the one that turned sticky)
   const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, A.step) : nullptr;
 
   int32_t id = -1;
@@ -991,7 +1002,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   if (tid < 64) {
     const float s = tanh_spec(pre);
     if (origin) {
-      if (tid == 0) { V.C->f_origin = s; mblock = V.morigin; }
+      if (tid == 0) { V.C->f_origin = s; V.C->origin_done = 1; mblock = V.morigin; }
     } else if (MODE == MODE_EVAL) {
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
     } else if (MODE == MODE_COARSE) {

@@ -35,10 +35,19 @@ def main():
     torch.set_num_threads(8)
     Ws, bs, latent = fixture.load_fixture_f2()
     dec = rh.build_reference_decoder(Ws, bs, weight_norm=False)
-    rsn = np.random.RandomState(99)
-    Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
-    dec_n = rh.build_reference_decoder(Wn, bs, weight_norm=False)
+    # noise floors: the reference against itself under 1e-7 relative weight noise, MAXIMUM over several noise draws -- on this
+    # fixture a residual is dominated by discrete events (a ray whose |sdf| lands within ~1e-7 of the stop threshold stops one
+    # step earlier or later and hands its gradient to another row), which a single draw may or may not contain
+    NSEEDS = 4
+    decs_n = []
+    for sd in range(NSEEDS):
+        rsn = np.random.RandomState(99 + sd)
+        Wn = [(Wl * (1 + 1e-7 * rsn.standard_normal(Wl.shape))).astype(np.float32) for Wl in Ws]
+        decs_n.append(rh.build_reference_decoder(Wn, bs, weight_norm=False))
     floor = {}
+
+    def upd(key, v):
+        floor[key] = max(floor.get(key, 0), v)
 
     H = W = 64
     K = fixture.make_intrinsic(H, W)
@@ -49,15 +58,15 @@ def main():
         name = 'g1f2_c1_%s_%s.npz' % (marcher, 'd2n' if d2n else 'agn')
         np.savez_compressed(os.path.join(OUT, name), **out)
         print(name, 'valid', int(out['mask'].sum()), 'glat', float(np.linalg.norm(out['g_latent'])), flush=True)
-        if marcher != 'trivial':
+        for dec_n in decs_n:
             b = render_case(dec_n, latent, K, R, T, H, W, 20, 3, marcher, d2n)
             key = 'c1_%s_%s' % (marcher, 'd2n' if d2n else 'agn')
             both = out['mask'].astype(bool) & b['mask'].astype(bool)
-            floor[key + '_flips'] = int((out['mask'] != b['mask']).sum())
-            floor[key + '_depth'] = float(np.abs(out['depth'] - b['depth'])[both].max())
-            floor[key + '_min_sdf'] = float(np.abs(out['min_abs_query'] - b['min_abs_query']).max())
+            upd(key + '_flips', int((out['mask'] != b['mask']).sum()))
+            upd(key + '_depth', float(np.abs(out['depth'] - b['depth'])[both].max()))
+            upd(key + '_min_sdf', float(np.abs(out['min_abs_query'] - b['min_abs_query']).max()))
             for k in ('g_latent', 'g_R', 'g_T'):
-                floor[key + '_' + k + '_rel'] = float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max())
+                upd(key + '_' + k + '_rel', float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max()))
 
     H = W = 256
     K = fixture.make_intrinsic(H, W)
@@ -75,12 +84,15 @@ def main():
     crop.update(meta(Ws, bs, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True))
     np.savez_compressed(os.path.join(OUT, 'g3f2_c2_pyramid_recursive_d2n.npz'), **crop)
     print('g3f2', summ, 'crop', y0, x0, 'crop valid', int(crop['mask'].sum()), flush=True)
-    b = render_case(dec_n, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
-    floor['c2_flips'] = int((out['mask'] != b['mask']).sum())
-    both = full & b['mask'].astype(bool)
-    floor['c2_depth'] = float(np.abs(out['depth'] - b['depth'])[both].max())
-    for k in ('g_latent', 'g_R', 'g_T'):
-        floor['c2_' + k + '_rel'] = float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max())
+    for dec_n in decs_n[:2]:
+        b = render_case(dec_n, latent, K, R, T, H, W, 50, 3, 'pyramid_recursive', True)
+        upd('c2_flips', int((out['mask'] != b['mask']).sum()))
+        both = full & b['mask'].astype(bool)
+        upd('c2_depth', float(np.abs(out['depth'] - b['depth'])[both].max()))
+        for k in ('g_latent', 'g_R', 'g_T'):
+            upd('c2_' + k + '_rel', float(np.abs(out[k] - b[k]).max() / np.abs(out[k]).max()))
+    floor['noise_draws_c1'] = NSEEDS
+    floor['noise_draws_c2'] = 2
     np.savez_compressed(os.path.join(OUT, 'noise_floor_f2.npz'), **floor)
     print('noise floors', floor)
 

@@ -61,6 +61,14 @@ def main():
     for _ in range(3):
         fwd()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fwd()
+    e1.record()
+    torch.cuda.synchronize()
+    wall_ms = e0.elapsed_time(e1) / 20
+    st0 = eng.ctx.render_stats(cfg, ws)
     times = []
     for _ in range(args.reps):
         eng.ctx.profile_enable(True)
@@ -94,6 +102,7 @@ def main():
         key = 'coarse' if i < ncoarse else ('rounds' if n >= 16384 else cls)
         c = classes.setdefault(key, [0, 0.0, 0])
         c[0] += 1; c[1] += us; c[2] += n
+    lines += ['', 'whole forward, 20 back-to-back without brackets: %.3f ms each; cluster fallbacks %d' % (wall_ms, st0['cluster_fallbacks'])]
     lines += ['', 'total: %d evaluations, %.2f ms in march kernels = %.1f TFLOP/s = %.3f of peak; at the dense rate (%.1f TFLOP/s) the same evaluations '
               'take %.2f ms' % (sum(counts), tot_us / 1e3, FLOP * sum(counts) / (tot_us * 1e-6) / 1e12, FLOP * sum(counts) / (tot_us * 1e-6) / 1e12 / PEAK,
                                dense_rate or 0.0, tot_prop / 1e3), '',

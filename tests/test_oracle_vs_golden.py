@@ -105,6 +105,51 @@ def test_render_matches_reference(cpu_oracle, name):
     _check(out, gl, gR, gT, g)
 
 
+# ---- fixture F2: the non-convex torus + thin plate decoder (tests/golden/fixture_f2.npz, oracle/gen_golden_f2.py)
+G1F2 = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1f2_*.npz')))
+
+
+@pytest.fixture(scope='module')
+def oracle_f2():
+    Ws, bs, _ = fixture.load_fixture_f2()
+    return orc.Oracle(Ws, bs), fixture.weights_sha256(Ws, bs)
+
+
+def _floor_f2():
+    return {k: float(v) for k, v in np.load(os.path.join(GOLDEN, 'noise_floor_f2.npz')).items()}
+
+
+@pytest.mark.parametrize('name', G1F2)
+def test_f2_render_matches_reference(oracle_f2, name):
+    """The oracle on a shape with thin parts, concavities and several surface crossings per ray, against the reference's own
+    outputs (C1: three marchers with depth2normal + autograd normals)."""
+    O, sha = oracle_f2
+    g = _load(name)
+    assert str(g['fixture']) == 'f2' and str(g['weights_sha256']) == sha
+    out, gl, gR, gT = _render_and_grads(O, g)
+    fl = _floor_f2()
+    key = 'c1_%s_%s' % (str(g['marcher']), 'd2n' if bool(g['use_depth2normal']) else 'agn')
+    bar = max(1e-3, 2.0 * max(fl.get(key + '_g_latent_rel', 0.0), fl.get(key + '_g_R_rel', 0.0), fl.get(key + '_g_T_rel', 0.0)))
+    _check(out, gl, gR, gT, g, grad_tol=bar)
+    assert int(out['mask'].sum()) > 1000
+
+
+def test_f2_c2_crop_and_summaries(oracle_f2):
+    """F2 at C2 (256 x 256, 50 steps, pyramid_recursive, depth2normal): the whole mask, a 32 x 32 crop, summaries, gradients."""
+    O, _ = oracle_f2
+    g = _load('g3f2_c2_pyramid_recursive_d2n.npz')
+    fl = _floor_f2()
+    out, gl, gR, gT = _render_and_grads(O, g)
+    _check(out, gl, gR, gT, g, crop=(int(g['crop_y0']), int(g['crop_x0'])),
+           grad_tol=max(1e-3, 2.0 * max(fl['c2_g_latent_rel'], fl['c2_g_R_rel'], fl['c2_g_T_rel'])))
+    H, W = int(g['H']), int(g['W'])
+    m = out['mask'].reshape(H, W).astype(bool)
+    ref_full = np.unpackbits(g['mask_full'])[:H * W].reshape(H, W).astype(bool)
+    assert int((m != ref_full).sum()) <= max(2, 2 * int(fl['c2_flips']), int(0.001 * int(g['valid_count'])))
+    assert abs(out['depth'].reshape(-1)[m.reshape(-1)].sum() / m.sum() - float(g['sum_depth']) / int(g['valid_count'])) <= 1e-4
+    assert abs(out['min_sdf'].sum() - float(g['sum_q'])) / (H * W) <= 1e-5
+
+
 def test_decode_sdf_matches_reference(cpu_oracle):
     g = _load('g2_decode_sdf.npz')
     sdf = cpu_oracle.decode_sdf(g['latent'], g['points'])
