@@ -6,7 +6,7 @@ set -u
 OUT=${1:-gpurun_out/ubench}
 mkdir -p "$OUT"
 cd "$(dirname "$0")"
-for b in mfma_sustain mfma_rate mfma_chain dual_pipe cluster_exchange; do
+for b in mfma_sustain mfma_rate mfma_chain dual_pipe cluster_exchange split_bf16_layer; do
   [ -f $b.hip ] && /opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 $b.hip -o /tmp/$b 2> "$OLDPWD/$OUT/$b.build.log"
 done
 cd "$OLDPWD"
@@ -18,5 +18,6 @@ kill $SMI 2>/dev/null
 /tmp/mfma_chain > "$OUT/mfma_chain.log" 2>&1
 /tmp/dual_pipe > "$OUT/dual_pipe.log" 2>&1
 /tmp/cluster_exchange > "$OUT/cluster_exchange.log" 2>&1
+/tmp/split_bf16_layer > "$OUT/split_bf16_layer.log" 2>&1
 rocm-smi --showclocks --showpower --showmaxpower > "$OUT/rocm_smi_idle.log" 2>&1
 tail -n 40 "$OUT/mfma_sustain.log"
