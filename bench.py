@@ -419,9 +419,9 @@ def main():
         stats = st if stats is None else {k: stats[k] + st[k] for k in st}
 
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see file
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))   # newest round's PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+    tpath = cands[-1] if cands else os.path.join(ROOT, 'profiles', 'r02_traffic.json')
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath))['bytes_per_launch']

@@ -7,10 +7,13 @@ cp $F/bench.json $P/${R}_bench.json
 cp $F/kernel_stats.md $P/${R}_kernel_stats.md
 for k in fetch write mfma l2; do cp $F/pmc_$k.md $P/${R}_pmc_$k.md; done
 cp $F/steps_c3.md $P/${R}_steps_c3.md
+for k in c2 c1 137_100 137_100_nosticky; do [ -f $F/steps_$k.md ] && cp $F/steps_$k.md $P/${R}_steps_$k.md; done
+[ -f $F/batch_round.log ] && cp $F/batch_round.log $P/${R}_batch_round.log
+[ -f $F/extra_c3_f2.json ] && cp $F/extra_c3_f2.json $P/${R}_extra_c3_f2.json
 cp $F/dense.log $P/${R}_dense.log
 for e in c3_reference_loss c5_n1 c2_256 c1_64 c3_recursive c3_trivial; do cp $F/extra_$e.json $P/${R}_extra_$e.json; done
 grep -v amdgpu.ids $F/loop.log > $P/${R}_single_view_loop.log
-grep "^[0-9]*x[0-9]*, 8 view pairs" $F/multiview.log > $P/${R}_multiview_round.log
+grep "^[0-9]*x[0-9]*, 8 view pairs" $F/multiview.log > $P/${R}_multiview_round.log || true
 cp $F/grid256.log $P/${R}_grid256.log
 cp $F/view_balance.md $P/${R}_view_balance.md
 [ -f $F/plan_check.md ] && cp $F/plan_check.md $P/${R}_plan_check_n8.md

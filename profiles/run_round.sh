@@ -4,7 +4,8 @@
 #   bench.json           default `python bench.py` (C3, 20 steps, cpu baselines)
 #   kernel_stats.md      rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu-baseline`, condensed by summarize.py
 #   pmc_fetch / pmc_write / pmc_mfma .md   separate rocprofv3 --pmc passes of the same command (never combined with tracing domains)
-#   steps_c3.md          per-launch table of one forward (tests/gpu_diag_steps.py)
+#   steps_c3.md (+ steps_c2 / _c1 / _137_100[_nosticky])   per-launch table of one forward (tests/gpu_diag_steps.py)
+#   batch_round.log      phases, evaluations and march roofline of one batched multi-view round (tests/gpu_diag_batch.py)
 #   dense.log            dense decoder rate + in-kernel phase stamps (tests/gpu_diag_dense.py)
 #   extra_*.json         other configurations through the same bench.py
 # Usage: bash profiles/run_round.sh gpurun_out/r02_final
@@ -14,6 +15,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python tests/gpu_diag_steps.py --out "$OUT/steps_c3.md" > /dev/null 2>&1
+python tests/gpu_diag_steps.py --size 256 --march-step 50 --out "$OUT/steps_c2.md" > /dev/null 2>&1
+python tests/gpu_diag_steps.py --size 64 --march-step 20 --out "$OUT/steps_c1.md" > /dev/null 2>&1
+python tests/gpu_diag_steps.py --size 137 --march-step 100 --out "$OUT/steps_137_100.md" > /dev/null 2>&1
+DISTR_STICKY=0 python tests/gpu_diag_steps.py --size 137 --march-step 100 --out "$OUT/steps_137_100_nosticky.md" > /dev/null 2>&1
 python tests/gpu_diag_dense.py --stamps 2>&1 | grep -v amdgpu.ids > "$OUT/dense.log"
 CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 R=$(pwd)
@@ -30,8 +35,10 @@ python bench.py --size 256 --no-cpu-baseline > "$OUT/extra_c2_256.json" 2>/dev/n
 python bench.py --size 64 --march-step 20 --no-cpu-baseline > "$OUT/extra_c1_64.json" 2>/dev/null
 python bench.py --marcher recursive --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/extra_c3_recursive.json" 2>/dev/null
 python bench.py --marcher trivial --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/extra_c3_trivial.json" 2>/dev/null
+python bench.py --fixture f2 --no-cpu-baseline > "$OUT/extra_c3_f2.json" 2>/dev/null
 python tests/gpu_diag_loop.py 64 137 224 > "$OUT/loop.log" 2>&1
 python tests/gpu_diag_multiview.py > "$OUT/multiview.log" 2>&1
+python tests/gpu_diag_batch.py 137 8 recursive 2>&1 | grep -v "amdgpu.ids\|Warning\|warn\|Consider\|return Variable" > "$OUT/batch_round.log"
 python tests/gpu_diag_grid.py > "$OUT/grid256.log" 2>&1
 # cost of each of the eight C4 views on one GPU -> the row-band plan bench.py --gpus 8 would derive from them (view_balance.md)
 for V in 0 1 2 3 4 5 6 7; do
