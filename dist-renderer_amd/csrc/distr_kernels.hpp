@@ -731,8 +731,9 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, D
 // every member computes lin8 and mirrors the depth update and the live test itself (identical arithmetic, nothing to
 // broadcast); only the lead member writes to memory. Finished rays stay in the tile as dead lanes; the tile ends when none is
 // live. A ray's arithmetic is exactly the per-step one (same points, same k-ordered chains) -> bit-identical outputs. The step
-// launches the host still issues find empty live lists and exit in a few microseconds. If a barrier times out (compute units
-// taken by another stream) the lead member finishes the tile alone on the single-workgroup path, like a non-sticky cluster tile.
+// launches the host still issues find empty live lists and exit in a few microseconds. A tile whose cluster does not assemble
+// (compute units held by another stream) is evaluated by its lead member alone and hands its rays back to the next step's live
+// list; if a barrier times out later, the lead member finishes the tile alone on the single-workgroup path.
 template <bool KEEP>
 __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, const View& V,
                                               int tile, int member, int64_t base, int64_t count) {
@@ -834,6 +835,13 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         if (a < minabs) minabs = a;
         m = mn;
         stay = (za < maxbound) && (a >= V.cfg.threshold);
+      }
+      if (solo && k == 0) {
+        // the cluster never assembled (its compute units are held by another stream / rank): this tile does NOT turn sticky -- the
+        // lead member evaluated the step alone and hands the surviving rays to the next step's live list like a per-step tile
+        // (marching 16 rays to the end on ONE compute unit would cost twice a cluster step, every step)
+        wave_append(tid < TILE && stay, id, live_sel(V, step + 1), &V.C->cnt_live[step + 1]);
+        stay = false;
       }
       live = stay;
       const unsigned long long now = __ballot(tid < TILE && live);
