@@ -125,15 +125,27 @@ def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images
                 sim3_scale = torch.norm(rot) / np.sqrt(3)
             pairs = [pair_indices(idx, i, rot_freq, sep_dist, num_images) for i in range(num_views_per_round)]
             mine = pairs[rank::world]                  # view-parallel: this rank's share of the round (all of it when world == 1)
-            if mine:
-                loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, mine, weight_list, sim3=sim_mtrx,
-                                                         sim3_scale=sim3_scale, visualizer=visualizer, pool=pool, batched=batched)
-                loss_total.backward()
-            else:
-                loss_total = torch.zeros((), device=shape_code.device)
-            if world > 1:                              # ONE collective per step: [g_shape_code | g_sim3 | loss]
+            err = None
+            loss_total = torch.zeros((), device=shape_code.device)
+            try:
+                if mine:
+                    loss_total, loss_pack = multi_view_round(renderer, shape_code, images, cameras, mine, weight_list, sim3=sim_mtrx,
+                                                             sim3_scale=sim3_scale, visualizer=visualizer, pool=pool, batched=batched)
+                    loss_total.backward()
+            except Exception as e:                     # noqa: BLE001 -- reported to every rank through the step's collective
+                if world == 1:
+                    raise
+                err = e
+            if world > 1:                              # ONE collective per step: [g_shape_code | g_sim3 | loss | pack of the last pair | error flag]
                 sim_params = [sim3[k] for k in ('rot', 'scale', 'trans')] if sim3 is not None else []
-                loss_total, = parallel.allreduce_grads([shape_code] + sim_params, [loss_total])
+                # the loss pack the reference prints / plots is the one of the round's LAST pair (optimize_multi.py:76-79): its owner
+                # contributes the two scalars, everybody else zeros, so every rank ends up with the serial loop's values
+                owner = (len(pairs) - 1) % world
+                mine_last = err is None and rank == owner and loss_pack is not None
+                pk = [loss_pack['color'].t if mine_last else 0.0, loss_pack['l2reg'].t if mine_last else 0.0]
+                loss_total, pc, pl = parallel.allreduce_grads([shape_code] + sim_params, [loss_total] + pk, error=err)
+                from .loss_multi import _LazyScalar
+                loss_pack = {'color': _LazyScalar(pc), 'l2reg': _LazyScalar(pl)}
             shape_optimizer.step()
             if on_round is not None:
                 on_round(epoch, idx, loss_total.detach(), loss_pack)

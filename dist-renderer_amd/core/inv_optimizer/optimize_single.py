@@ -57,30 +57,36 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
         optimizer.zero_grad()
         extrinsics = camera_tensor if optimizer_type == 'shape' else get_camera_from_tensor(camera_tensor)
         loss = 0
-        for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights)):
-            if idx % world != rank:          # renderer-parallel: another rank renders this scale
-                continue
-            # only the first (full-resolution) renderer of a multi-scale list feeds the visualiser (optimize_single.py:63-74)
-            pack, vis_out = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(),
-                                             profile=profile, visualizer=visualizer if idx == 0 else None,
-                                             ray_marching_type=ray_marching_type, grad_settings=dict(grad_settings))
-            if idx == 0:
-                visualizer = vis_out
-                if not silent:
-                    print_loss_pack(pack, '{0}/s224'.format(i))
-                if visualize:
-                    visualizer.show_loss_curve(os.path.join(vis_folder, 'vis_loss_curve_{}.png'.format(i)))
-                    visualizer.show_all_data(os.path.join(vis_folder, 'vis_all_data_{}.png'.format(i)))
-            loss = loss + rw * (weight_dict['w_depth'] * pack['depth'] + weight_dict['w_normal'] * pack['normal'] +
-                                weight_dict['w_mask_gt'] * pack['mask_gt'] + weight_dict['w_mask_out'] * pack['mask_out'] +
-                                weight_dict['w_l2reg'] * pack['l2reg'])
-            if on_iteration is not None and idx == 0:
-                on_iteration(i, pack, loss)
-        if torch.is_tensor(loss):
-            loss.backward()
-        if world > 1:                        # ONE collective per step: [gradient of the optimised tensor | loss]
+        err = None
+        try:
+            for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights)):
+                if idx % world != rank:          # renderer-parallel: another rank renders this scale
+                    continue
+                # only the first (full-resolution) renderer of a multi-scale list feeds the visualiser (optimize_single.py:63-74)
+                pack, vis_out = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(),
+                                                 profile=profile, visualizer=visualizer if idx == 0 else None,
+                                                 ray_marching_type=ray_marching_type, grad_settings=dict(grad_settings))
+                if idx == 0:
+                    visualizer = vis_out
+                    if not silent:
+                        print_loss_pack(pack, '{0}/s224'.format(i))
+                    if visualize:
+                        visualizer.show_loss_curve(os.path.join(vis_folder, 'vis_loss_curve_{}.png'.format(i)))
+                        visualizer.show_all_data(os.path.join(vis_folder, 'vis_all_data_{}.png'.format(i)))
+                loss = loss + rw * (weight_dict['w_depth'] * pack['depth'] + weight_dict['w_normal'] * pack['normal'] +
+                                    weight_dict['w_mask_gt'] * pack['mask_gt'] + weight_dict['w_mask_out'] * pack['mask_out'] +
+                                    weight_dict['w_l2reg'] * pack['l2reg'])
+                if on_iteration is not None and idx == 0:
+                    on_iteration(i, pack, loss)
+            if torch.is_tensor(loss):
+                loss.backward()
+        except Exception as e:               # noqa: BLE001 -- reported to every rank through the step's collective
+            if world == 1:
+                raise
+            err = e
+        if world > 1:                        # ONE collective per step: [gradient of the optimised tensor | loss | error flag]
             target = shape_code if optimizer_type == 'shape' else camera_tensor
-            loss, = parallel.allreduce_grads([target], [loss if torch.is_tensor(loss) else torch.zeros((), device=target.device)])
+            loss, = parallel.allreduce_grads([target], [loss if torch.is_tensor(loss) else torch.zeros((), device=target.device)], error=err)
         if visualize:
             visualizer.add_loss(loss)
         optimizer.step()

@@ -14,7 +14,10 @@ from . import binding, decoder_pack
 
 
 def _param_key(module):
-    """Identity + in-place version of every parameter: changes after load_state_dict / an optimiser step / .to()."""
+    """Identity + in-place version of every parameter: changes after load_state_dict / an optimiser step / .to().
+    NOT seen: edits through `.data` (`p.data.copy_()`, `p.data.mul_()`, EMA-style updates) -- they do not bump `_version`. Code
+    that edits decoder weights that way must call `get_engine(decoder, dev).refresh(decoder)` itself (a content checksum per
+    render would cost a device reduction and a host sync in the hot path)."""
     return tuple((p.data_ptr(), p._version) for p in module.parameters())
 
 
@@ -33,10 +36,13 @@ class DecoderEngine(object):
         self._key = None
         self.refresh(decoder)
 
+    generation = 0     # number of weight uploads so far: a forward remembers it, its backward refuses to run on newer weights
+
     def refresh(self, decoder):
         """(Re)uploads the weights."""
         self.ctx.set_decoder(decoder_pack.pack_module(decoder))
         self._key = _param_key(decoder)
+        self.generation += 1
 
     def sync(self, decoder):
         """The reference reads the live module on every call (decoder_utils.py:53-74); the packed copy follows it: re-packed
@@ -161,6 +167,15 @@ def _f32c(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _check_generation(ctx):
+    """A backward must run on the decoder weights its forward used: the saved ReLU masks (and every selected row) belong to THAT
+    evaluation. Rendering A, updating the decoder, rendering B, then back-propagating A would silently mix new weights with old
+    masks -- refuse instead."""
+    if getattr(ctx.engine, 'generation', 0) != ctx.generation:
+        raise RuntimeError('the decoder weights were re-uploaded (load_state_dict / optimiser step / refresh) between this render\'s '
+                           'forward and its backward; back-propagate before changing the decoder, or render again')
+
+
 class RenderFunction(torch.autograd.Function):
     """(latent, R, T) -> (zdepth[P], mask[P] uint8, min_sdf[P], depth[H,W], normal[H,W,3])"""
 
@@ -189,6 +204,7 @@ class RenderFunction(torch.autograd.Function):
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None,
             p(ws), ws.numel(), engine.ctx.stream()))
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes = engine, cfg, ws, bwd_bytes
+        ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)
         ctx.in_meta = tuple((t.device, t.dtype) for t in (latent, R, T))
         ctx.mark_non_differentiable(mask)
@@ -197,6 +213,7 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zdepth, g_mask, g_min_sdf, g_depth, g_normal):
         engine, cfg, ws = ctx.engine, ctx.cfg, ctx.ws
+        _check_generation(ctx)
         dev = engine.device
 
         def prep(g, n):
@@ -262,6 +279,7 @@ class RenderBatchFunction(torch.autograd.Function):
             engine.ctx.h, C.byref(cfg), B, flags, p(lat), 0 if shared else 256, p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None, p(ws), ws.numel(), engine.ctx.stream()))
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes, ctx.B, ctx.shared = engine, cfg, ws, bwd_bytes, B, shared
+        ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)
         ctx.in_meta = tuple((t.device, t.dtype) for t in (latent, R, T))
         ctx.view_bytes = fwd_bytes
@@ -271,6 +289,7 @@ class RenderBatchFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_zdepth, g_mask, g_min_sdf, g_depth, g_normal):
         engine, cfg, ws, B = ctx.engine, ctx.cfg, ctx.ws, ctx.B
+        _check_generation(ctx)
         dev = engine.device
 
         def prep(g, n):

@@ -65,32 +65,67 @@ def rank_world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def allreduce_grads(params, scalars=(), group=None):
+class RemoteRankError(RuntimeError):
+    """Another rank failed inside this step (it reported so through the step's all-reduce): every rank leaves the step together."""
+
+
+def _reduction_device(group, params):
+    """Device the packed buffer must live on: the current HIP device for RCCL ('nccl' only moves device memory), else wherever the
+    first parameter lives (gloo takes host or device tensors)."""
+    if dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return params[0].device if params else torch.device('cpu')
+
+
+def allreduce_grads(params, scalars=(), group=None, error=None):
     """The one collective of an optimisation step: the gradients of `params` (shape code, sim(3) parameters, camera
-    tensor ...) and the detached loss `scalars` are packed into ONE flat f32 buffer [g_latent | g_sim3 / g_cam | loss ...] and summed
-    over the ranks with a single all-reduce (RCCL on GPUs, gloo on CPU); every rank then holds identical gradients and applies the
-    identical optimiser step -- no parameter broadcast. A parameter whose .grad is None on this rank (it rendered nothing that
-    depends on it) contributes zeros and receives the sum. Returns the reduced scalars as a list of 0-d tensors."""
+    tensor ...) and the detached loss `scalars` are packed into ONE flat buffer [g_latent | g_sim3 / g_cam | loss ... | error flag]
+    and summed over the ranks with a single all-reduce (RCCL on GPUs, gloo on CPU); every rank then holds identical gradients and
+    applies the identical optimiser step -- no parameter broadcast. A parameter whose .grad is None on this rank (it rendered nothing
+    that depends on it) contributes zeros and receives the sum. Parameters may live on different devices (a host-resident camera
+    tensor next to a CUDA shape code) and in different float types: every piece is moved to the reduction device for the
+    collective and copied back in its own device / dtype (the buffer is f64 as soon as one piece is, so f64 gradients are not rounded
+    through f32). `error`: an exception this rank caught while computing its share of the step (or None). The flag travels in the
+    same buffer, so a failure on one rank does not leave the others waiting in a collective: the failing rank re-raises its own
+    exception after the all-reduce, every other rank raises RemoteRankError. Returns the reduced scalars as 0-d tensors."""
     params = [p for p in params if p is not None]
     if not is_distributed(group):
+        if error is not None:
+            raise error
         return [s.detach() if torch.is_tensor(s) else torch.tensor(float(s)) for s in scalars]
-    dev = params[0].device if params else torch.device('cpu')
-    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-    sc = [(s.detach().to(dev, torch.float32).reshape(1) if torch.is_tensor(s) else torch.tensor([float(s)], dtype=torch.float32, device=dev))
-          for s in scalars]
-    flat = torch.cat([g.detach().reshape(-1).to(torch.float32) for g in grads] + sc) if (grads or sc) else torch.zeros(0, device=dev)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    off = 0
+    dev = _reduction_device(group, params)
+    grads = [p.grad if p.grad is not None else None for p in params]
+    wide = any((g if g is not None else p).dtype == torch.float64 for g, p in zip(grads, params)) or \
+        any(torch.is_tensor(s) and s.dtype == torch.float64 for s in scalars)
+    dt = torch.float64 if wide else torch.float32
+    pieces = []
     for p, g in zip(params, grads):
-        n = g.numel()
-        red = flat[off:off + n].reshape(g.shape).to(g.dtype)
+        pieces.append(torch.zeros(p.numel(), dtype=dt, device=dev) if (g is None or error is not None)
+                      else g.detach().reshape(-1).to(device=dev, dtype=dt))
+    for s_ in scalars:
+        if error is not None:
+            pieces.append(torch.zeros(1, dtype=dt, device=dev))
+        else:
+            pieces.append(s_.detach().reshape(1).to(device=dev, dtype=dt) if torch.is_tensor(s_) else torch.tensor([float(s_)], dtype=dt, device=dev))
+    pieces.append(torch.tensor([0.0 if error is None else 1.0], dtype=dt, device=dev))
+    flat = torch.cat(pieces)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    failed = float(flat[-1]) > 0.0
+    if error is not None:
+        raise error
+    if failed:
+        raise RemoteRankError('%d rank(s) failed inside this step; leaving the step on every rank' % int(round(float(flat[-1]))))
+    off = 0
+    for p in params:
+        n = p.numel()
+        red = flat[off:off + n].reshape(p.shape).to(device=p.device, dtype=(p.grad.dtype if p.grad is not None else p.dtype))
         if p.grad is None:
             p.grad = red.clone()
         else:
             p.grad.copy_(red)
         off += n
     out = []
-    for _ in sc:
+    for _ in scalars:
         out.append(flat[off].clone())
         off += 1
     return out

@@ -149,7 +149,8 @@ def _g9_first_round(distributed):
 
     def on_round(epoch, idx, loss, pack):
         if not got:
-            got.append([float(loss)] + [t.grad.detach().clone().numpy() for t in (lat, sim3['rot'], sim3['scale'], sim3['trans'])])
+            got.append([float(loss)] + [t.grad.detach().clone().numpy() for t in (lat, sim3['rot'], sim3['scale'], sim3['trans'])] +
+                       [np.array([float(pack['color']), float(pack['l2reg'])])])
     optimize_multi_view(r, None, lat, opt, [torch.from_numpy(i) for i in g['images']], [_GCam(e) for e in g['extrinsics']],
                         {'color': float(g['w_color']), 'l2reg': float(g['w_l2reg'])}, num_views_per_round=2, num_iters=1, sep_dist=1, sim3=sim3,
                         sim3_init=torch.cat([torch.eye(3), torch.zeros(3, 1)], 1), streams=0, on_round=on_round, distributed=distributed)
@@ -204,13 +205,62 @@ def test_product_optimisation_loops_distributed_gloo():
         assert p.exitcode == 0
     # serial run of the shipped loop vs the reference's golden round
     assert abs(serial[0] - float(g['loss_total'])) <= 2e-4 * abs(float(g['loss_total']))
-    for a, name in zip(serial[1:], ('g_latent', 'g_rot', 'g_scale', 'g_trans')):
+    for a, name in zip(serial[1:5], ('g_latent', 'g_rot', 'g_scale', 'g_trans')):
         rel = np.abs(a - g[name]).max() / np.abs(g[name]).max()
         assert rel <= 1e-2, (name, rel)
+    # the loss pack handed to on_round / printed per epoch is the one of the round's LAST pair on every rank (it was rank
+    # 0's last LOCAL pair); serial[5] = [color, l2reg] of the serial loop = the reference's packs[-1]
+    assert abs(serial[5][0] - g['packs'][-1, 0]) <= 1e-4
     for rank, r in res:
-        if isinstance(r, list):            # round gradients of a rank
+        if isinstance(r, list):            # round gradients of a rank (+ the loss pack of the round's last pair)
             assert abs(r[0] - serial[0]) <= 1e-5 * abs(serial[0]), rank
             for a, b in zip(r[1:], serial[1:]):
                 assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), rank
         else:                              # final shape code of the multi-scale single-view loop
             assert np.abs(r - final_serial).max() <= 1e-6, rank
+
+
+def _error_worker(rank, world, port, q):
+    for p in (PKG, ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from distr import parallel
+    parallel.init_from_env(backend='gloo')
+    # (1) mixed float types: an f64 camera tensor next to an f32 shape code; a parameter without a gradient on this rank
+    a = torch.zeros(4, dtype=torch.float32, requires_grad=True)
+    b = torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    a.grad = torch.full((4,), 1.0 + rank)
+    if rank == 0:
+        b.grad = torch.tensor([1.0 + 2.0 ** -40, 2.0, 3.0], dtype=torch.float64)        # needs more than 24 bits
+    loss, = parallel.allreduce_grads([a, b], [torch.tensor(0.5 + rank)])
+    ok = bool((a.grad == 3.0).all()) and a.grad.dtype == torch.float32 and b.grad.dtype == torch.float64 and \
+        float(b.grad[0]) == 1.0 + 2.0 ** -40 and float(loss) == 2.0
+    # (2) a failure on ONE rank inside the step: nobody hangs, the failing rank re-raises its own exception, the other one a RemoteRankError
+    kind = 'none'
+    try:
+        err = ValueError('rank 1 broke') if rank == 1 else None
+        parallel.allreduce_grads([a], [torch.tensor(1.0)], error=err)
+    except ValueError:
+        kind = 'own'
+    except parallel.RemoteRankError:
+        kind = 'remote'
+    parallel.barrier()                       # the group is still usable afterwards
+    q.put((rank, ok, kind))
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_mixed_types_and_error_flag_gloo():
+    """allreduce_grads with parameters of different float types (f64 not rounded through f32), a parameter without a
+    local gradient, and the error flag that makes all ranks leave a step together when one of them failed."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_error_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (ok, kind)) for r, ok, kind in [q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == (True, 'remote') and res[1] == (True, 'own'), res

@@ -1463,3 +1463,28 @@ def test_plain_c_program_renders(engine, fixture_decoder, tmp_path):
     ref = np.concatenate([x.cpu().numpy().reshape(-1) for x in (z, q, d, nm, gl, gR, gT)])
     assert out.tobytes() == ref.tobytes() and mask.tobytes() == m.cpu().numpy().tobytes()
     assert int(mask.sum()) > 100 and np.abs(out[6 * P:6 * P + 256]).max() > 0
+
+
+@pytest.mark.gpu
+def test_backward_refuses_re_uploaded_decoder(fixture_decoder):
+    """render A, change the decoder (the packed copy is re-uploaded on the next call), render B, back-propagate A -- A's
+    saved ReLU masks belong to the OLD weights; the backward must refuse instead of mixing them with the new ones."""
+    import torch
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.sdfrenderer import SDFRenderer
+    from distr import fixture
+    Ws, bs, latent = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W), ('bias', b))})
+    H = W = 32
+    r = SDFRenderer(dec.cuda(), fixture.make_intrinsic(H, W), img_hw=(H, W), march_step=16, buffer_size=2)
+    R, T = (torch.from_numpy(a).cuda() for a in fixture.make_camera(10, 10, 1.6, 0))
+    lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+    dA = r.render(lat, R, T)[0]
+    with torch.no_grad():
+        dec.lin8.bias.add_(1e-3)                       # in-place edit: bumps _version -> re-upload on the next render
+    dB = r.render(lat, R, T)[0]
+    with pytest.raises(RuntimeError, match='re-uploaded'):
+        dA[dA < 1e5].sum().backward()
+    dB[dB < 1e5].sum().backward()                      # the current render back-propagates fine
+    assert lat.grad is not None and float(lat.grad.abs().max()) > 0
