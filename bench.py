@@ -101,7 +101,7 @@ def host_description():
     return {'cpu_model': model, 'nproc': os.cpu_count()}
 
 
-def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=25.0):
+def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=70.0):
     """BASELINE.md section 3, baseline (2): the build's own PyTorch-CPU restatement (oracle/torch_restatement.py: batched ATen ops, one
     decoder evaluation per march step over the live rays, autograd backward -- how the reference itself executes) on the host's cores.
     Config C1 (64x64, 20 steps: BASELINE.json configs[0], 'PyTorch CPU reference path') plus the largest power-of-two size of the bench
@@ -133,6 +133,7 @@ def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=25
         size *= 2
     return {'value': size * size / t, 'unit': 'rays/s', 'cores': int(th.get_num_threads()), 'kind': 'port',
             'sample': 'PyTorch-CPU restatement, %dx%d image of view 0, %d steps, %s, fwd+bwd, %.1f s wall' % (size, size, march_step, marcher, t),
+            'image_size': size, 'same_size_as_value': bool(size == H),      # (smaller than the bench image only when the time budget ran out)
             'c1_64x64_20steps': {'rays_per_s': 64 * 64 / t_c1, 'seconds': t_c1}}
 
 
@@ -166,7 +167,10 @@ def main():
                     help='dense (default): seeded per-pixel weights on depth, normal and min-sdf of EVERY pixel (the loss of the golden '
                          'vectors; the heaviest backward: every in-sphere ray carries a gradient sample); reference: the single-view '
                          'loss of run_single_shape.py:93-98 against a ground truth rendered once from a perturbed latent')
-    ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU (c5 at N <= 4)')
+    ap.add_argument('--streams', type=int, default=4, help='HIP streams for several work items on one GPU that cannot share a batch (row bands)')
+    ap.add_argument('--no-batch', action='store_true',
+                    help='several whole images on one GPU (c5 at N <= 2: a batch of shapes): render them one by one on the stream pool instead '
+                         'of as ONE batched launch sequence (distr_render_forward_batch)')
     ap.add_argument('--items', default=None,
                     help='diagnostics (N = 1, c3): the work items of the step as view:r0:r1[,view:r0:r1...] instead of one whole view, e.g. '
                          '"5:0:512,7:480:512" = what rank 5 renders under the N = 8 balance plan (profiles/r02_view_balance.md)')
@@ -286,8 +290,23 @@ def main():
         for (Rt, Tt) in cams.values():
             Rt.grad = None
             Tt.grad = None
-        losses = [pool.run(i, lambda it=it: render_item(*it)) for i, it in enumerate(items)]
-        pool.join(losses)
+        whole = [it for it in items if (it[2], it[3]) == (0, H)]
+        if len(whole) >= 2 and not args.no_batch:
+            # a batch of whole images (C5: a batch of shapes): every march step is ONE launch over the live rays of all of them
+            # (each image with its own shape code and camera; values identical to rendering them one by one)
+            outs = functions.render_batch_call(eng, cfg, torch.cat([lats[it[0]] for it in whole], 0), torch.stack([cams[it[1]][0] for it in whole]),
+                                               torch.stack([cams[it[1]][1] for it in whole]))
+            losses = []
+            for b, it in enumerate(whole):
+                last_mask[it[1]] = outs[1][b]
+                losses.append(image_loss(tuple(o[b] for o in outs), 0, H, (it[0], it[1])))
+            rest = [it for it in items if (it[2], it[3]) != (0, H)]
+            more = [pool.run(i, lambda it=it: render_item(*it)) for i, it in enumerate(rest)]
+            pool.join(more)
+            losses += more
+        else:
+            losses = [pool.run(i, lambda it=it: render_item(*it)) for i, it in enumerate(items)]
+            pool.join(losses)
         total = losses[0]
         for L in losses[1:]:
             total = total + L
@@ -443,7 +462,7 @@ def main():
                                    '%s loss, fwd+loss+bwd, %s' % ('C5: 4 shapes x ' if c5 else ('C3: ' if (H, MARCH_STEP) == (512, 50) else ''), H, W, MARCH_STEP,
                                                          args.marcher, BUFFER_SIZE, RATIO,
                                                          'dense per-pixel' if args.loss == 'dense' else 'reference single-view',
-                                                         'fixed total work split shape-major then in row bands' if c5 else
+                                                         ('fixed total work split shape-major then in row bands' + (', whole images of a rank as one batched launch sequence' if not args.no_batch else '')) if c5 else
                                                          ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
                                                           'ranks' if plan else '1 view per GPU')),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
