@@ -24,17 +24,18 @@ def get_samples(N, voxel_origin=(-1.0, -1.0, -1.0), voxel_size=None, transform=F
     return pts
 
 
-def infer_samples(decoder, latent_vec, samples, max_batch=None):
+def infer_samples(decoder, latent_vec, samples, max_batch=None, arith='f32'):
     """SDF (clamped to +-0.1 like decode_sdf's default) of (M,3|4) samples -> (M,). One kernel launch; `max_batch` is
-    accepted for signature compatibility and ignored."""
+    accepted for signature compatibility and ignored. arith='bf16x6': the split-bf16 decoder tile (values within ~1e-6 of the
+    exact ones: marching cubes cannot tell, the evaluation is faster)."""
     with torch.no_grad():
-        return decode_sdf(decoder, latent_vec, samples[:, :3].contiguous(), no_grad=True).reshape(-1)
+        return decode_sdf(decoder, latent_vec, samples[:, :3].contiguous(), no_grad=True, arith=arith).reshape(-1)
 
 
-def create_sdf_grid(decoder, latent_vec, N=256, transform=False):
+def create_sdf_grid(decoder, latent_vec, N=256, transform=False, arith='f32'):
     """(N,N,N) SDF grid on [-1,1]^3 (the tensor create_mesh hands to marching cubes, create_mesh.py:56-68)."""
     dev = next(decoder.parameters()).device
-    return infer_samples(decoder, latent_vec, get_samples(N, transform=transform, device=dev)).reshape(N, N, N)
+    return infer_samples(decoder, latent_vec, get_samples(N, transform=transform, device=dev), arith=arith).reshape(N, N, N)
 
 
 def create_sdf_grid_speedup(decoder, latent_vec, N=256, transform=False, relaxation=1.5):

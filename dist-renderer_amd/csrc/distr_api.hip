@@ -14,6 +14,7 @@
 
 #include "distr_kernels.hpp"
 #include "distr_losses.hpp"
+#include "distr_mlp_b6.hpp"
 
 using namespace distr;
 
@@ -27,6 +28,8 @@ struct distr_ctx {
   bool has_color = false;
   DecoderDev D{};
   DecoderDev16 D16{};
+  DecoderB6 B6{};                   // split-bf16 weight planes of the shape decoder (distr_mlp_eval_bf16x6), own allocation
+  uint32_t* dec_buf_b6 = nullptr;
   bool has_decoder = false;
   bool profiling = false;
   int hybrid_threshold = 8192;  // t32: largest remainder of a march step (rays) that runs on 32-ray tiles (fine_split)
@@ -109,6 +112,43 @@ void pack_fragments16(const float* W, int K, int O, float* dst) {
           const int o = w * 16 * NB + 16 * ob + (lane & 15), kq = lane >> 4;
           float* d = dst + ((((size_t)g * 4 + w) * NB + ob) * 64 + lane) * 4;
           for (int s = 0; s < 4; ++s) d[s] = W[(size_t)o * K + 16 * g + 4 * s + kq];
+        }
+}
+
+// bf16 (round to nearest even) of an f32, as its upper 16 bits
+inline uint16_t to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float from_bf16(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Split-bf16 A-fragment planes of v_mfma_f32_32x32x16_bf16 (distr_mlp_b6.hpp::dense_b6): W = w0 + w1 + w2 with w0 = bf16(W),
+// w1 = bf16(W - w0), w2 = bf16(W - w0 - w1); fragment index (((kb * 4 + wave) * NOB + ob) * 3 + plane) * 64 + lane holds the 8 bf16
+// W_plane[o][16 kb + 8 h + 0..7], o = wave * 32 NOB + 32 ob + (lane & 31), h = lane >> 5.
+void pack_fragments_b6(const float* W, int K, int O, uint16_t* dst) {
+  const int NOB = O / 128, NKB = K / 16;
+  for (int kb = 0; kb < NKB; ++kb)
+    for (int w = 0; w < 4; ++w)
+      for (int ob = 0; ob < NOB; ++ob)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int o = w * 32 * NOB + 32 * ob + (lane & 31), h = lane >> 5;
+          for (int i = 0; i < 8; ++i) {
+            const float v = W[(size_t)o * K + 16 * kb + 8 * h + i];
+            const uint16_t p0 = to_bf16(v);
+            const float r1 = v - from_bf16(p0);
+            const uint16_t p1 = to_bf16(r1);
+            const uint16_t p2 = to_bf16(r1 - from_bf16(p1));
+            const uint16_t pl[3] = {p0, p1, p2};
+            for (int p = 0; p < 3; ++p)
+              dst[((((((size_t)kb * 4 + w) * NOB + ob) * 3 + p) * 64 + lane) * 8) + i] = pl[p];
+          }
         }
 }
 
@@ -353,6 +393,7 @@ void distr_destroy(distr_ctx* ctx) {
   if (!ctx) return;
   if (ctx->dec_buf) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf); }
   if (ctx->dec_buf_color) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_color); }
+  if (ctx->dec_buf_b6) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_b6); }
   for (auto& r : ctx->xr) { if (r.buf) (void)hipFree(r.buf); if (r.flags) (void)hipFree(r.flags); }
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete ctx;
@@ -363,7 +404,7 @@ const char* distr_last_error(const distr_ctx* ctx) { return ctx ? ctx->err.c_str
 // Packs one DeepSDF-8x512-shaped decoder for the tile kernels. nlat = latent length (the latent columns of lin0 / lin4 are
 // folded into per-call constants, so the tile itself never sees them); nout = rows of lin8 (1: SDF, 3: colour).
 static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, size_t n_floats, float** dev_buf, DecoderDev& D,
-                         DecoderDev16* D16) {
+                         DecoderDev16* D16, DecoderB6* B6 = nullptr, uint32_t** dev_buf_b6 = nullptr) {
   const int in0 = nlat + 3, in4 = 256 + nlat;
   const int OUT[9] = {512, 512, 512, 253, 512, 512, 512, 512, nout};
   const int IN[9] = {in0, 512, 512, 512, in4, 512, 512, 512, 512};
@@ -436,6 +477,20 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   D.b8x[0] = nout > 1 ? b[8][1] : 0.f; D.b8x[1] = nout > 2 ? b[8][2] : 0.f;
   D.nlat = nlat;
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
+  if (B6) {   // split-bf16 planes of lin1..lin7 for the opt-in arithmetic mode (distr_mlp_eval_bf16x6): 9.4 MB, own allocation
+    std::vector<uint16_t> hb;
+    size_t offb[8] = {0};
+    for (int l = 1; l < 8; ++l) {
+      offb[l] = (hb.size() + 127) & ~(size_t)127;
+      hb.resize(offb[l] + Wp[l].size() * 3, 0);
+      pack_fragments_b6(Wp[l].data(), Kp[l], Op[l], hb.data() + offb[l]);
+    }
+    if (*dev_buf_b6) { HIP_TRY(hipFree(*dev_buf_b6)); *dev_buf_b6 = nullptr; }
+    HIP_TRY(hipMalloc((void**)dev_buf_b6, hb.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(*dev_buf_b6, hb.data(), hb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    B6->Wp[0] = nullptr;
+    for (int l = 1; l < 8; ++l) B6->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offb[l]);
+  }
   return DISTR_OK;
 }
 
@@ -445,7 +500,7 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
   if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
                 "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
-  int rc = build_decoder(ctx, LAT, 1, w, n_floats, &ctx->dec_buf, ctx->D, &ctx->D16);
+  int rc = build_decoder(ctx, LAT, 1, w, n_floats, &ctx->dec_buf, ctx->D, &ctx->D16, &ctx->B6, &ctx->dec_buf_b6);
   if (rc) return rc;
   ctx->has_decoder = true;
   return DISTR_OK;
@@ -835,6 +890,26 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent, const float* xyz, int64_
   else hipLaunchKernelGGL((k_march<MODE_EVAL, 2, false>), dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, A, ctx->D);
   timer.end();
   LAUNCH_CHECK("k_march<eval>");
+  return DISTR_OK;
+}
+
+int distr_mlp_eval_bf16x6(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float clamp, float* sdf, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (n < 0 || (n > 0 && (!xyz || !sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  if (n == 0) return DISTR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);      // (exact f32: the latent columns stay a per-call constant)
+  LAUNCH_CHECK("k_latent_consts");
+  MarchTimer timer(ctx, s);
+  timer.begin();
+  hipLaunchKernelGGL(k_eval_b6, dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, clamp, sdf, ctx->D, ctx->B6);
+  timer.end();
+  LAUNCH_CHECK("k_eval_b6");
   return DISTR_OK;
 }
 

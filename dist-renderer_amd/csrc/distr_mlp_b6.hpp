@@ -1,0 +1,225 @@
+// distr_mlp_b6.hpp -- the DeepSDF 8x512 decoder tile in SIX-PRODUCT SPLIT-bf16 arithmetic (opt-in; forward only).
+//
+// The default decoder tile (distr_mlp.hpp) computes every dense layer with f32-input MFMAs: exact f32, bit-identical to the
+// oracle's k-ordered fmaf chains, at 1/16 of the bf16 MFMA rate. This tile evaluates the same network (Decoder.inference,
+// core/graph/deep_sdf_decoder.py:80-111) with every f32 product W x replaced by six bf16 products
+//     W = w0 + w1 + w2,  x = a0 + a1 + a2   (bf16 planes, round to nearest even of the running remainder)
+//     W x ~ w0 a0 + w1 a0 + w0 a1 + w1 a1 + w2 a0 + w0 a2
+// on v_mfma_f32_32x32x16_bf16 with f32 accumulation: both operands keep 24 significant bits, the dropped terms are below 2^-24
+// relative, and one layer's error against a float64 product is no larger than the f32 chain's own (profiles/r03_split_bf16_layer.md:
+// 1.4e-7 vs 2.0e-7). It is NOT bit-identical to the oracle (different summation order inside the MFMA), so it never replaces the
+// exact path silently: callers ask for it (distr_mlp_eval_bf16x6; bulk SDF grids for meshing, core/evaluation/create_mesh.py, where
+// marching cubes is indifferent to 1e-6). Measured: see profiles/ (dense decoder, TFLOP/s-equivalent and max |delta sdf|).
+//
+// Data flow of a 64-ray tile (one workgroup = 4 waves):
+//   * activations stay f32 in LDS (128 KiB; three bf16 planes of 512 x 64 would need 192 KiB), k-MINOR: X[k >> 3][ray][k & 7], so
+//     the 8 k-values a lane feeds to one bf16 MFMA are 32 contiguous bytes; they are split into the three planes in registers
+//     while the next block's fragments load (VALU that hides in the gaps of bf16 MFMAs, unlike next to f32 MFMAs);
+//   * weights: three pre-split bf16 planes per layer, pre-packed on the host as A fragments of v_mfma_f32_32x32x16_bf16
+//     (fragment index (((kb * 4 + wave) * NOB + ob) * 3 + plane) * 64 + lane = 8 bf16 W_plane[o][16 kb + 8 h + 0..7]);
+//   * wave w owns output rows [w O/4, (w+1) O/4) as NOB x 2 accumulator tiles of 32 x 32, started from the bias (exact f32);
+//   * lin0 (K = 3) and lin8 (one row) are plain f32 VALU work, as in the exact tile.
+#pragma once
+#include "distr_mlp.hpp"
+
+namespace distr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct DecoderB6 {
+  const uint32_t* Wp[8];   // split-bf16 A-fragment planes of lin1..lin7 ([0] unused); lin3: O padded to 256; lin4: K = 256
+};
+
+struct alignas(16) SmemB6 {
+  float X[HID * 64];       // k-minor activations
+  float xyz[4 * 64];
+  float part[4 * 64];
+};
+
+__device__ __forceinline__ int xk(int k, int ray) { return ((k >> 3) * 64 + ray) * 8 + (k & 7); }
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // {bf16(a) low half, bf16(b) high half}, round to nearest even
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));      // v_cvt_pk_bf16_f32
+}
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pk_bf16(a, b);
+  const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+  p1 = pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk_bf16(sa, sb);
+}
+
+// acc[ob][rb] (started by the caller) += W[rows of this wave][0..K) x X[0..K)[64 rays], six bf16 products per f32 product
+template <int K, int NOB>
+__device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][2], int wave, int lane) {
+  constexpr int NKB = K / 16;
+  const int j = lane & 31, h = lane >> 5;
+  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)wave * NOB * 3 * 64 + lane;
+  constexpr int PW[6] = {0, 1, 0, 1, 2, 0}, PA[6] = {0, 0, 1, 1, 0, 2};     // (weight plane, activation plane) of the six products
+  u32x4 a[NOB][3], b[2][3];
+  f32x4 xr[2][2];
+  auto load_a = [&](u32x4 (&dst)[NOB][3], int kb) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * NOB + ob) * 3 + p) * 64];
+  };
+  auto load_x = [&](f32x4 (&dst)[2][2], int kb) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const f32x4* xp = reinterpret_cast<const f32x4*>(&X[xk(16 * kb + 8 * h, 32 * rb + j)]);
+      dst[rb][0] = xp[0]; dst[rb][1] = xp[1];
+    }
+  };
+  auto split = [&](const f32x4 (&src)[2][2], u32x4 (&dst)[2][3]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      uint32_t q0[4], q1[4], q2[4];
+      split_pair(src[rb][0][0], src[rb][0][1], q0[0], q1[0], q2[0]);
+      split_pair(src[rb][0][2], src[rb][0][3], q0[1], q1[1], q2[1]);
+      split_pair(src[rb][1][0], src[rb][1][1], q0[2], q1[2], q2[2]);
+      split_pair(src[rb][1][2], src[rb][1][3], q0[3], q1[3], q2[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dst[rb][0][i] = q0[i]; dst[rb][1][i] = q1[i]; dst[rb][2][i] = q2[i]; }
+    }
+  };
+  load_a(a, 0);
+  load_x(xr, 0);
+  split(xr, b);
+#pragma unroll 2
+  for (int kb = 0; kb < NKB; ++kb) {
+    // register double buffer: block kb + 1 (weights from L2, activations from LDS) is requested before the MFMAs of block kb,
+    // its split into planes sits between them (one wave per SIMD: nothing else hides the L2 round trip)
+    u32x4 an[NOB][3], bn[2][3];
+    f32x4 xn[2][2];
+    const int kn = (kb + 1 < NKB) ? kb + 1 : kb;
+    load_a(an, kn);
+    load_x(xn, kn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ob][PW[q]]), __builtin_bit_cast(bf16x8, b[rb][PA[q]]),
+                                                                acc[ob][rb], 0, 0, 0);
+      if (q == 0) split(xn, bn);
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[ob][p] = an[ob][p];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[rb][p] = bn[rb][p];
+  }
+}
+
+// ReLU + write-back into the k-minor layout: D rows of register r on lane (j, h) are (r & 3) + 8 (r >> 2) + 4 h -> 4 consecutive
+// features = one 16-byte store
+template <int NOB>
+__device__ __forceinline__ void writeback_b6(float* X, const f32x16 (&acc)[NOB][2], int row0, int lane) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __int_as_float(max(__float_as_int(acc[ob][rb][4 * q + i]), 0));
+        *reinterpret_cast<f32x4*>(&X[xk(row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v;
+      }
+}
+
+template <int K, int NOB>
+__device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const float* __restrict__ bias, int nbias, float* X, int wave, int lane) {
+  const int h = lane >> 5;
+  f32x16 acc[NOB][2];
+  const int row0 = wave * 32 * NOB;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float bv = (row < nbias) ? bias[row] : 0.f;
+      acc[ob][0][r] = bv; acc[ob][1][r] = bv;
+    }
+  dense_b6<K, NOB>(Wp, X, acc, wave, lane);
+  __syncthreads();                         // everybody is done reading the layer input
+  writeback_b6<NOB>(X, acc, row0, lane);
+  __syncthreads();
+}
+
+// Preconditions as mlp_forward: S.xyz rows 0..2 hold the 64 points. Returns (every thread, ray = tid & 63) the pre-tanh output.
+__device__ __forceinline__ float mlp_forward_b6(const DecoderDev& D, const DecoderB6& B6, const float* __restrict__ c0, const float* __restrict__ c4,
+                                                SmemB6& S) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  float* X = S.X;
+  // lin0: x0[o] = relu(c0[o] + W0x[:, o] . xyz)  (K = 3: plain f32 fmaf chain in the order of the exact tile: x, y, z from the bias)
+  {
+    const int ray = tid & 63;
+    const float px = S.xyz[ray], py = S.xyz[64 + ray], pz = S.xyz[128 + ray];
+#pragma unroll 4
+    for (int o = wave * 128; o < wave * 128 + 128; ++o) {
+      float v = c0[o];
+      v = __builtin_fmaf(D.W0x[o], px, v);
+      v = __builtin_fmaf(D.W0x[HID + o], py, v);
+      v = __builtin_fmaf(D.W0x[2 * HID + o], pz, v);
+      X[xk(o, ray)] = fmaxf(v, 0.f);
+    }
+  }
+  __syncthreads();
+  layer_b6<512, 4>(B6.Wp[1], D.bias[1], HID, X, wave, lane);
+  layer_b6<512, 4>(B6.Wp[2], D.bias[2], HID, X, wave, lane);
+  layer_b6<512, 2>(B6.Wp[3], D.bias[3], 253, X, wave, lane);       // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
+  if (tid < 192) X[xk(253 + tid / 64, tid & 63)] = S.xyz[tid];
+  __syncthreads();
+  layer_b6<256, 4>(B6.Wp[4], c4, HID, X, wave, lane);               // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
+  layer_b6<512, 4>(B6.Wp[5], D.bias[5], HID, X, wave, lane);
+  layer_b6<512, 4>(B6.Wp[6], D.bias[6], HID, X, wave, lane);
+  layer_b6<512, 4>(B6.Wp[7], D.bias[7], HID, X, wave, lane);
+  // lin8: four 128-long f32 chains per ray (one per wave), combined in the exact tile's order
+  {
+    const int ray = tid & 63;
+    float p = 0.f;
+    const float* w8 = D.w8 + wave * 128;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], X[xk(wave * 128 + k, ray)], p);
+    S.part[wave * 64 + ray] = p;
+  }
+  __syncthreads();
+  const int ray = tid & 63;
+  return ((S.part[ray] + S.part[64 + ray]) + (S.part[128 + ray] + S.part[192 + ray])) + D.b8;
+}
+
+// decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-bf16 arithmetic
+__global__ void __launch_bounds__(256, 1) k_eval_b6(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
+                                                    float* __restrict__ sdf, DecoderDev D, DecoderB6 B6) {
+  __shared__ SmemB6 S;
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * 64;
+  if (base >= n) return;
+  if (tid < 64) {
+    const int64_t r = base + tid;
+    const bool v = r < n;
+    S.xyz[tid] = v ? xyz[r * 3] : 0.f; S.xyz[64 + tid] = v ? xyz[r * 3 + 1] : 0.f; S.xyz[128 + tid] = v ? xyz[r * 3 + 2] : 0.f;
+  }
+  __syncthreads();
+  const float pre = mlp_forward_b6(D, B6, c0c4, c0c4 + HID, S);
+  if (tid < 64 && base + tid < n) {
+    const float s = tanh_spec(pre);
+    sdf[base + tid] = (clamp >= 0.f) ? clampf(s, -clamp, clamp) : s;
+  }
+}
+
+}  // namespace distr

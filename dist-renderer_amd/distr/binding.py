@@ -23,7 +23,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
            'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward',
            'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
-           'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch']
+           'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6']
 
 MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
 VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
@@ -85,7 +85,7 @@ class RenderStats(C.Structure):
 
 def build_library(force=False, verbose=False):
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
-    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
+    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -132,6 +132,7 @@ def lib():
             L.distr_mlp_workspace_bytes.argtypes = [C.c_int64]
             L.distr_mlp_workspace_bytes.restype = C.c_size_t
             L.distr_mlp_eval.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
+            L.distr_mlp_eval_bf16x6.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
             L.distr_mlp_grad.argtypes = [vp, fp, fp, C.c_int64, fp, fp, vp, C.c_size_t, vp]
             L.distr_debug_mlp_layer.argtypes = [vp, fp, fp, C.c_int64, C.c_int, fp, vp, C.c_size_t, vp]
             L.distr_debug_tile_timing.argtypes = [vp, fp, fp, C.c_int64, fp, vp, vp, C.c_size_t, vp]

@@ -391,8 +391,11 @@ def render_normal_call(engine, cfg, latent, R, T, zdepth, mask):
     return out
 
 
-def mlp_eval(engine, latent, points, clamp_dist=None):
-    """decode_sdf forward (core/utils/decoder_utils.py:53-74): points (n,3) -> (n,1)."""
+def mlp_eval(engine, latent, points, clamp_dist=None, arith='f32'):
+    """decode_sdf forward (core/utils/decoder_utils.py:53-74): points (n,3) -> (n,1). arith='f32' (default): exact f32 MFMA, bit-identical
+    to the oracle; 'bf16x6': six-product split-bf16 arithmetic (distr_mlp_eval_bf16x6: f32-equivalent accuracy, faster, not bit-identical)."""
+    if arith not in ('f32', 'bf16x6'):
+        raise ValueError("arith must be 'f32' or 'bf16x6'")
     dev = engine.device
     lat = _f32c(latent, dev).reshape(-1)
     x = _f32c(points, dev).reshape(-1, 3)
@@ -400,8 +403,9 @@ def mlp_eval(engine, latent, points, clamp_dist=None):
     out = torch.empty(n, 1, dtype=torch.float32, device=dev)
     ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
     p = binding.ptr
-    engine.ctx.check(engine.ctx.L.distr_mlp_eval(engine.ctx.h, p(lat), p(x), n, -1.0 if clamp_dist is None else float(clamp_dist),
-                                                p(out), p(ws), ws.numel(), engine.ctx.stream()))
+    fn = engine.ctx.L.distr_mlp_eval if arith == 'f32' else engine.ctx.L.distr_mlp_eval_bf16x6
+    engine.ctx.check(fn(engine.ctx.h, p(lat), p(x), n, -1.0 if clamp_dist is None else float(clamp_dist), p(out), p(ws), ws.numel(),
+                        engine.ctx.stream()))
     return out
 
 

@@ -180,6 +180,13 @@ int distr_render_normal_batch(distr_ctx* ctx, const distr_render_cfg* cfg, int32
 size_t distr_mlp_workspace_bytes(int64_t n);
 int distr_mlp_eval(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float clamp_dist,
                    float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* decode_sdf in SIX-PRODUCT SPLIT-bf16 arithmetic (opt-in): every f32 product of the seven wide layers is replaced by six bf16
+ * products (three bf16 planes per operand, f32 accumulation, v_mfma_f32_32x32x16_bf16) -- f32-equivalent accuracy (measured max
+ * |delta sdf| against distr_mlp_eval: profiles/r03_dense_b6.log) at a multiple of the f32-MFMA rate, but NOT bit-identical to the
+ * exact path, which is why it is a separate entry point and nothing switches to it silently. Same arguments as distr_mlp_eval.
+ * Used by the bulk SDF grid evaluation for meshing (core/evaluation/create_mesh.py: create_sdf_grid(..., arith='bf16x6')). */
+int distr_mlp_eval_bf16x6(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float clamp_dist,
+                          float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int distr_mlp_grad(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float* sdf_dev,
                    float* grad_dev, void* ws_dev, size_t ws_bytes, void* stream);
 /* Backward of decode_sdf for callers that differentiate through it (decoder_utils.py:53-74 without no_grad): g_sdf[n] is

@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
   RESOLVE(distr_warp_loss_forward); RESOLVE(distr_warp_loss_backward); RESOLVE(distr_set_color_decoder); RESOLVE(distr_color_eval); RESOLVE(distr_color_backward);
   RESOLVE(distr_debug_mlp_layer); RESOLVE(distr_debug_tile_timing); RESOLVE(distr_debug_xchg_ts);
   RESOLVE(distr_render_forward_batch); RESOLVE(distr_render_backward_batch); RESOLVE(distr_render_normal_batch);
+  RESOLVE(distr_mlp_eval_bf16x6);
   const char* (*version)(void);
   size_t (*mlp_ws)(int64_t);
   size_t (*loss_ws)(int32_t, int32_t);

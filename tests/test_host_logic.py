@@ -21,7 +21,7 @@ def libdistr():
 def test_library_exports_every_declared_symbol(libdistr):
     hdr = open(os.path.join(ROOT, 'include', 'distr.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    declared = set(re.findall(r'\b(distr_[a-z_]+)\s*\(', hdr))
+    declared = set(re.findall(r'\b(distr_[a-z0-9_]+)\s*\(', hdr))
     assert {'distr_create', 'distr_render_forward', 'distr_render_backward', 'distr_mlp_eval'} <= declared
     for name in declared:
         assert hasattr(libdistr, name), name
