@@ -1511,7 +1511,7 @@ def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix):
         assert b.shape == a.shape and float((a - b).abs().max()) <= 1e-5, (n, float((a - b).abs().max()))
         ac = functions.mlp_eval(eng, lat, pts, clamp_dist=0.05)
         bc = functions.mlp_eval(eng, lat, pts, clamp_dist=0.05, arith='bf16x6')
-        assert float((ac - bc).abs().max()) <= 1e-5 and float(bc.abs().max()) <= 0.05
+        assert float((ac - bc).abs().max()) <= 1e-5 and float(bc.abs().max()) <= 0.05 + 1e-7
     if n >= 50000:
         print('%s: max |sdf_bf16x6 - sdf_f32| over %d points = %.3e' % (fix, n, float((a - b).abs().max())))
     dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
