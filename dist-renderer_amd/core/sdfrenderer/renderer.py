@@ -15,7 +15,12 @@ class SDFRenderer(object):
     # reference: renderer.py:13
     def __init__(self, decoder, intrinsic, img_hw=None, transform_matrix=None, march_step=50, buffer_size=5,
                  ray_marching_ratio=1.5, use_depth2normal=False, max_sample_dist=0.2, radius=1.0, threshold=5e-5,
-                 scale_list=[4, 2, 1], march_step_list=[3, 3, -1], use_gpu=True, is_eval=True):
+                 scale_list=[4, 2, 1], march_step_list=[3, 3, -1], use_gpu=True, is_eval=True, arith='f32'):
+        # arith (not in the reference): 'f32' = exact f32 decoder evaluations (default); 'bf16x6' = the six-product split-bf16 march
+        # tiles (values within ~1e-6, ~1.5x the dense rate, no cluster tiles: for large dense renders); also settable later (self.arith)
+        if arith not in binding.ARITH:
+            raise ValueError("arith must be one of %s" % sorted(binding.ARITH))
+        self.arith = arith
         if not use_gpu:
             raise ValueError('SDFRenderer(use_gpu=False): this build has no CPU path (MI355X kernels only).')
         if torch.cuda.device_count() == 0:
@@ -117,7 +122,7 @@ class SDFRenderer(object):
                                 transform_matrix=self._M_np, use_transform=use_transform,
                                 use_depth2normal=self.use_depth2normal, normalize_normal=normalize_normal,
                                 want_normal=want_normal, grad_depth=not no_grad_depth, grad_mask=not no_grad_mask,
-                                grad_camera=not no_grad_camera)
+                                grad_camera=not no_grad_camera, arith=self.arith)
 
     @staticmethod
     def _check_marcher(ray_marching_type):

@@ -178,6 +178,7 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
   if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
+  if (c->arith != DISTR_ARITH_F32 && c->arith != DISTR_ARITH_BF16X6) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown arith %d", c->arith);
   if (c->rows != 0) {
     if (c->rows < 0 || c->row0 < 0 || c->row0 + c->rows > c->H) return fail(ctx, DISTR_ERR_INVALID_ARG, "row band [%d,+%d) outside the %d-row image", c->row0, c->rows, c->H);
     if ((c->row0 & 3) || ((c->rows & 3) && c->row0 + c->rows != c->H))
@@ -628,12 +629,14 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
   MarchArgs A;
   memset(&A, 0, sizeof(A));
   A.V = V;
+  A.B6 = ctx->B6;
+  const bool b6 = cfg->arith == DISTR_ARITH_BF16X6;                // split-bf16 tiles: 64- and 32-ray roles only, no cluster tiles
   const bool recursive = cfg->marcher != DISTR_MARCH_TRIVIAL;     // live-ray lists + tile-size split (fine_split)
-  const int t32 = ctx->hybrid_threshold, t16 = std::min(ctx->tail16_threshold, ctx->hybrid_threshold);
+  const int t32 = ctx->hybrid_threshold, t16 = b6 ? 0 : std::min(ctx->tail16_threshold, ctx->hybrid_threshold);
   A.t16 = recursive ? t16 : 0; A.t32 = recursive ? t32 : 0; A.which = 64;
   // f(origin) of every view (sample point of padded rows) is evaluated by nviews extra workgroups of ONE march launch: for the
   // recursive marchers they ride on the 16-ray role of the last step (free: a tail step); 'trivial' puts them on its first launch
-  distr_ctx::XRegion* xr = recursive ? xchg_region(ctx, s) : nullptr;
+  distr_ctx::XRegion* xr = (recursive && !b6) ? xchg_region(ctx, s) : nullptr;
   auto up8 = [](int64_t v) { return (int32_t)((v + 7) / 8 * 8); };
   for (int l = V.nlev - 1; l >= 1; --l) {
     hipLaunchKernelGGL(k_coarse_init, gridv(V.lv[l].n), dim3(256), 0, s, V, l);
@@ -643,7 +646,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       // tile size of a coarse level from the (host-known) pixel count of all views: a level that fits one round of 16- / 32-ray
       // tiles runs on those (small images: 111 / 212 us per step instead of 380 us)
       const int64_t ln = V.lv[l].n;
-      const bool c16 = nviews * pad_to(ln, 16) <= t16;
+      const bool c16 = !b6 && nviews * pad_to(ln, 16) <= t16;
       const int crb = (nviews * pad_to(ln, 32) <= t32) ? 1 : 2;
       const int ctile = c16 ? 16 : 32 * crb;
       unsigned tiles = NV * (unsigned)((ln + ctile - 1) / ctile);
@@ -653,6 +656,14 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       if (c16) {
         if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_COARSE, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
         else hipLaunchKernelGGL((k_march16<MODE_COARSE, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+      } else if (b6) {
+        if (V.save_masks) {
+          if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+          else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, true, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        } else {
+          if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, false, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+          else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, false, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        }
       } else if (V.save_masks) {
         if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
         else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
@@ -675,7 +686,10 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       // 'trivial': every in-sphere ray, every step, on 64-ray tiles
       A.origin_tile = (st == 0) ? 1 : 0;
       const unsigned tiles = NV * (unsigned)((P + 63) / 64) + (A.origin_tile ? NV : 0u);
-      if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      if (b6) {
+        if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      } else if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       timer.end();
       LAUNCH_CHECK("k_march<fine>");
@@ -689,15 +703,25 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
     const bool skip32 = t32 <= t16 || N64 <= t16;
     StepGrid G;
     G.n64 = skip64 ? 0 : std::min(up8(N64 / 64), 256);            // persistent: at most one 64-ray workgroup per CU
-    G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
     A.origin_tile = (st == V.fine_steps - 1) ? 1 : 0;
-    A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky);
-    unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
-    if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
-    G.n16 = up8(n16);
-    const unsigned grid = (unsigned)(G.n64 + G.n32 + G.n16);
-    if (V.save_masks) hipLaunchKernelGGL((k_step<true>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
-    else hipLaunchKernelGGL((k_step<false>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+    if (b6) {
+      // split-bf16: no 16-ray role; the views' origin tiles (last step) close the 32-ray role's grid
+      G.n32 = up8(std::min<int64_t>(N64, t32) / 32 + (A.origin_tile ? nviews : 0));
+      G.n16 = 0;
+      A.xc = next_xchg(nullptr, s, false, ctx->max_cl, 0, ctx->min_cl);
+      const unsigned grid = (unsigned)(G.n64 + G.n32);
+      if (V.save_masks) hipLaunchKernelGGL((k_step<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+      else hipLaunchKernelGGL((k_step<false, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+    } else {
+      G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
+      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky);
+      unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
+      if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
+      G.n16 = up8(n16);
+      const unsigned grid = (unsigned)(G.n64 + G.n32 + G.n16);
+      if (V.save_masks) hipLaunchKernelGGL((k_step<true>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+      else hipLaunchKernelGGL((k_step<false>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+    }
     timer.end();
     LAUNCH_CHECK("k_step");
   }

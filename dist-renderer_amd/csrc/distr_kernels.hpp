@@ -10,6 +10,7 @@
 //   autograd backward                   (PyTorch tape in the reference; SURVEY.md Appendix A.6 contract)
 #pragma once
 #include "distr_mlp.hpp"
+#include "distr_mlp_b6.hpp"
 #include "../../include/distr.h"
 
 namespace distr {
@@ -574,6 +575,7 @@ struct MarchArgs {
   // 32-ray tiles; which = tile size of THIS launch (a plain k_march launch; the roles of k_step pass their own)
   int32_t t16, t32, which;
   Xchg xc;                   // 16-ray launches: exchange region of the cluster tiles (buf == null: single-workgroup tiles only)
+  DecoderB6 B6;              // split-bf16 weight planes (kernels instantiated with ARITH = 1, distr_render_cfg.arith)
 };
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
@@ -581,9 +583,13 @@ struct MarchArgs {
 // Body of one 32*RB-ray tile; `tile` / `ntile_grid` = index and count of the tiles this launch (or this role of a merged
 // launch, k_step) provides, `which` = the tile size the split rule (fine_range) knows this role by.
 // Returns false when the tile lies beyond this role's range (nothing done).
-template <int MODE, int RB, bool KEEP>
-__device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev& D, Smem<RB>& S, int tile, int ntile_grid, int which,
-                                           int origin_tile) {
+// ARITH = 0: exact f32 MFMA tile (distr_mlp.hpp); 1: six-product split-bf16 tile (distr_mlp_b6.hpp, distr_render_cfg.arith)
+template <int RB, int ARITH> struct TileSmem { using type = Smem<RB>; };
+template <int RB> struct TileSmem<RB, 1> { using type = SmemB6<RB>; };
+
+template <int MODE, int RB, bool KEEP, int ARITH = 0>
+__device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev& D, typename TileSmem<RB, ARITH>::type& S, int tile, int ntile_grid,
+                                           int which, int origin_tile) {
   constexpr int TILE = 32 * RB;
   const View& V0 = A.V;
   const int tid = threadIdx.x;
@@ -628,7 +634,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   else if (MODE == MODE_FINE) list = split ? live_sel(V, A.step) : V.lv[0].list;
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  stage_bias<RB>(D, c0, c4, S);      // first thing: these loads travel under the prologue's dependent state loads
+  if constexpr (ARITH == 0) stage_bias<RB>(D, c0, c4, S);      // first thing: these loads travel under the prologue's dependent state loads
 
   int32_t id = -1;
   float zd = 0.f;
@@ -661,7 +667,9 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   __syncthreads();
 
   uint32_t masks[8][4];
-  const float pre = mlp_forward<RB, KEEP, false, true>(D, c0, c4, S, masks);
+  float pre;
+  if constexpr (ARITH == 0) pre = mlp_forward<RB, KEEP, false, true>(D, c0, c4, S, masks);
+  else pre = mlp_forward_b6<RB, KEEP>(D, A.B6, c0, c4, S, masks);
 
   // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
   int64_t mblock = -1;   // mask block this ray's row goes to (KEEP), -1: row not kept
@@ -718,10 +726,10 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   return true;
 }
 
-template <int MODE, int RB, bool KEEP>
-__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
-  __shared__ Smem<RB> S;
-  (void)march_tile<MODE, RB, KEEP>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
+template <int MODE, int RB, bool KEEP, int ARITH = 0>
+__global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_march(MarchArgs A, DecoderDev D) {
+  __shared__ typename TileSmem<RB, ARITH>::type S;
+  (void)march_tile<MODE, RB, KEEP, ARITH>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
 }
 
 // Sticky tail tile (renderer.py:528-567 from the point where few rays are left): once ALL live rays of a step fit the cluster
@@ -1074,21 +1082,22 @@ __global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, D
 // Against three launches per step this saves two empty launches (4-5 us each) on almost every step.
 struct StepGrid { int32_t n64, n32, n16; };
 
-template <bool KEEP>
+template <bool KEEP, int ARITH = 0>
 __global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, DecoderDev16 D16, StepGrid G) {
-  __shared__ __attribute__((aligned(16))) unsigned char raw[sizeof(Smem<2>)];
-  static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CL), "role shared memory");
+  __shared__ __attribute__((aligned(16))) unsigned char raw[(sizeof(Smem<2>) > sizeof(SmemB6<2>)) ? sizeof(Smem<2>) : sizeof(SmemB6<2>)];
+  static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CL) && sizeof(SmemB6<2>) >= sizeof(SmemB6<1>), "role shared memory");
   // role order in the grid: 32-ray tiles, 16-ray / cluster tiles, 64-ray tiles. On a tail step the cluster tiles start
   // after one wave of idle 32-ray workgroups and the idle 64-ray workgroups retire on the free CUs while the clusters
   // run; on a dense step the remainder tiles start first and the persistent 64-ray workgroups follow as CUs free up.
+  // ARITH = 1 (split-bf16): 64- and 32-ray roles only (G.n16 = 0, t16 = 0); the views' origin tiles close the 32-ray role.
   const int b = blockIdx.x;
   if (b < G.n32) {
-    (void)march_tile<MODE_FINE, 1, KEEP>(A, D, *reinterpret_cast<Smem<1>*>(raw), b, G.n32, 32, 0);
+    (void)march_tile<MODE_FINE, 1, KEEP, ARITH>(A, D, *reinterpret_cast<typename TileSmem<1, ARITH>::type*>(raw), b, G.n32, 32, ARITH ? A.origin_tile : 0);
   } else if (b < G.n32 + G.n16) {
-    march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n32, A.origin_tile);
+    if constexpr (ARITH == 0) march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n32, A.origin_tile);
   } else {
     for (int t = b - G.n32 - G.n16;; t += G.n64) {
-      if (!march_tile<MODE_FINE, 2, KEEP>(A, D, *reinterpret_cast<Smem<2>*>(raw), t, 0x7fffffff, 64, 0)) break;
+      if (!march_tile<MODE_FINE, 2, KEEP, ARITH>(A, D, *reinterpret_cast<typename TileSmem<2, ARITH>::type*>(raw), t, 0x7fffffff, 64, 0)) break;
       __syncthreads();       // the tile's last LDS reads (mask store) are done before the next tile's points are written
     }
   }

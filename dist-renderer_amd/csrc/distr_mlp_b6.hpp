@@ -18,7 +18,9 @@
 //   * weights: three pre-split bf16 planes per layer, pre-packed on the host as A fragments of v_mfma_f32_32x32x16_bf16
 //     (fragment index (((kb * 4 + wave) * NOB + ob) * 3 + plane) * 64 + lane = 8 bf16 W_plane[o][16 kb + 8 h + 0..7]);
 //   * wave w owns output rows [w O/4, (w+1) O/4) as NOB x 2 accumulator tiles of 32 x 32, started from the bias (exact f32);
-//   * lin0 (K = 3) and lin8 (one row) are plain f32 VALU work, as in the exact tile.
+//   * lin0 (K = 3) and lin8 (one row) are plain f32 VALU work, as in the exact tile;
+//   * march tiles (round 3): the same forward inside k_march / k_step when distr_render_cfg.arith = DISTR_ARITH_BF16X6, on 64- and
+//     32-ray tiles only (no 16-ray / cluster tiles: they are built on the f32 16x16x4 MFMA and would not be bit-identical to these).
 #pragma once
 #include "distr_mlp.hpp"
 
@@ -31,13 +33,20 @@ struct DecoderB6 {
   const uint32_t* Wp[8];   // split-bf16 A-fragment planes of lin1..lin7 ([0] unused); lin3: O padded to 256; lin4: K = 256
 };
 
+// A tile = RB blocks of 32 rays (RB = 2: 64 rays, RB = 1: 32 rays). Every output column of v_mfma_f32_32x32x16_bf16 depends only
+// on its own B column, so a ray's value does not depend on RB or on which other rays share its tile: the two tile sizes are
+// bit-identical (within this arithmetic), like the tile sizes of the exact path are among themselves.
+template <int RB>
 struct alignas(16) SmemB6 {
-  float X[HID * 64];       // k-minor activations
-  float xyz[4 * 64];
-  float part[4 * 64];
+  static constexpr int TILE = 32 * RB;
+  float X[HID * TILE];     // k-minor activations
+  float xyz[4 * TILE];
+  float part[4 * TILE];
+  float aux[4 * TILE];     // march tiles (KEEP): the rays' mask-block indices (8 bytes each)
 };
 
-__device__ __forceinline__ int xk(int k, int ray) { return ((k >> 3) * 64 + ray) * 8 + (k & 7); }
+template <int TILE>
+__device__ __forceinline__ int xk(int k, int ray) { return ((k >> 3) * TILE + ray) * 8 + (k & 7); }
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {   // {bf16(a) low half, bf16(b) high half}, round to nearest even
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -53,31 +62,31 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& p0, uint3
   p2 = pk_bf16(sa, sb);
 }
 
-// acc[ob][rb] (started by the caller) += W[rows of this wave][0..K) x X[0..K)[64 rays], six bf16 products per f32 product
-template <int K, int NOB>
-__device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][2], int wave, int lane) {
-  constexpr int NKB = K / 16;
+// acc[ob][rb] (started by the caller) += W[rows of this wave][0..K) x X[0..K)[rays], six bf16 products per f32 product
+template <int K, int NOB, int RB>
+__device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][RB], int wave, int lane) {
+  constexpr int NKB = K / 16, TILE = 32 * RB;
   const int j = lane & 31, h = lane >> 5;
   const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)wave * NOB * 3 * 64 + lane;
   constexpr int PW[6] = {0, 1, 0, 1, 2, 0}, PA[6] = {0, 0, 1, 1, 0, 2};     // (weight plane, activation plane) of the six products
-  u32x4 a[NOB][3], b[2][3];
-  f32x4 xr[2][2];
+  u32x4 a[NOB][3], b[RB][3];
+  f32x4 xr[RB][2];
   auto load_a = [&](u32x4 (&dst)[NOB][3], int kb) {
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
       for (int p = 0; p < 3; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * NOB + ob) * 3 + p) * 64];
   };
-  auto load_x = [&](f32x4 (&dst)[2][2], int kb) {
+  auto load_x = [&](f32x4 (&dst)[RB][2], int kb) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const f32x4* xp = reinterpret_cast<const f32x4*>(&X[xk(16 * kb + 8 * h, 32 * rb + j)]);
+    for (int rb = 0; rb < RB; ++rb) {
+      const f32x4* xp = reinterpret_cast<const f32x4*>(&X[xk<TILE>(16 * kb + 8 * h, 32 * rb + j)]);
       dst[rb][0] = xp[0]; dst[rb][1] = xp[1];
     }
   };
-  auto split = [&](const f32x4 (&src)[2][2], u32x4 (&dst)[2][3]) {
+  auto split = [&](const f32x4 (&src)[RB][2], u32x4 (&dst)[RB][3]) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
       uint32_t q0[4], q1[4], q2[4];
       split_pair(src[rb][0][0], src[rb][0][1], q0[0], q1[0], q2[0]);
       split_pair(src[rb][0][2], src[rb][0][3], q0[1], q1[1], q2[1]);
@@ -94,8 +103,8 @@ __device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const 
   for (int kb = 0; kb < NKB; ++kb) {
     // register double buffer: block kb + 1 (weights from L2, activations from LDS) is requested before the MFMAs of block kb,
     // its split into planes sits between them (one wave per SIMD: nothing else hides the L2 round trip)
-    u32x4 an[NOB][3], bn[2][3];
-    f32x4 xn[2][2];
+    u32x4 an[NOB][3], bn[RB][3];
+    f32x4 xn[RB][2];
     const int kn = (kb + 1 < NKB) ? kb + 1 : kb;
     load_a(an, kn);
     load_x(xn, kn);
@@ -105,7 +114,7 @@ __device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const 
 #pragma unroll
       for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
           acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ob][PW[q]]), __builtin_bit_cast(bf16x8, b[rb][PA[q]]),
                                                                 acc[ob][rb], 0, 0, 0);
       if (q == 0) split(xn, bn);
@@ -115,34 +124,48 @@ __device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const 
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[ob][p] = an[ob][p];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int p = 0; p < 3; ++p) b[rb][p] = bn[rb][p];
   }
 }
 
 // ReLU + write-back into the k-minor layout: D rows of register r on lane (j, h) are (r & 3) + 8 (r >> 2) + 4 h -> 4 consecutive
-// features = one 16-byte store
-template <int NOB>
-__device__ __forceinline__ void writeback_b6(float* X, const f32x16 (&acc)[NOB][2], int row0, int lane) {
+// features = one 16-byte store. KEEP: bit (rb * 16 + r) of mask[ob] = value > 0 -- the format of the exact tile's write-back
+// (distr_mlp.hpp::writeback; the C/D layout of the bf16 MFMA is that of v_mfma_f32_32x32x2_f32), so the saved mask blocks feed the
+// same backward kernel.
+template <int NOB, int RB, bool KEEP>
+__device__ __forceinline__ void writeback_b6(float* X, const f32x16 (&acc)[NOB][RB], int row0, int lane, uint32_t (&mask)[4]) {
+  constexpr int TILE = 32 * RB;
   const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
+  for (int ob = 0; ob < NOB; ++ob) {
+    uint32_t m = 0u;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __int_as_float(max(__float_as_int(acc[ob][rb][4 * q + i]), 0));
-        *reinterpret_cast<f32x4*>(&X[xk(row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v;
+        for (int i = 0; i < 4; ++i) {
+          const int32_t rbits = max(__float_as_int(acc[ob][rb][4 * q + i]), 0);
+          v[i] = __int_as_float(rbits);
+          if (KEEP) m |= min((uint32_t)rbits, 1u) << (rb * 16 + 4 * q + i);
+        }
+        *reinterpret_cast<f32x4*>(&X[xk<TILE>(row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v;
       }
+    if (KEEP) {
+      asm volatile("" : "+v"(m));      // (see distr_mlp.hpp::writeback: keeps LLVM from carrying the accumulators instead of the bits)
+      mask[ob] = m;
+    }
+  }
 }
 
-template <int K, int NOB>
-__device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const float* __restrict__ bias, int nbias, float* X, int wave, int lane) {
+template <int K, int NOB, int RB, bool KEEP>
+__device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const float* __restrict__ bias, int nbias, float* X, int wave, int lane,
+                                         uint32_t (&mask)[4]) {
   const int h = lane >> 5;
-  f32x16 acc[NOB][2];
+  f32x16 acc[NOB][RB];
   const int row0 = wave * 32 * NOB;
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
@@ -150,62 +173,86 @@ __device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const 
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
       const float bv = (row < nbias) ? bias[row] : 0.f;
-      acc[ob][0][r] = bv; acc[ob][1][r] = bv;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[ob][rb][r] = bv;
     }
-  dense_b6<K, NOB>(Wp, X, acc, wave, lane);
+  dense_b6<K, NOB, RB>(Wp, X, acc, wave, lane);
   __syncthreads();                         // everybody is done reading the layer input
-  writeback_b6<NOB>(X, acc, row0, lane);
+  writeback_b6<NOB, RB, KEEP>(X, acc, row0, lane, mask);
   __syncthreads();
 }
 
-// Preconditions as mlp_forward: S.xyz rows 0..2 hold the 64 points. Returns (every thread, ray = tid & 63) the pre-tanh output.
+// Preconditions as mlp_forward: S.xyz rows 0..2 hold the TILE points. Returns (every thread, ray = tid & (TILE - 1)) the pre-tanh
+// output; masks[l] = ReLU bitmasks of layer l in the exact tile's format (KEEP).
+template <int RB, bool KEEP>
 __device__ __forceinline__ float mlp_forward_b6(const DecoderDev& D, const DecoderB6& B6, const float* __restrict__ c0, const float* __restrict__ c4,
-                                                SmemB6& S) {
+                                                SmemB6<RB>& S, uint32_t (&masks)[8][4]) {
+  constexpr int TILE = 32 * RB;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
   float* X = S.X;
-  // lin0: x0[o] = relu(c0[o] + W0x[:, o] . xyz)  (K = 3: plain f32 fmaf chain in the order of the exact tile: x, y, z from the bias)
+  // lin0 (K = 3): the f32 fmaf chain of the exact tile (bias, then x, y, z), computed in the accumulator layout of the wide layers
+  // (lane (j, h), register r <-> row, column) so that its ReLU bits land in the common mask format
   {
-    const int ray = tid & 63;
-    const float px = S.xyz[ray], py = S.xyz[64 + ray], pz = S.xyz[128 + ray];
-#pragma unroll 4
-    for (int o = wave * 128; o < wave * 128 + 128; ++o) {
-      float v = c0[o];
-      v = __builtin_fmaf(D.W0x[o], px, v);
-      v = __builtin_fmaf(D.W0x[HID + o], py, v);
-      v = __builtin_fmaf(D.W0x[2 * HID + o], pz, v);
-      X[xk(o, ray)] = fmaxf(v, 0.f);
+    float px[RB], py[RB], pz[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { px[rb] = S.xyz[32 * rb + j]; py[rb] = S.xyz[TILE + 32 * rb + j]; pz[rb] = S.xyz[2 * TILE + 32 * rb + j]; }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      uint32_t m = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v[RB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wave * 128 + 32 * ob + 8 * q + 4 * h + i;
+          const float b0 = c0[row], wx = D.W0x[row], wy = D.W0x[HID + row], wz = D.W0x[2 * HID + row];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            float t = __builtin_fmaf(wx, px[rb], b0);
+            t = __builtin_fmaf(wy, py[rb], t);
+            t = __builtin_fmaf(wz, pz[rb], t);
+            const int32_t rbits = max(__float_as_int(t), 0);
+            v[rb][i] = __int_as_float(rbits);
+            if (KEEP) m |= min((uint32_t)rbits, 1u) << (rb * 16 + 4 * q + i);
+          }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<f32x4*>(&X[xk<TILE>(wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v[rb];
+      }
+      if (KEEP) masks[0][ob] = m;
     }
   }
   __syncthreads();
-  layer_b6<512, 4>(B6.Wp[1], D.bias[1], HID, X, wave, lane);
-  layer_b6<512, 4>(B6.Wp[2], D.bias[2], HID, X, wave, lane);
-  layer_b6<512, 2>(B6.Wp[3], D.bias[3], 253, X, wave, lane);       // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
-  if (tid < 192) X[xk(253 + tid / 64, tid & 63)] = S.xyz[tid];
+  layer_b6<512, 4, RB, KEEP>(B6.Wp[1], D.bias[1], HID, X, wave, lane, masks[1]);
+  layer_b6<512, 4, RB, KEEP>(B6.Wp[2], D.bias[2], HID, X, wave, lane, masks[2]);
+  masks[3][2] = 0; masks[3][3] = 0;
+  layer_b6<512, 2, RB, KEEP>(B6.Wp[3], D.bias[3], 253, X, wave, lane, masks[3]);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
+  if (tid < 3 * TILE) X[xk<TILE>(253 + tid / TILE, tid % TILE)] = S.xyz[tid];
   __syncthreads();
-  layer_b6<256, 4>(B6.Wp[4], c4, HID, X, wave, lane);               // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
-  layer_b6<512, 4>(B6.Wp[5], D.bias[5], HID, X, wave, lane);
-  layer_b6<512, 4>(B6.Wp[6], D.bias[6], HID, X, wave, lane);
-  layer_b6<512, 4>(B6.Wp[7], D.bias[7], HID, X, wave, lane);
+  layer_b6<256, 4, RB, KEEP>(B6.Wp[4], c4, HID, X, wave, lane, masks[4]);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
+  layer_b6<512, 4, RB, KEEP>(B6.Wp[5], D.bias[5], HID, X, wave, lane, masks[5]);
+  layer_b6<512, 4, RB, KEEP>(B6.Wp[6], D.bias[6], HID, X, wave, lane, masks[6]);
+  layer_b6<512, 4, RB, KEEP>(B6.Wp[7], D.bias[7], HID, X, wave, lane, masks[7]);
   // lin8: four 128-long f32 chains per ray (one per wave), combined in the exact tile's order
+  const int ray = tid & (TILE - 1);
   {
-    const int ray = tid & 63;
     float p = 0.f;
     const float* w8 = D.w8 + wave * 128;
 #pragma unroll 8
-    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], X[xk(wave * 128 + k, ray)], p);
-    S.part[wave * 64 + ray] = p;
+    for (int k = 0; k < 128; ++k) p = __builtin_fmaf(w8[k], X[xk<TILE>(wave * 128 + k, ray)], p);
+    S.part[wave * TILE + ray] = p;
   }
   __syncthreads();
-  const int ray = tid & 63;
-  return ((S.part[ray] + S.part[64 + ray]) + (S.part[128 + ray] + S.part[192 + ray])) + D.b8;
+  return ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
 }
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-bf16 arithmetic
 __global__ void __launch_bounds__(256, 1) k_eval_b6(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
                                                     float* __restrict__ sdf, DecoderDev D, DecoderB6 B6) {
-  __shared__ SmemB6 S;
+  __shared__ SmemB6<2> S;
   const int tid = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * 64;
   if (base >= n) return;
@@ -215,7 +262,8 @@ __global__ void __launch_bounds__(256, 1) k_eval_b6(const float* __restrict__ xy
     S.xyz[tid] = v ? xyz[r * 3] : 0.f; S.xyz[64 + tid] = v ? xyz[r * 3 + 1] : 0.f; S.xyz[128 + tid] = v ? xyz[r * 3 + 2] : 0.f;
   }
   __syncthreads();
-  const float pre = mlp_forward_b6(D, B6, c0c4, c0c4 + HID, S);
+  uint32_t masks[8][4];
+  const float pre = mlp_forward_b6<2, false>(D, B6, c0c4, c0c4 + HID, S, masks);
   if (tid < 64 && base + tid < n) {
     const float s = tanh_spec(pre);
     sdf[base + tid] = (clamp >= 0.f) ? clampf(s, -clamp, clamp) : s;

@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, '..', 'csrc')
 LIB_PATH = os.path.abspath(os.path.join(CSRC, 'libdistr.so'))
 
 MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
+ARITH = {'f32': 0, 'bf16x6': 1}
 EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
            'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
@@ -51,6 +52,7 @@ class RenderCfg(C.Structure):
         ('grad_depth', C.c_int32), ('grad_mask', C.c_int32), ('grad_camera', C.c_int32),
         ('save_for_backward', C.c_int32),
         ('row0', C.c_int32), ('rows', C.c_int32),
+        ('arith', C.c_int32),
     ]
 
     @property
@@ -161,7 +163,7 @@ def lib():
 def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
              marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
              use_depth2normal=False, normalize_normal=True, want_normal=True,
-             grad_depth=True, grad_mask=True, grad_camera=True, band=None):
+             grad_depth=True, grad_mask=True, grad_camera=True, band=None, arith='f32'):
     """Host-side part of SDFRenderer.__init__ (core/sdfrenderer/renderer.py:13-59) as a C struct."""
     cfg = RenderCfg()
     cfg.H, cfg.W = int(img_hw[0]), int(img_hw[1])
@@ -189,6 +191,9 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
     cfg.save_for_backward = 1
     if band is not None:       # (row0, rows): render only these image rows (strong scaling of one view, include/distr.h)
         cfg.row0, cfg.rows = int(band[0]), int(band[1])
+    if arith not in ARITH:
+        raise ValueError("arith must be one of %s" % sorted(ARITH))
+    cfg.arith = ARITH[arith]     # 'f32': exact (default); 'bf16x6': six-product split-bf16 march tiles (DISTR_ARITH_BF16X6)
     return cfg
 
 

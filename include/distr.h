@@ -36,6 +36,9 @@ extern "C" {
 #define DISTR_MARCH_RECURSIVE 1         /* SDFRenderer.ray_marching_recursive          renderer.py:512 */
 #define DISTR_MARCH_PYRAMID_RECURSIVE 2 /* SDFRenderer.ray_marching_pyramid_recursive  renderer.py:713 */
 
+#define DISTR_ARITH_F32 0    /* exact f32 MFMA (default): bit-identical to a k-ordered fmaf chain */
+#define DISTR_ARITH_BF16X6 1 /* six-product split-bf16 (opt-in): f32-equivalent accuracy, ~1.6x the dense rate, not bit-identical */
+
 #define DISTR_MAX_BUFFER_SIZE 8
 #define DISTR_MAX_VIEWS 64 /* views per batched render (distr_render_forward_batch) */
 
@@ -90,6 +93,11 @@ typedef struct distr_render_cfg {
                                  cover rows*W band pixels. depth2normal needs the rows above/below: the first/last band row that
                                  is not an image border row gets an undefined normal -- callers render a halo of 4 rows and
                                  crop it (distr/functions.py::render_band_call). */
+  int32_t arith;              /* DISTR_ARITH_*: arithmetic of the decoder evaluations of the MARCH (no counterpart in the reference, which has
+                                 one arithmetic: f32). 0 (default, also what a zeroed struct selects): exact f32. 1: every f32 product of
+                                 the seven wide layers as six bf16 products with f32 accumulation (csrc/distr_mlp_b6.hpp): values within
+                                 ~1e-6 of the exact ones, on 64- / 32-ray tiles only (no cluster tiles: meant for large, dense renders). The
+                                 backward pass is the exact dX chain on the ReLU masks this forward saved. */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */
