@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--marcher', default='pyramid_recursive')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--arith', default='f32')
     args = ap.parse_args()
     import ctypes as C
     import bench
@@ -44,7 +45,7 @@ def main():
     H = W = args.size
     K = fixture.make_intrinsic(H, W)
     R, T = bench.view_camera(fixture, args.view)
-    cfg = binding.make_cfg((H, W), K, march_step=args.march_step, buffer_size=3, ratio=1.5, marcher=args.marcher, use_depth2normal=True)
+    cfg = binding.make_cfg((H, W), K, march_step=args.march_step, buffer_size=3, ratio=1.5, marcher=args.marcher, use_depth2normal=True, arith=args.arith)
     dev = eng.device
     P = H * W
     fwd_bytes, _ = eng.ctx.workspace_bytes(cfg)

@@ -51,8 +51,9 @@ def _bench_camera(view):
 
 
 # ------------------------------------------------------------------------------------------------------------------ C2
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('name', ['g3_c2_recursive_d2n.npz', 'g3_c2_pyramid_recursive_d2n.npz'])
-def test_c2_hip_matches_reference_golden(engine, name):
+def test_c2_hip_matches_reference_golden(engine, name, arith):
     """C2 through the HIP path against what the reference itself produced at 256x256/50 (G3): the 32x32 crop pixel by pixel,
     the whole-image summaries, and the latent / camera gradients (bar = 2x the reference's own noise floor for this config,
     tests/golden/noise_floor_c2_pyramid_d2n.npz, printed next to the residual)."""
@@ -61,7 +62,7 @@ def test_c2_hip_matches_reference_golden(engine, name):
     H, W = int(g['H']), int(g['W'])
     a = helpers.hip_render(engine, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']),
                            march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']),
-                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']))
+                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']), arith=arith)
     y0, x0 = int(g['crop_y0']), int(g['crop_x0'])
     sl = (slice(y0, y0 + 32), slice(x0, x0 + 32))
     m = a['mask'].reshape(H, W).astype(bool)
@@ -83,7 +84,7 @@ def test_c2_hip_matches_reference_golden(engine, name):
     for k, fk in (('g_latent', 'g_latent_rel'), ('g_R', 'g_R_rel'), ('g_T', 'g_T_rel')):
         rel = np.abs(a[k].reshape(-1) - g[k].reshape(-1)).max() / np.abs(g[k]).max()
         fl = float(floor[fk])
-        print('%s %s: residual %.3e, reference noise floor %.3e' % (name, k, rel, fl))
+        print('%s %s (%s): residual %.3e, reference noise floor %.3e' % (name, k, arith, rel, fl))
         assert rel <= 2.0 * fl, (k, rel, fl)
 
 

@@ -119,10 +119,12 @@ def test_render_c1_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, marc
     assert res['flips'] == 0, res
 
 
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))
                                           if re.match(r'g1[bc]?_', os.path.basename(p))))
-def test_render_matches_reference_goldens(engine, name):
-    """HIP path directly against outputs of the reference itself (tests/golden, made by oracle/gen_golden.py)."""
+def test_render_matches_reference_goldens(engine, name, arith):
+    """HIP path directly against outputs of the reference itself (tests/golden, made by oracle/gen_golden.py) -- in the default exact
+    f32 arithmetic and in the opt-in split-bf16 arithmetic, both at the north-star bar (1e-4, <= 0.1 % mask flips)."""
     from distr import fixture, decoder_pack, functions
     g = dict(np.load(os.path.join(GOLDEN, name)))
     H, W = int(g['H']), int(g['W'])
@@ -133,12 +135,13 @@ def test_render_matches_reference_goldens(engine, name):
         eng = functions.engine_from_weights(Wse, bse, 0)
     a = helpers.hip_render(eng, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']),
                            march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']),
-                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']))
+                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']), arith=arith)
     b = dict(mask=g['mask'], depth=g['depth'], zdepth=g['zdepth'], min_sdf=g['min_abs_query'], normal=g['normal'],
              g_latent=g['g_latent'], g_R=g['g_R'], g_T=g['g_T'])
     fx = float(g['K'][0, 0])
-    helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=2e-3,
-                    normal_p99=max(1e-4, 1e-5 * fx) if bool(g['use_depth2normal']) else 1e-4)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=2e-3,
+                          normal_p99=max(1e-4, 1e-5 * fx) if bool(g['use_depth2normal']) else 1e-4)
+    print(name, arith, res)
 
 
 def test_render_depth_and_warp_gradient_path(engine, cpu_oracle, orc, fixture_decoder):
