@@ -52,16 +52,18 @@ def _floor():
     return {k: float(v) for k, v in np.load(os.path.join(GOLDEN, 'noise_floor_f2.npz')).items()}
 
 
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1f2_*.npz'))))
-def test_f2_hip_matches_reference_goldens(engine_f2, f2, name):
-    """HIP path on F2 directly against outputs of the reference itself (64 x 64, 20 steps: three marchers + autograd normals)."""
+def test_f2_hip_matches_reference_goldens(engine_f2, f2, name, arith):
+    """HIP path on F2 directly against outputs of the reference itself (64 x 64, 20 steps: three marchers + autograd normals), in the
+    exact f32 arithmetic and in the opt-in split-bf16 arithmetic."""
     from distr import fixture
     g = dict(np.load(os.path.join(GOLDEN, name)))
     assert str(g['fixture']) == 'f2' and fixture.weights_sha256(f2[0], f2[1]) == str(g['weights_sha256'])
     H, W = int(g['H']), int(g['W'])
     a = helpers.hip_render(engine_f2, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']),
                            march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']),
-                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']))
+                           marcher=str(g['marcher']), use_depth2normal=bool(g['use_depth2normal']), arith=arith)
     b = dict(mask=g['mask'], depth=g['depth'], zdepth=g['zdepth'], min_sdf=g['min_abs_query'], normal=g['normal'],
              g_latent=g['g_latent'], g_R=g['g_R'], g_T=g['g_T'])
     fl = _floor()
@@ -71,7 +73,7 @@ def test_f2_hip_matches_reference_goldens(engine_f2, f2, name):
     fx = float(g['K'][0, 0])
     res = helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=tol_grad,
                           normal_p99=max(1e-4, 1e-5 * fx) if bool(g['use_depth2normal']) else 1e-4)
-    print(name, res, 'grad bar', tol_grad)
+    print(name, arith, res, 'grad bar', tol_grad)
     assert int(a['mask'].sum()) > 150
 
 
