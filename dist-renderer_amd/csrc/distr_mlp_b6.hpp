@@ -62,21 +62,31 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& p0, uint3
   p2 = pk_bf16(sa, sb);
 }
 
-// acc[ob][rb] (started by the caller) += W[rows of this wave][0..K) x X[0..K)[rays], six bf16 products per f32 product
-template <int K, int NOB, int RB>
-__device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const float* X, f32x16 (&acc)[NOB][RB], int wave, int lane) {
+// weight fragments of one 16-feature block: 3 planes x NOB row blocks, one 16-byte load each (buffers are sized for NOB = 4)
+template <int NOB>
+__device__ __forceinline__ void load_a_b6(const uint32_t* __restrict__ Wp, int kb, int wave, int lane, u32x4 (&dst)[4][3]) {
+  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)wave * NOB * 3 * 64 + lane;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * NOB + ob) * 3 + p) * 64];
+}
+
+// acc[ob][rb] (started by the caller) += W[rows of this wave][0..K) x X[0..K)[rays], six bf16 products per f32 product.
+// Register double buffer: block kb + 1 (weights from L2, activations from LDS) is requested before the MFMAs of block kb, its
+// activations are split into their bf16 planes between those MFMAs (one wave per SIMD: nothing else hides the L2 round trip).
+// On entry `a` holds this layer's block 0 -- requested by the previous layer during ITS last block -- and the look-ahead slot of
+// the last block requests block 0 of the NEXT layer (WpNext, NOBN row blocks per wave; null: nothing), returned in `a`: no layer
+// begins with an exposed round trip (the same arrangement as dense_pf of the exact tile). (A three-deep ring, two blocks ahead,
+// was tried: the compiler needs > 512 registers for it and spills inside the loop.)
+template <int K, int NOB, int RB, int NOBN>
+__device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const float* X, f32x16 (&acc)[NOB][RB],
+                                         int wave, int lane, u32x4 (&a)[4][3]) {
   constexpr int NKB = K / 16, TILE = 32 * RB;
   const int j = lane & 31, h = lane >> 5;
-  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)wave * NOB * 3 * 64 + lane;
   constexpr int PW[6] = {0, 1, 0, 1, 2, 0}, PA[6] = {0, 0, 1, 1, 0, 2};     // (weight plane, activation plane) of the six products
-  u32x4 a[NOB][3], b[RB][3];
+  u32x4 b[RB][3];
   f32x4 xr[RB][2];
-  auto load_a = [&](u32x4 (&dst)[NOB][3], int kb) {
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * NOB + ob) * 3 + p) * 64];
-  };
   auto load_x = [&](f32x4 (&dst)[RB][2], int kb) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -96,18 +106,16 @@ __device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const 
       for (int i = 0; i < 4; ++i) { dst[rb][0][i] = q0[i]; dst[rb][1][i] = q1[i]; dst[rb][2][i] = q2[i]; }
     }
   };
-  load_a(a, 0);
   load_x(xr, 0);
   split(xr, b);
 #pragma unroll 2
   for (int kb = 0; kb < NKB; ++kb) {
-    // register double buffer: block kb + 1 (weights from L2, activations from LDS) is requested before the MFMAs of block kb,
-    // its split into planes sits between them (one wave per SIMD: nothing else hides the L2 round trip)
-    u32x4 an[NOB][3], bn[RB][3];
+    u32x4 an[4][3], bn[RB][3];
     f32x4 xn[RB][2];
-    const int kn = (kb + 1 < NKB) ? kb + 1 : kb;
-    load_a(an, kn);
-    load_x(xn, kn);
+    const bool last = (kb + 1 == NKB);
+    if (!last) load_a_b6<NOB>(Wp, kb + 1, wave, lane, an);
+    else if (WpNext) load_a_b6<NOBN>(WpNext, 0, wave, lane, an);
+    load_x(xn, last ? kb : kb + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -120,7 +128,7 @@ __device__ __forceinline__ void dense_b6(const uint32_t* __restrict__ Wp, const 
       if (q == 0) split(xn, bn);
     }
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
+    for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
       for (int p = 0; p < 3; ++p) a[ob][p] = an[ob][p];
 #pragma unroll
@@ -161,9 +169,10 @@ __device__ __forceinline__ void writeback_b6(float* X, const f32x16 (&acc)[NOB][
   }
 }
 
-template <int K, int NOB, int RB, bool KEEP>
-__device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const float* __restrict__ bias, int nbias, float* X, int wave, int lane,
-                                         uint32_t (&mask)[4]) {
+// One wide layer; `a` = its first weight block on entry, the next layer's first block on return (see dense_b6)
+template <int K, int NOB, int RB, bool KEEP, int NOBN>
+__device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const float* __restrict__ bias, int nbias,
+                                         float* X, int wave, int lane, uint32_t (&mask)[4], u32x4 (&a)[4][3]) {
   const int h = lane >> 5;
   f32x16 acc[NOB][RB];
   const int row0 = wave * 32 * NOB;
@@ -176,7 +185,7 @@ __device__ __forceinline__ void layer_b6(const uint32_t* __restrict__ Wp, const 
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) acc[ob][rb][r] = bv;
     }
-  dense_b6<K, NOB, RB>(Wp, X, acc, wave, lane);
+  dense_b6<K, NOB, RB, NOBN>(Wp, WpNext, X, acc, wave, lane, a);
   __syncthreads();                         // everybody is done reading the layer input
   writeback_b6<NOB, RB, KEEP>(X, acc, row0, lane, mask);
   __syncthreads();
@@ -222,20 +231,25 @@ __device__ __forceinline__ float mlp_forward_b6(const DecoderDev& D, const Decod
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<f32x4*>(&X[xk<TILE>(wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v[rb];
       }
-      if (KEEP) masks[0][ob] = m;
+      if (KEEP) {
+        asm volatile("" : "+v"(m));      // (opaque, like writeback_b6: otherwise LLVM keeps lin0's 128 raw values alive instead of the 4 words)
+        masks[0][ob] = m;
+      }
     }
   }
   __syncthreads();
-  layer_b6<512, 4, RB, KEEP>(B6.Wp[1], D.bias[1], HID, X, wave, lane, masks[1]);
-  layer_b6<512, 4, RB, KEEP>(B6.Wp[2], D.bias[2], HID, X, wave, lane, masks[2]);
+  u32x4 a[4][3];                           // first weight block of the next layer, travelling across the write-backs
+  load_a_b6<4>(B6.Wp[1], 0, wave, lane, a);
+  layer_b6<512, 4, RB, KEEP, 4>(B6.Wp[1], B6.Wp[2], D.bias[1], HID, X, wave, lane, masks[1], a);
+  layer_b6<512, 4, RB, KEEP, 2>(B6.Wp[2], B6.Wp[3], D.bias[2], HID, X, wave, lane, masks[2], a);
   masks[3][2] = 0; masks[3][3] = 0;
-  layer_b6<512, 2, RB, KEEP>(B6.Wp[3], D.bias[3], 253, X, wave, lane, masks[3]);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
+  layer_b6<512, 2, RB, KEEP, 4>(B6.Wp[3], B6.Wp[4], D.bias[3], 253, X, wave, lane, masks[3], a);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
   if (tid < 3 * TILE) X[xk<TILE>(253 + tid / TILE, tid % TILE)] = S.xyz[tid];
   __syncthreads();
-  layer_b6<256, 4, RB, KEEP>(B6.Wp[4], c4, HID, X, wave, lane, masks[4]);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
-  layer_b6<512, 4, RB, KEEP>(B6.Wp[5], D.bias[5], HID, X, wave, lane, masks[5]);
-  layer_b6<512, 4, RB, KEEP>(B6.Wp[6], D.bias[6], HID, X, wave, lane, masks[6]);
-  layer_b6<512, 4, RB, KEEP>(B6.Wp[7], D.bias[7], HID, X, wave, lane, masks[7]);
+  layer_b6<256, 4, RB, KEEP, 4>(B6.Wp[4], B6.Wp[5], c4, HID, X, wave, lane, masks[4], a);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
+  layer_b6<512, 4, RB, KEEP, 4>(B6.Wp[5], B6.Wp[6], D.bias[5], HID, X, wave, lane, masks[5], a);
+  layer_b6<512, 4, RB, KEEP, 4>(B6.Wp[6], B6.Wp[7], D.bias[6], HID, X, wave, lane, masks[6], a);
+  layer_b6<512, 4, RB, KEEP, 4>(B6.Wp[7], nullptr, D.bias[7], HID, X, wave, lane, masks[7], a);
   // lin8: four 128-long f32 chains per ray (one per wave), combined in the exact tile's order
   const int ray = tid & (TILE - 1);
   {
