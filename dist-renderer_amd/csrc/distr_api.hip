@@ -480,17 +480,27 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
   if (B6) {   // split-bf16 planes of lin1..lin7 for the opt-in arithmetic mode (distr_mlp_eval_bf16x6): 9.4 MB, own allocation
     std::vector<uint16_t> hb;
-    size_t offb[8] = {0};
+    size_t offb[8] = {0}, offbt[8] = {0};
     for (int l = 1; l < 8; ++l) {
       offb[l] = (hb.size() + 127) & ~(size_t)127;
       hb.resize(offb[l] + Wp[l].size() * 3, 0);
       pack_fragments_b6(Wp[l].data(), Kp[l], Op[l], hb.data() + offb[l]);
     }
+    for (int l = 1; l < 8; ++l) {   // transposed matrices (backward dX chain): K' = Op[l], O' = Kp[l]
+      std::vector<float> Wt((size_t)Kp[l] * Op[l]);
+      for (int o = 0; o < Op[l]; ++o) for (int k = 0; k < Kp[l]; ++k) Wt[(size_t)k * Op[l] + o] = Wp[l][(size_t)o * Kp[l] + k];
+      offbt[l] = (hb.size() + 127) & ~(size_t)127;
+      hb.resize(offbt[l] + Wt.size() * 3, 0);
+      pack_fragments_b6(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], hb.data() + offbt[l]);
+    }
     if (*dev_buf_b6) { HIP_TRY(hipFree(*dev_buf_b6)); *dev_buf_b6 = nullptr; }
     HIP_TRY(hipMalloc((void**)dev_buf_b6, hb.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(*dev_buf_b6, hb.data(), hb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    B6->Wp[0] = nullptr;
-    for (int l = 1; l < 8; ++l) B6->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offb[l]);
+    B6->Wp[0] = nullptr; B6->Wb[0] = nullptr;
+    for (int l = 1; l < 8; ++l) {
+      B6->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offb[l]);
+      B6->Wb[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offbt[l]);
+    }
   }
   return DISTR_OK;
 }
@@ -784,13 +794,18 @@ int render_backward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews
   LAUNCH_CHECK("k_bwd_prep<emit>");
   BwdArgs B;
   memset(&B, 0, sizeof(B));
-  B.V = V; B.samples = W.samples; B.partial = W.partial; B.bstride = W.bstride;
+  B.V = V; B.samples = W.samples; B.partial = W.partial; B.bstride = W.bstride; B.B6 = ctx->B6;
   // tile-size split of every view's sample list (bwd_range): full rounds on 64-sample tiles, a small remainder on 32-sample tiles
   const bool bsplit = V.save_masks != 0;
   if (bsplit) {
     B.split = 1;
-    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
-    hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+    if (cfg->arith == DISTR_ARITH_BF16X6) {     // the dX chain in the arithmetic of the forward it differentiates
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2, 1>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+    } else {
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+    }
   } else {
     hipLaunchKernelGGL((k_bwd<BWD_FULL, 2>), dim3(NV * tiles), dim3(NTHREADS), 0, s, B, D);     // DISTR_SAVE_MASKS=0: recompute the forward
   }

@@ -1326,6 +1326,7 @@ struct BwdArgs {
   int32_t split;             // SAVED / FULL: 1 = the sample list is split by tile size like a march step (bwd_range)
   float* out_sdf;            // POINTGRAD explicit: [n]   (pixel lists: V.n_sdf)
   float* out_g;              // POINTGRAD explicit: [n][3] (pixel lists: V.n_g)
+  DecoderB6 B6;              // split-bf16 weight planes (k_bwd<BWD_SAVED, RB, 1>: distr_render_cfg.arith)
 };
 
 __device__ __forceinline__ int32_t vget(int32_t x, int b, int B) { return (B <= 1) ? x : __shfl(x, b); }
@@ -1353,10 +1354,11 @@ __device__ __forceinline__ void bwd_range(int64_t count, int split, int tile_siz
   else { lo = full; hi = count; first_tile = t64; }
 }
 
-template <int MODE, int RB>
-__global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, DecoderDev D) {
+template <int MODE, int RB, int ARITH = 0>
+__global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_bwd(BwdArgs A, DecoderDev D) {
+  static_assert(ARITH == 0 || MODE == BWD_SAVED, "the split-bf16 backward exists for saved masks only");
   constexpr int TILE = 32 * RB;
-  __shared__ Smem<RB> S;
+  __shared__ typename TileSmem<RB, ARITH>::type S;
   const View& V0 = A.V;
   const int tid = threadIdx.x;
   const bool explicit_points = MODE == BWD_POINTGRAD && A.xyz;
@@ -1462,7 +1464,8 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     __syncthreads();
     const float* c0 = A.c0c4 ? A.c0c4 : V.C->c0;
     const float* c4 = A.c0c4 ? A.c0c4 + HID : V.C->c4;
-    const float pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
+    float pre = 0.f;
+    if constexpr (ARITH == 0) pre = mlp_forward<RB, true>(D, c0, c4, S, masks);
     if (tid < TILE) {
       y = tanh_spec(pre);
       if (MODE == BWD_POINTGRAD && A.coef && A.clamp >= 0.f && !(fabsf(y) <= A.clamp)) sm.coef = 0.f;
@@ -1471,7 +1474,8 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_bwd(BwdArgs A, Decod
     __syncthreads();
   }
   float* part = (MODE != BWD_POINTGRAD || partial) ? partial + (size_t)tile * PSTRIDE : nullptr;
-  mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
+  if constexpr (ARITH == 0) mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
+  else mlp_backward_b6<RB>(D, A.B6, S, masks, part, part ? part + HID : nullptr);
 
   if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
   const int rl = tid & (TILE - 1);

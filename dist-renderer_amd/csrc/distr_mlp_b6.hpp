@@ -1,4 +1,4 @@
-// distr_mlp_b6.hpp -- the DeepSDF 8x512 decoder tile in SIX-PRODUCT SPLIT-bf16 arithmetic (opt-in; forward only).
+// distr_mlp_b6.hpp -- the DeepSDF 8x512 decoder tile in SIX-PRODUCT SPLIT-bf16 arithmetic (opt-in), forward and backward.
 //
 // The default decoder tile (distr_mlp.hpp) computes every dense layer with f32-input MFMAs: exact f32, bit-identical to the
 // oracle's k-ordered fmaf chains, at 1/16 of the bf16 MFMA rate. This tile evaluates the same network (Decoder.inference,
@@ -20,7 +20,8 @@
 //   * wave w owns output rows [w O/4, (w+1) O/4) as NOB x 2 accumulator tiles of 32 x 32, started from the bias (exact f32);
 //   * lin0 (K = 3) and lin8 (one row) are plain f32 VALU work, as in the exact tile;
 //   * march tiles (round 3): the same forward inside k_march / k_step when distr_render_cfg.arith = DISTR_ARITH_BF16X6, on 64- and
-//     32-ray tiles only (no 16-ray / cluster tiles: they are built on the f32 16x16x4 MFMA and would not be bit-identical to these).
+//     32-ray tiles only (no 16-ray / cluster tiles: they are built on the f32 16x16x4 MFMA and would not be bit-identical to these);
+//   * backward (mlp_backward_b6): the dX chain on the saved ReLU masks with the transposed weight planes, same loop.
 #pragma once
 #include "distr_mlp.hpp"
 
@@ -31,6 +32,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct DecoderB6 {
   const uint32_t* Wp[8];   // split-bf16 A-fragment planes of lin1..lin7 ([0] unused); lin3: O padded to 256; lin4: K = 256
+  const uint32_t* Wb[8];   // the same for the TRANSPOSED matrices (backward dX chain), index = layer whose weights are used (1..7)
 };
 
 // A tile = RB blocks of 32 rays (RB = 2: 64 rays, RB = 1: 32 rays). Every output column of v_mfma_f32_32x32x16_bf16 depends only
@@ -41,8 +43,8 @@ struct alignas(16) SmemB6 {
   static constexpr int TILE = 32 * RB;
   float X[HID * TILE];     // k-minor activations
   float xyz[4 * TILE];
-  float part[4 * TILE];
-  float aux[4 * TILE];     // march tiles (KEEP): the rays' mask-block indices (8 bytes each)
+  float part[12 * TILE];   // lin8 partial chains [4][TILE]; backward: xyz-gradient partials [3][4][TILE], mask-block indices
+  float aux[4 * TILE];     // march tiles (KEEP): the rays' mask-block indices (8 bytes each); backward: row 0 = d8, rows 1..3 = d/dxyz
 };
 
 template <int TILE>
@@ -261,6 +263,160 @@ __device__ __forceinline__ float mlp_forward_b6(const DecoderDev& D, const Decod
   }
   __syncthreads();
   return ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+}
+
+// ---------------------------------------------------------------------------------------- backward tile (dX chain)
+// Gate + write-back of a backward layer: delta = mask bit ? acc : 0 (bits in the forward's format), k-minor layout
+template <int NOB, int RB>
+__device__ __forceinline__ void writeback_gate_b6(float* X, const f32x16 (&acc)[NOB][RB], int row0, int lane, const uint32_t (&mask)[4]) {
+  constexpr int TILE = 32 * RB;
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    const uint32_t m = mask[ob];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gate(acc[ob][rb][4 * q + i], (m >> (rb * 16 + 4 * q + i)) & 1u);
+        *reinterpret_cast<f32x4*>(&X[xk<TILE>(row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v;
+      }
+  }
+}
+
+template <int RB>
+__device__ __forceinline__ void row_sums_b6(const float* X, float* __restrict__ dst, int tid) {
+  constexpr int TILE = 32 * RB;
+  const int lane = tid & 63;
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = tid + rr * 256;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < TILE; ++i) s += X[xk<TILE>(row, (i + lane) & (TILE - 1))];   // (same summation order as the exact tile's row_sums)
+    dst[row] = s;
+  }
+}
+
+// The dX chain of mlp_backward (distr_mlp.hpp) in split-bf16 arithmetic. Preconditions: masks = the ReLU bitmasks of the forward
+// being differentiated (saved mask blocks); S.aux row 0 = d8[ray] = coef (1 - y^2). On return S.aux rows 1..3 hold d(coef f)/d xyz
+// per ray; sd0 / sd4 receive the row sums over the tile's rays of delta0 / delta4 (latent gradient).
+template <int RB>
+__device__ __forceinline__ void mlp_backward_b6(const DecoderDev& D, const DecoderB6& B6, SmemB6<RB>& S, uint32_t (&masks)[8][4],
+                                                float* __restrict__ sd0, float* __restrict__ sd4) {
+  constexpr int TILE = 32 * RB;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int ray = tid & (TILE - 1);
+  float* X = S.X;
+  u32x4 a[4][3];
+  load_a_b6<4>(B6.Wb[7], 0, wave, lane, a);
+  // delta7[k][ray] = relu'(h7) * w8[k] * d8[ray]   (exact f32, like the exact tile)
+  {
+    float d8[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) d8[rb] = S.aux[32 * rb + j];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const uint32_t m = masks[7][ob];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v[RB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wave * 128 + 32 * ob + 8 * q + 4 * h + i;
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) v[rb][i] = gate(D.w8[row] * d8[rb], (m >> (16 * rb + 4 * q + i)) & 1u);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<f32x4*>(&X[xk<TILE>(wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j)]) = v[rb];
+      }
+    }
+  }
+  __syncthreads();
+  auto zero4 = [&](f32x16 (&acc)[4][RB]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+  };
+#pragma unroll
+  for (int l = 7; l >= 5; --l) {  // delta_l (512) -> delta_{l-1} (512)
+    f32x16 acc[4][RB];
+    zero4(acc);
+    if (l > 5) dense_b6<512, 4, RB, 4>(B6.Wb[l], B6.Wb[l - 1], X, acc, wave, lane, a);
+    else dense_b6<512, 4, RB, 2>(B6.Wb[5], B6.Wb[4], X, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_b6<4, RB>(X, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd4) row_sums_b6<RB>(X, sd4, tid);  // X = delta4
+  {  // lin4^T: delta4 (512) -> [delta3 (253) | d xyz (3)]
+    f32x16 acc[2][RB];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+    dense_b6<512, 2, RB, 4>(B6.Wb[4], B6.Wb[3], X, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_b6<2, RB>(X, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
+    if (wave == 3 && h == 1) {
+#pragma unroll
+      for (int r = 13; r < 16; ++r)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) S.aux[(1 + r - 13) * TILE + 32 * rb + j] = acc[1][rb][r];
+    }
+    __syncthreads();
+  }
+  {  // lin3^T: delta3 (256 rows, 253 real) -> delta2 (512)
+    f32x16 acc[4][RB];
+    zero4(acc);
+    dense_b6<256, 4, RB, 4>(B6.Wb[3], B6.Wb[2], X, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_b6<4, RB>(X, acc, wave * 128, lane, masks[2]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 2; l >= 1; --l) {
+    f32x16 acc[4][RB];
+    zero4(acc);
+    if (l > 1) dense_b6<512, 4, RB, 4>(B6.Wb[2], B6.Wb[1], X, acc, wave, lane, a);
+    else dense_b6<512, 4, RB, 4>(B6.Wb[1], nullptr, X, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_b6<4, RB>(X, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd0) row_sums_b6<RB>(X, sd0, tid);  // X = delta0
+  // d xyz through lin0's xyz columns: 3 x four 128-long f32 chains per ray
+  {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    const float* wx = D.W0x + wave * 128;
+#pragma unroll 4
+    for (int k = 0; k < 128; ++k) {
+      const float d = X[xk<TILE>(wave * 128 + k, ray)];
+      p0 = __builtin_fmaf(wx[k], d, p0);
+      p1 = __builtin_fmaf(wx[HID + k], d, p1);
+      p2 = __builtin_fmaf(wx[2 * HID + k], d, p2);
+    }
+    S.part[(0 * 4 + wave) * TILE + ray] = p0;
+    S.part[(1 * 4 + wave) * TILE + ray] = p1;
+    S.part[(2 * 4 + wave) * TILE + ray] = p2;
+  }
+  __syncthreads();
+  if (tid < 3 * TILE) {
+    const int c = tid / TILE, r = tid % TILE;
+    const float* p = S.part + c * 4 * TILE + r;
+    S.aux[(1 + c) * TILE + r] = S.aux[(1 + c) * TILE + r] + ((p[0] + p[TILE]) + (p[2 * TILE] + p[3 * TILE]));
+  }
+  __syncthreads();
 }
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-bf16 arithmetic
