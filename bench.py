@@ -182,7 +182,7 @@ def main():
                     help='f1 (default, the headline): the seed-defined geometric-init decoder (a smooth blob); f2: the decoder fitted to a '
                          'non-convex shape (torus pierced by a thin plate, tests/golden/fixture_f2.npz) -- a second data point for '
                          'evaluations per ray and the roofline fraction, not the headline metric')
-    ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x6'],
+    ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x6', 'f16x3'],
                     help='f32 (default, the headline): exact f32 decoder evaluations; bf16x6: the opt-in six-product split-bf16 march tiles '
                          '(values within ~1e-6 of the exact ones; reported under its own name, never as the headline metric)')
     ap.add_argument('--no-split-bf16-pass', action='store_true', help='skip the extra, separately reported pass with the opt-in split-bf16 march tiles')
@@ -395,31 +395,56 @@ def main():
         per_step.append(time.perf_counter() - ts)
     median_s = parallel.allreduce_max_scalar(float(np.median(per_step)), device=dev)
 
+    def forward_stats(cfg0):
+        """counters of one forward of every work item of this rank (identical every step: same inputs)"""
+        import ctypes as C
+        p = binding.ptr
+        stats = None
+        for (shape, v, r0, r1) in items:
+            icfg = cfg0 if (r0, r1) == (0, H) else functions.band_cfg(cfg0, r0, r1)[0]
+            n = icfg.band_rows * W
+            fwd_bytes, _ = eng.ctx.workspace_bytes(icfg)
+            ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
+            outs = [torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, device=dev),
+                    torch.empty(n, device=dev), torch.empty(n, 3, device=dev)]
+            Rt, Tt = cams[v]
+            eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(icfg), p(lats[shape].detach().reshape(-1).contiguous()),
+                                                       p(Rt.detach().reshape(-1).contiguous()), p(Tt.detach().contiguous()),
+                                                       p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(),
+                                                       eng.ctx.stream()))
+            st = eng.ctx.render_stats(icfg, ws)
+            stats = st if stats is None else {k: stats[k] + st[k] for k in st}
+        return stats
+
     # ---- extra pass (not part of `value`, reported under its own key): the same K steps with the OPT-IN split-bf16 march tiles
     # (distr_render_cfg.arith = DISTR_ARITH_BF16X6: six bf16 products per f32 product, f32 accumulation; values within ~1e-6 of the
     # exact ones, parity against the reference's goldens at the 1e-4 bar: tests). Same protocol: warm-up, barrier + synchronize on both
     # sides, max over ranks. The headline stays the exact-f32 number above.
-    split_bf16 = None
+    split_modes = {}
     if args.arith == 'f32' and not args.no_split_bf16_pass:
-        cfg_b6 = cfg.clone()
-        cfg_b6.arith = binding.ARITH['bf16x6']
-        cur['cfg'] = cfg_b6
-        for _ in range(max(2, min(args.warmup, 5))):
-            step()
-        torch.cuda.synchronize()
-        parallel.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            tot_b6 = step()
-        torch.cuda.synchronize()
-        el_b6 = time.perf_counter() - t0
-        parallel.barrier()
-        el_b6 = parallel.allreduce_max_scalar(el_b6, device=dev)
-        g_b6 = float(sum(float(g.norm()) for g in last['grads']))
+        for mode in ('bf16x6', 'f16x3'):
+            cfg_m = cfg.clone()
+            cfg_m.arith = binding.ARITH[mode]
+            cur['cfg'] = cfg_m
+            for _ in range(max(2, min(args.warmup, 5))):
+                step()
+            torch.cuda.synchronize()
+            parallel.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tot_m = step()
+            torch.cuda.synchronize()
+            el_m = time.perf_counter() - t0
+            parallel.barrier()
+            el_m = parallel.allreduce_max_scalar(el_m, device=dev)
+            g_m = float(sum(float(g.norm()) for g in last['grads']))
+            split_modes[mode] = {'ms_per_step': 1e3 * el_m / args.steps, 'loss_rank0': float(tot_m.detach()), 'latent_grad_norm_all_ranks': g_m, 'elapsed_s': el_m}
+            if mode == 'f16x3':
+                split_modes[mode]['f16_overflows'] = forward_stats(cfg_m)['f16_overflows']
         cur['cfg'] = cfg
         tot_f32 = step()                                   # back on the exact path (also what the passes below measure)
-        split_bf16 = {'ms_per_step': 1e3 * el_b6 / args.steps, 'loss_rank0': float(tot_b6.detach()), 'loss_rank0_exact_f32': float(tot_f32.detach()),
-                      'latent_grad_norm_all_ranks': g_b6, 'elapsed_s': el_b6}
+        for m in split_modes.values():
+            m['loss_rank0_exact_f32'] = float(tot_f32.detach())
 
     # ---- third pass: roofline of the march kernels. Every march launch is bracketed by hipEvents on the launch stream (the
     # brackets serialise a little, which is why they are not in the timed region); algorithmic FLOP / summed kernel time
@@ -450,24 +475,7 @@ def main():
     Lsplit = image_loss(outs0, r00, r01, (shape0, v0))
     _, bwd_ms = timed(lambda: Lsplit.backward())
 
-    # counters of one forward of every work item of this rank (identical every step: same inputs)
-    import ctypes as C
-    p = binding.ptr
-    stats = None
-    for (shape, v, r0, r1) in items:
-        icfg = cfg if (r0, r1) == (0, H) else functions.band_cfg(cfg, r0, r1)[0]
-        n = icfg.band_rows * W
-        fwd_bytes, _ = eng.ctx.workspace_bytes(icfg)
-        ws = torch.empty(fwd_bytes, dtype=torch.uint8, device=dev)
-        outs = [torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, device=dev),
-                torch.empty(n, device=dev), torch.empty(n, 3, device=dev)]
-        Rt, Tt = cams[v]
-        eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(icfg), p(lats[shape].detach().reshape(-1).contiguous()),
-                                                   p(Rt.detach().reshape(-1).contiguous()), p(Tt.detach().contiguous()),
-                                                   p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(),
-                                                   eng.ctx.stream()))
-        st = eng.ctx.render_stats(icfg, ws)
-        stats = st if stats is None else {k: stats[k] + st[k] for k in st}
+    stats = forward_stats(cfg)
 
     traffic = None
     import glob
@@ -509,19 +517,24 @@ def main():
                        'decoder_evals_per_s_march': evals / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0, 'unit': 'TFLOP/s',
                          'frac': achieved / (PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0), 'traffic': traffic,
-                         'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16-MFMA dense peak; algorithmic FLOP counted once (the six bf16 products per f32 product are not counted six times)',
+                         'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16 / f16 MFMA dense peak; algorithmic FLOP counted once (the six bf16 / three f16 products per f32 product are not counted several times)',
                          'traffic_note': 'fabric-side bytes per march launch from a separate rocprofv3 PMC pass (%s)' % os.path.relpath(tpath, ROOT),
                          'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
                                    % (ROOF_STEPS, launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
         }
-        if split_bf16 is not None:
-            split_bf16.update(value=rays / split_bf16.pop('elapsed_s'), unit='rays/s', speedup_vs_exact_f32=(elapsed / args.steps) / (split_bf16['ms_per_step'] * 1e-3),
-                              note='opt-in arithmetic (distr_render_cfg.arith = 1, `--arith bf16x6`): every f32 product of the seven wide decoder layers '
-                                   'as six bf16 products with f32 accumulation; same workload, same K steps, same timing protocol; NOT the headline '
-                                   '(the headline `value` is exact f32, bit-identical to the oracle). Parity of this mode: reference goldens at the 1e-4 '
-                                   'bar with 0 mask flips (tests/test_gpu_parity.py::test_render_matches_reference_goldens[*-bf16x6]).')
-            out['split_bf16'] = split_bf16
+        notes = {'bf16x6': 'opt-in arithmetic (distr_render_cfg.arith = 1, `--arith bf16x6`): every f32 product of the seven wide decoder layers '
+                           'as six bf16 products with f32 accumulation; same workload, same K steps, same timing protocol; NOT the headline '
+                           '(the headline `value` is exact f32, bit-identical to the oracle). Parity of this mode: reference goldens at the 1e-4 '
+                           'bar with 0 mask flips (tests/test_gpu_parity.py::test_render_matches_reference_goldens[*-bf16x6]).',
+                 'f16x3': 'opt-in arithmetic (distr_render_cfg.arith = 2, `--arith f16x3`): three f16 products per f32 product on two f16 planes per '
+                          'operand (scaled by 64), activations kept as planes in LDS; backward = the split-bf16 dX chain. Limited to decoders '
+                          'whose weights and activations stay below 1023 (checked; f16_overflows must be 0). Same protocol as split_bf16; NOT the headline.'}
+        for mode, key in (('bf16x6', 'split_bf16'), ('f16x3', 'split_f16')):
+            if mode in split_modes:
+                m = split_modes[mode]
+                m.update(value=rays / m.pop('elapsed_s'), unit='rays/s', speedup_vs_exact_f32=(elapsed / args.steps) / (m['ms_per_step'] * 1e-3), note=notes[mode])
+                out[key] = m
         if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)
             out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np, H, MARCH_STEP, args.marcher)
             out['cpu_baseline_torch'] = cpu_baseline_torch(fixture, Ws, bs, latent_np, MARCH_STEP, args.marcher)

@@ -50,14 +50,14 @@ def load_decoder(experiment_directory, checkpoint_num=None, color_size=None, exp
 def decode_sdf(decoder, latent_vector, points, clamp_dist=0.1, MAX_POINTS=100000, no_grad=False, arith='f32'):
     """(n,3) points -> (n,1) SDF, optionally clamped (decoder_utils.py:53-74). Differentiable w.r.t. the latent code and
     the points unless `no_grad` (fused backward: distr_mlp_backward); the decoder weights are frozen. `arith` (not in the
-    reference): 'f32' = exact f32 MFMA (default); 'bf16x6' = six-product split-bf16 arithmetic, forward only, f32-equivalent but
-    not bit-identical (distr_mlp_eval_bf16x6)."""
+    reference): 'f32' = exact f32 MFMA (default); 'bf16x6' / 'f16x3' = split-bf16 / split-f16 arithmetic, forward only, f32-equivalent
+    but not bit-identical (distr_mlp_eval_bf16x6 / distr_mlp_eval_f16x3; the latter needs activations below 1023 and returns NaN otherwise)."""
     if latent_vector is None:
         raise NotImplementedError('latent_vector=None (decoder_utils.py:58-59) is not supported')
     eng = _engine(decoder, points)
     if (not no_grad) and torch.is_grad_enabled() and (latent_vector.requires_grad or points.requires_grad):
         if arith != 'f32':
-            raise NotImplementedError("arith='bf16x6' is forward-only: call decode_sdf(..., no_grad=True)")
+            raise NotImplementedError("arith=%r is forward-only: call decode_sdf(..., no_grad=True)" % arith)
         return functions.mlp_eval_autograd(eng, latent_vector, points, clamp_dist)
     return functions.mlp_eval(eng, latent_vector, points, clamp_dist, arith=arith)
 

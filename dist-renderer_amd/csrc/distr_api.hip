@@ -30,6 +30,8 @@ struct distr_ctx {
   DecoderDev16 D16{};
   DecoderB6 B6{};                   // split-bf16 weight planes of the shape decoder (distr_mlp_eval_bf16x6), own allocation
   uint32_t* dec_buf_b6 = nullptr;
+  DecoderH3 H3{};                   // split-f16 weight planes (distr_mlp_h3.hpp), in the same allocation; h3_ok: the weights fit the f16 range
+  bool h3_ok = false;
   bool has_decoder = false;
   bool profiling = false;
   int hybrid_threshold = 8192;  // t32: largest remainder of a march step (rays) that runs on 32-ray tiles (fine_split)
@@ -152,6 +154,31 @@ void pack_fragments_b6(const float* W, int K, int O, uint16_t* dst) {
         }
 }
 
+// Split-f16 A-fragment planes of v_mfma_f32_32x32x16_f16 (distr_mlp_h3.hpp::dense_h3): SW W = w0 + w1 with w0 = f16(SW W),
+// w1 = f16(SW W - w0) (round to nearest even, denormals kept); fragment index (((kb * 4 + wave) * NOB + ob) * 2 + plane) * 64 + lane
+// holds the 8 f16 W_plane[o][16 kb + 8 h + 0..7]. Returns false when a scaled weight leaves the f16 range.
+bool pack_fragments_h3(const float* W, int K, int O, uint16_t* dst) {
+  const int NOB = O / 128, NKB = K / 16;
+  bool ok = true;
+  for (int kb = 0; kb < NKB; ++kb)
+    for (int w = 0; w < 4; ++w)
+      for (int ob = 0; ob < NOB; ++ob)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int o = w * 32 * NOB + 32 * ob + (lane & 31), h = lane >> 5;
+          for (int i = 0; i < 8; ++i) {
+            const float v = H3_SW * W[(size_t)o * K + 16 * kb + 8 * h + i];
+            if (!(fabsf(v) < 65504.f)) ok = false;
+            const _Float16 h0 = (_Float16)v;
+            const _Float16 h1 = (_Float16)(v - (float)h0);
+            uint16_t pl[2];
+            memcpy(&pl[0], &h0, 2); memcpy(&pl[1], &h1, 2);
+            for (int p = 0; p < 2; ++p)
+              dst[((((((size_t)kb * 4 + w) * NOB + ob) * 2 + p) * 64 + lane) * 8) + i] = pl[p];
+          }
+        }
+  return ok;
+}
+
 struct Carver {
   char* base;
   size_t off = 0;
@@ -178,7 +205,9 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
   if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
-  if (c->arith != DISTR_ARITH_F32 && c->arith != DISTR_ARITH_BF16X6) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown arith %d", c->arith);
+  if (c->arith != DISTR_ARITH_F32 && c->arith != DISTR_ARITH_BF16X6 && c->arith != DISTR_ARITH_F16X3) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown arith %d", c->arith);
+  if (c->arith == DISTR_ARITH_F16X3 && ctx->has_decoder && !ctx->h3_ok)
+    return fail(ctx, DISTR_ERR_UNSUPPORTED, "arith f16x3: a decoder weight times %g leaves the f16 range; use bf16x6 or f32 for this decoder", (double)H3_SW);
   if (c->rows != 0) {
     if (c->rows < 0 || c->row0 < 0 || c->row0 + c->rows > c->H) return fail(ctx, DISTR_ERR_INVALID_ARG, "row band [%d,+%d) outside the %d-row image", c->row0, c->rows, c->H);
     if ((c->row0 & 3) || ((c->rows & 3) && c->row0 + c->rows != c->H))
@@ -405,7 +434,8 @@ const char* distr_last_error(const distr_ctx* ctx) { return ctx ? ctx->err.c_str
 // Packs one DeepSDF-8x512-shaped decoder for the tile kernels. nlat = latent length (the latent columns of lin0 / lin4 are
 // folded into per-call constants, so the tile itself never sees them); nout = rows of lin8 (1: SDF, 3: colour).
 static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, size_t n_floats, float** dev_buf, DecoderDev& D,
-                         DecoderDev16* D16, DecoderB6* B6 = nullptr, uint32_t** dev_buf_b6 = nullptr) {
+                         DecoderDev16* D16, DecoderB6* B6 = nullptr, uint32_t** dev_buf_b6 = nullptr, DecoderH3* H3 = nullptr,
+                         bool* h3_ok = nullptr) {
   const int in0 = nlat + 3, in4 = 256 + nlat;
   const int OUT[9] = {512, 512, 512, 253, 512, 512, 512, 512, nout};
   const int IN[9] = {in0, 512, 512, 512, in4, 512, 512, 512, 512};
@@ -493,6 +523,15 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
       hb.resize(offbt[l] + Wt.size() * 3, 0);
       pack_fragments_b6(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], hb.data() + offbt[l]);
     }
+    size_t offh[8] = {0};
+    if (H3) {   // split-f16 planes of lin1..lin7 (forward only; the backward of that mode is the split-bf16 dX chain): 6.3 MB
+      *h3_ok = true;
+      for (int l = 1; l < 8; ++l) {
+        offh[l] = (hb.size() + 127) & ~(size_t)127;
+        hb.resize(offh[l] + Wp[l].size() * 2, 0);
+        if (!pack_fragments_h3(Wp[l].data(), Kp[l], Op[l], hb.data() + offh[l])) *h3_ok = false;
+      }
+    }
     if (*dev_buf_b6) { HIP_TRY(hipFree(*dev_buf_b6)); *dev_buf_b6 = nullptr; }
     HIP_TRY(hipMalloc((void**)dev_buf_b6, hb.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(*dev_buf_b6, hb.data(), hb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -500,6 +539,10 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
     for (int l = 1; l < 8; ++l) {
       B6->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offb[l]);
       B6->Wb[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offbt[l]);
+    }
+    if (H3) {
+      H3->Wp[0] = nullptr;
+      for (int l = 1; l < 8; ++l) H3->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offh[l]);
     }
   }
   return DISTR_OK;
@@ -511,7 +554,7 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
   if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
                 "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
-  int rc = build_decoder(ctx, LAT, 1, w, n_floats, &ctx->dec_buf, ctx->D, &ctx->D16, &ctx->B6, &ctx->dec_buf_b6);
+  int rc = build_decoder(ctx, LAT, 1, w, n_floats, &ctx->dec_buf, ctx->D, &ctx->D16, &ctx->B6, &ctx->dec_buf_b6, &ctx->H3, &ctx->h3_ok);
   if (rc) return rc;
   ctx->has_decoder = true;
   return DISTR_OK;
@@ -640,7 +683,9 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
   memset(&A, 0, sizeof(A));
   A.V = V;
   A.B6 = ctx->B6;
-  const bool b6 = cfg->arith == DISTR_ARITH_BF16X6;                // split-bf16 tiles: 64- and 32-ray roles only, no cluster tiles
+  A.H3 = ctx->H3;
+  const bool b6 = cfg->arith != DISTR_ARITH_F32;                   // split-bf16 / split-f16 tiles: 64- and 32-ray roles only, no cluster tiles
+  const bool h3 = cfg->arith == DISTR_ARITH_F16X3;
   const bool recursive = cfg->marcher != DISTR_MARCH_TRIVIAL;     // live-ray lists + tile-size split (fine_split)
   const int t32 = ctx->hybrid_threshold, t16 = b6 ? 0 : std::min(ctx->tail16_threshold, ctx->hybrid_threshold);
   A.t16 = recursive ? t16 : 0; A.t32 = recursive ? t32 : 0; A.which = 64;
@@ -666,6 +711,14 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       if (c16) {
         if (V.save_masks) hipLaunchKernelGGL((k_march16<MODE_COARSE, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
         else hipLaunchKernelGGL((k_march16<MODE_COARSE, false>), dim3(tiles), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+      } else if (h3) {
+        if (V.save_masks) {
+          if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+          else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, true, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        } else {
+          if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, false, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+          else hipLaunchKernelGGL((k_march<MODE_COARSE, 2, false, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        }
       } else if (b6) {
         if (V.save_masks) {
           if (crb == 1) hipLaunchKernelGGL((k_march<MODE_COARSE, 1, true, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
@@ -696,7 +749,10 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       // 'trivial': every in-sphere ray, every step, on 64-ray tiles
       A.origin_tile = (st == 0) ? 1 : 0;
       const unsigned tiles = NV * (unsigned)((P + 63) / 64) + (A.origin_tile ? NV : 0u);
-      if (b6) {
+      if (h3) {
+        if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+        else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false, 2>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
+      } else if (b6) {
         if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
         else hipLaunchKernelGGL((k_march<MODE_FINE, 2, false, 1>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
       } else if (V.save_masks) hipLaunchKernelGGL((k_march<MODE_FINE, 2, true>), dim3(tiles), dim3(NTHREADS), 0, s, A, D);
@@ -720,7 +776,10 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       G.n16 = 0;
       A.xc = next_xchg(nullptr, s, false, ctx->max_cl, 0, ctx->min_cl);
       const unsigned grid = (unsigned)(G.n64 + G.n32);
-      if (V.save_masks) hipLaunchKernelGGL((k_step<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+      if (h3) {
+        if (V.save_masks) hipLaunchKernelGGL((k_step<true, 2>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+        else hipLaunchKernelGGL((k_step<false, 2>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
+      } else if (V.save_masks) hipLaunchKernelGGL((k_step<true, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
       else hipLaunchKernelGGL((k_step<false, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
     } else {
       G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
@@ -799,7 +858,7 @@ int render_backward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews
   const bool bsplit = V.save_masks != 0;
   if (bsplit) {
     B.split = 1;
-    if (cfg->arith == DISTR_ARITH_BF16X6) {     // the dX chain in the arithmetic of the forward it differentiates
+    if (cfg->arith != DISTR_ARITH_F32) {        // split arithmetic: the split-bf16 dX chain (also for f16x3: loss gradients have no bounded range)
       hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2, 1>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
       hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
     } else {
@@ -952,6 +1011,27 @@ int distr_mlp_eval_bf16x6(distr_ctx* ctx, const float* latent, const float* xyz,
   return DISTR_OK;
 }
 
+int distr_mlp_eval_f16x3(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float clamp, float* sdf, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (!ctx) return DISTR_ERR_INVALID_ARG;
+  EntryGuard guard_(ctx);
+  if (!ctx->has_decoder) return fail(ctx, DISTR_ERR_NO_DECODER, "distr_set_decoder has not been called");
+  if (!ctx->h3_ok) return fail(ctx, DISTR_ERR_UNSUPPORTED, "f16x3: a decoder weight times %g leaves the f16 range; use bf16x6 or f32 for this decoder", (double)H3_SW);
+  if (n < 0 || (n > 0 && (!xyz || !sdf)) || !latent || !ws) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad argument");
+  if (ws_bytes < distr_mlp_workspace_bytes(n)) return fail(ctx, DISTR_ERR_WORKSPACE, "workspace too small");
+  if (n == 0) return DISTR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* c0c4 = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_latent_consts, dim3(4), dim3(256), 0, s, c0c4, ctx->D, latent);      // (exact f32: the latent columns stay a per-call constant)
+  LAUNCH_CHECK("k_latent_consts");
+  MarchTimer timer(ctx, s);
+  timer.begin();
+  hipLaunchKernelGGL(k_eval_h3, dim3((unsigned)((n + 63) / 64)), dim3(NTHREADS), 0, s, xyz, n, (const float*)c0c4, clamp, sdf, ctx->D, ctx->H3);
+  timer.end();
+  LAUNCH_CHECK("k_eval_h3");
+  return DISTR_OK;
+}
+
 int distr_mlp_grad(distr_ctx* ctx, const float* latent, const float* xyz, int64_t n, float* sdf, float* grad, void* ws,
                    size_t ws_bytes, void* stream) {
   if (!ctx) return DISTR_ERR_INVALID_ARG;
@@ -1063,6 +1143,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   out->num_valid = C->cnt_valid;
   out->num_grad_samples = C->cnt_samples;
   out->cluster_fallbacks = C->xchg_err;
+  out->f16_overflows = C->f16_overflow;
   return DISTR_OK;
 }
 

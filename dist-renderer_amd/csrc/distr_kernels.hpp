@@ -11,6 +11,7 @@
 #pragma once
 #include "distr_mlp.hpp"
 #include "distr_mlp_b6.hpp"
+#include "distr_mlp_h3.hpp"
 #include "../../include/distr.h"
 
 namespace distr {
@@ -39,6 +40,7 @@ struct Consts {
   float red[PSTRIDE];     // backward: reduced tile partials
   int32_t cnt_live[MAX_STEPS + 2];  // live rays entering fine step t (compacted list of that step's launch)
   int32_t cnt_sticky[MAX_STEPS + 2]; // rays evaluated at fine step t by sticky tiles (no list: sticky_tile16); statistics only
+  int32_t f16_overflow;   // split-f16 arithmetic (cfg.arith = 2): decoder evaluations whose value left the f16 range (non-finite result)
 };
 
 struct LevelView {
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float
       C->f_origin = 0.f;
       C->origin_done = 0;
       C->xchg_err = 0;
+      C->f16_overflow = 0;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
     }
   }
@@ -576,6 +579,7 @@ struct MarchArgs {
   int32_t t16, t32, which;
   Xchg xc;                   // 16-ray launches: exchange region of the cluster tiles (buf == null: single-workgroup tiles only)
   DecoderB6 B6;              // split-bf16 weight planes (kernels instantiated with ARITH = 1, distr_render_cfg.arith)
+  DecoderH3 H3;              // split-f16 weight planes (ARITH = 2)
 };
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
@@ -583,9 +587,11 @@ struct MarchArgs {
 // Body of one 32*RB-ray tile; `tile` / `ntile_grid` = index and count of the tiles this launch (or this role of a merged
 // launch, k_step) provides, `which` = the tile size the split rule (fine_range) knows this role by.
 // Returns false when the tile lies beyond this role's range (nothing done).
-// ARITH = 0: exact f32 MFMA tile (distr_mlp.hpp); 1: six-product split-bf16 tile (distr_mlp_b6.hpp, distr_render_cfg.arith)
+// ARITH = 0: exact f32 MFMA tile (distr_mlp.hpp); 1: six-product split-bf16 tile (distr_mlp_b6.hpp); 2: three-product split-f16
+// tile (distr_mlp_h3.hpp)   (distr_render_cfg.arith)
 template <int RB, int ARITH> struct TileSmem { using type = Smem<RB>; };
 template <int RB> struct TileSmem<RB, 1> { using type = SmemB6<RB>; };
+template <int RB> struct TileSmem<RB, 2> { using type = SmemH3<RB>; };
 
 template <int MODE, int RB, bool KEEP, int ARITH = 0>
 __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev& D, typename TileSmem<RB, ARITH>::type& S, int tile, int ntile_grid,
@@ -669,12 +675,18 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   uint32_t masks[8][4];
   float pre;
   if constexpr (ARITH == 0) pre = mlp_forward<RB, KEEP, false, true>(D, c0, c4, S, masks);
-  else pre = mlp_forward_b6<RB, KEEP>(D, A.B6, c0, c4, S, masks);
+  else if constexpr (ARITH == 1) pre = mlp_forward_b6<RB, KEEP>(D, A.B6, c0, c4, S, masks);
+  else pre = mlp_forward_h3<RB, KEEP>(D, A.H3, c0, c4, S, masks);
 
   // epilogue: wave 0 (kept whole for the ballot), lane = ray of the tile; lanes >= TILE are invalid
   int64_t mblock = -1;   // mask block this ray's row goes to (KEEP), -1: row not kept
   if (tid < 64) {
     const float s = tanh_spec(pre);
+    if constexpr (ARITH == 2 && MODE != MODE_EVAL) {
+      // an activation left the f16 range (non-finite result): counted, not hidden by the clamps below (one wave-uniform test per tile)
+      const unsigned long long bad = __ballot((valid || origin) && !(fabsf(pre) <= 3.0e38f));
+      if (bad != 0ull && tid == 0) atomicAdd(&V.C->f16_overflow, (int)__popcll(bad));
+    }
     if (origin) {
       if (tid == 0) V.C->f_origin = s;
     } else if (MODE == MODE_EVAL) {

@@ -1,0 +1,277 @@
+// distr_mlp_h3.hpp -- the DeepSDF 8x512 decoder tile in THREE-PRODUCT SPLIT-f16 arithmetic (opt-in), forward.
+//
+// Same network, same tile geometry and the same place in the march kernels as the six-product split-bf16 tile
+// (distr_mlp_b6.hpp); what differs is the number format of the planes:
+//     SW W = w0 + w1,  SX x = a0 + a1   (f16 planes of the SCALED operands, round to nearest even of the running remainder)
+//     W x ~ (w0 a0 + w1 a0 + w0 a1) / (SW SX)             on v_mfma_f32_32x32x16_f16, f32 accumulation
+// An f16 plane carries 11 significant bits, two planes 22, and the dropped product w1 a1 is 2^-22 of w0 a0 -- the size of the f32
+// chain's own rounding. Measured on both fixture decoders (oracle/study_split_bf16.py, CPU restatement, 20 000 points against a
+// float64 decoder): max |sdf - sdf_f64| 3.5e-7 for this form, 3.0e-7 for the exact f32 chain, 3.0e-7 for six bf16 products, 7.9e-6
+// for three bf16 products. Three MFMAs per f32 product instead of six, and -- because two f16 planes of a 512 x 64 activation tile
+// are 128 KiB, the size of the f32 tile -- the planes themselves live in LDS: the split is done ONCE by the wave that produces a
+// value (write-back), not by each of the four waves that consume it, and the k-loop has no VALU work at all. The weight stream is
+// two f16 planes = the bytes of f32 (the bf16 form streams 1.5 x). profiles/ubench/split_f16_layer.hip: 34.3 k cycles per
+// 512 x 512 layer on a 64-ray tile (bf16x6 66.4 k, exact f32 133.7 k).
+//
+// What f16 costs is RANGE (5 exponent bits): a scaled operand beyond 65504 becomes inf. SX = SW = 64 keeps the second planes of
+// this network's magnitudes (activations 1e-3 .. 1, weights ~ 0.05) above the f16 denormals and allows |x|, |W| < 1023;
+// weights outside that range make the mode unavailable for the decoder (distr_set_decoder notes it, the calls that ask for the
+// mode fail), and an activation that overflows turns the evaluation's result non-finite, which the tiles COUNT
+// (Consts.f16_overflow -> distr_render_stats.f16_overflows; distr_mlp_eval_f16x3 writes NaN for the point) instead of hiding it
+// behind the clamps of the march.
+// The backward of a render in this mode is the split-bf16 dX chain (mlp_backward_b6: per-ray loss gradients have no bounded
+// range, bf16 planes keep f32's exponent) on the ReLU masks this forward saved -- the mask format is common to all three tiles.
+#pragma once
+#include "distr_mlp_b6.hpp"
+
+namespace distr {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float H3_SX = 64.f, H3_SW = 64.f;      // powers of two: every rescale below is exact
+
+struct DecoderH3 {
+  const uint32_t* Wp[8];   // two f16 A-fragment planes of SW * lin1..lin7 ([0] unused); lin3: O padded to 256; lin4: K = 256
+};
+
+template <int RB>
+struct alignas(16) SmemH3 {
+  static constexpr int TILE = 32 * RB;
+  uint16_t P[2][HID * TILE];   // the two f16 planes of SX * activation, k-minor: P[p][k >> 3][ray][k & 7]
+  float xyz[4 * TILE];
+  float part[12 * TILE];       // lin8 partial chains [4][TILE]
+  float aux[4 * TILE];         // march tiles (KEEP): the rays' mask-block indices (8 bytes each)
+};
+static_assert(sizeof(SmemH3<2>) == sizeof(SmemB6<2>) && sizeof(SmemH3<1>) == sizeof(SmemB6<1>), "the tiles share k_step's role buffer");
+
+// {f16(a) low half, f16(b) high half} of the value and of its remainder (v_cvt_pk_f16_f32, v_cvt_f32_f16, v_sub_f32)
+__device__ __forceinline__ void split2_f16(float a, float b, uint32_t& p0, uint32_t& p1) {
+  const f32x2 v = {a, b};
+  const f16x2 h0 = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h0, f32x2);
+  const f16x2 h1 = __builtin_convertvector(r, f16x2);
+  p0 = __builtin_bit_cast(uint32_t, h0);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+}
+// four consecutive features of one ray -> one 8-byte store per plane
+template <int TILE>
+__device__ __forceinline__ void store4_h3(uint16_t (&P)[2][HID * TILE], int row, int ray, float v0, float v1, float v2, float v3) {
+  u32x2 p0, p1;
+  uint32_t t0, t1;
+  split2_f16(v0, v1, t0, t1); p0[0] = t0; p1[0] = t1;
+  split2_f16(v2, v3, t0, t1); p0[1] = t0; p1[1] = t1;
+  *reinterpret_cast<u32x2*>(&P[0][xk<TILE>(row, ray)]) = p0;
+  *reinterpret_cast<u32x2*>(&P[1][xk<TILE>(row, ray)]) = p1;
+}
+
+// weight fragments of one 16-feature block: 2 planes x NOB row blocks, one 16-byte load each (buffers are sized for NOB = 4)
+template <int NOB>
+__device__ __forceinline__ void load_a_h3(const uint32_t* __restrict__ Wp, int kb, int wave, int lane, u32x4 (&dst)[4][2]) {
+  const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)wave * NOB * 2 * 64 + lane;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * NOB + ob) * 2 + p) * 64];
+}
+
+// acc[ob][rb] (started by the caller, in units of SW SX) += (SW W)[rows of this wave][0..K) x (SX X)[0..K)[rays], three f16 products
+// per f32 product. Register double buffer as in dense_b6 (block kb + 1 requested before the MFMAs of block kb; `a` = this layer's
+// block 0 on entry, the next layer's on return), with nothing but loads and MFMAs in the loop.
+template <int K, int NOB, int RB, int NOBN>
+__device__ __forceinline__ void dense_h3(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const uint16_t (&P)[2][HID * 32 * RB],
+                                         f32x16 (&acc)[NOB][RB], int wave, int lane, u32x4 (&a)[4][2]) {
+  constexpr int NKB = K / 16, TILE = 32 * RB;
+  const int j = lane & 31, h = lane >> 5;
+  constexpr int PW[3] = {0, 1, 0}, PA[3] = {0, 0, 1};     // (weight plane, activation plane) of the three products
+  u32x4 b[RB][2];
+  auto load_b = [&](u32x4 (&dst)[RB][2], int kb) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) dst[rb][p] = *reinterpret_cast<const u32x4*>(&P[p][xk<TILE>(16 * kb + 8 * h, 32 * rb + j)]);
+  };
+  load_b(b, 0);
+#pragma unroll 2
+  for (int kb = 0; kb < NKB; ++kb) {
+    u32x4 an[4][2], bn[RB][2];
+    const bool last = (kb + 1 == NKB);
+    if (!last) load_a_h3<NOB>(Wp, kb + 1, wave, lane, an);
+    else if (WpNext) load_a_h3<NOBN>(WpNext, 0, wave, lane, an);
+    load_b(bn, last ? kb : kb + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ob][PW[q]]), __builtin_bit_cast(f16x8, b[rb][PA[q]]),
+                                                               acc[ob][rb], 0, 0, 0);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a[ob][p] = an[ob][p];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) b[rb][p] = bn[rb][p];
+  }
+}
+
+// ReLU, rescale (acc = SW SX y -> SX relu(y)), split into the two planes, write back. KEEP: mask bits in the common format
+// (distr_mlp.hpp::writeback: bit (rb * 16 + r) of mask[ob] = value > 0).
+template <int NOB, int RB, bool KEEP>
+__device__ __forceinline__ void writeback_h3(uint16_t (&P)[2][HID * 32 * RB], const f32x16 (&acc)[NOB][RB], int row0, int lane, uint32_t (&mask)[4]) {
+  constexpr int TILE = 32 * RB;
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int32_t rbits = max(__float_as_int(acc[ob][rb][4 * q + i]), 0);
+          v[i] = __int_as_float(rbits) * (1.0f / H3_SW);
+          if (KEEP) m |= min((uint32_t)rbits, 1u) << (rb * 16 + 4 * q + i);
+        }
+        store4_h3<TILE>(P, row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[0], v[1], v[2], v[3]);
+      }
+    if (KEEP) {
+      asm volatile("" : "+v"(m));
+      mask[ob] = m;
+    }
+  }
+}
+
+template <int K, int NOB, int RB, bool KEEP, int NOBN>
+__device__ __forceinline__ void layer_h3(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const float* __restrict__ bias, int nbias,
+                                         uint16_t (&P)[2][HID * 32 * RB], int wave, int lane, uint32_t (&mask)[4], u32x4 (&a)[4][2]) {
+  const int h = lane >> 5;
+  f32x16 acc[NOB][RB];
+  const int row0 = wave * 32 * NOB;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float bv = (row < nbias) ? bias[row] * (H3_SW * H3_SX) : 0.f;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[ob][rb][r] = bv;
+    }
+  dense_h3<K, NOB, RB, NOBN>(Wp, WpNext, P, acc, wave, lane, a);
+  __syncthreads();                         // everybody is done reading the layer input
+  writeback_h3<NOB, RB, KEEP>(P, acc, row0, lane, mask);
+  __syncthreads();
+}
+
+// Preconditions and results as mlp_forward_b6. A non-finite result (an activation left the f16 range) is returned as it is: the
+// callers test it.
+template <int RB, bool KEEP>
+__device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const DecoderH3& H3, const float* __restrict__ c0, const float* __restrict__ c4,
+                                                SmemH3<RB>& S, uint32_t (&masks)[8][4]) {
+  constexpr int TILE = 32 * RB;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int j = lane & 31, h = lane >> 5;
+  // lin0 (K = 3): the f32 fmaf chain of the exact tile in the accumulator layout of the wide layers, written as planes
+  {
+    float px[RB], py[RB], pz[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { px[rb] = S.xyz[32 * rb + j]; py[rb] = S.xyz[TILE + 32 * rb + j]; pz[rb] = S.xyz[2 * TILE + 32 * rb + j]; }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      uint32_t m = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[RB][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wave * 128 + 32 * ob + 8 * q + 4 * h + i;
+          const float b0 = c0[row], wx = D.W0x[row], wy = D.W0x[HID + row], wz = D.W0x[2 * HID + row];
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            float t = __builtin_fmaf(wx, px[rb], b0);
+            t = __builtin_fmaf(wy, py[rb], t);
+            t = __builtin_fmaf(wz, pz[rb], t);
+            const int32_t rbits = max(__float_as_int(t), 0);
+            v[rb][i] = __int_as_float(rbits) * H3_SX;
+            if (KEEP) m |= min((uint32_t)rbits, 1u) << (rb * 16 + 4 * q + i);
+          }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) store4_h3<TILE>(S.P, wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[rb][0], v[rb][1], v[rb][2], v[rb][3]);
+      }
+      if (KEEP) {
+        asm volatile("" : "+v"(m));
+        masks[0][ob] = m;
+      }
+    }
+  }
+  __syncthreads();
+  u32x4 a[4][2];                           // first weight block of the next layer, travelling across the write-backs
+  load_a_h3<4>(H3.Wp[1], 0, wave, lane, a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[1], H3.Wp[2], D.bias[1], HID, S.P, wave, lane, masks[1], a);
+  layer_h3<512, 4, RB, KEEP, 2>(H3.Wp[2], H3.Wp[3], D.bias[2], HID, S.P, wave, lane, masks[2], a);
+  masks[3][2] = 0; masks[3][3] = 0;
+  layer_h3<512, 2, RB, KEEP, 4>(H3.Wp[3], H3.Wp[4], D.bias[3], 253, S.P, wave, lane, masks[3], a);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
+  if (tid < 3 * TILE) {                    // rows 253..255 <- SX * xyz (signed), as planes
+    const _Float16 h0 = (_Float16)(S.xyz[tid] * H3_SX);
+    const _Float16 h1 = (_Float16)(S.xyz[tid] * H3_SX - (float)h0);
+    S.P[0][xk<TILE>(253 + tid / TILE, tid % TILE)] = __builtin_bit_cast(uint16_t, h0);
+    S.P[1][xk<TILE>(253 + tid / TILE, tid % TILE)] = __builtin_bit_cast(uint16_t, h1);
+  }
+  __syncthreads();
+  layer_h3<256, 4, RB, KEEP, 4>(H3.Wp[4], H3.Wp[5], c4, HID, S.P, wave, lane, masks[4], a);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[5], H3.Wp[6], D.bias[5], HID, S.P, wave, lane, masks[5], a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[6], H3.Wp[7], D.bias[6], HID, S.P, wave, lane, masks[6], a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[7], nullptr, D.bias[7], HID, S.P, wave, lane, masks[7], a);
+  // lin8: four 128-long f32 chains per ray (one per wave) on x7 = (a0 + a1) / SX (the sum of the planes is exact in f32),
+  // combined in the exact tile's order
+  const int ray = tid & (TILE - 1);
+  {
+    float p = 0.f;
+    const float* w8 = D.w8 + wave * 128;
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) {
+      const int i = xk<TILE>(wave * 128 + k, ray);
+      const float x = ((float)__builtin_bit_cast(_Float16, S.P[0][i]) + (float)__builtin_bit_cast(_Float16, S.P[1][i])) * (1.0f / H3_SX);
+      p = __builtin_fmaf(w8[k], x, p);
+    }
+    S.part[wave * TILE + ray] = p;
+  }
+  __syncthreads();
+  return ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+}
+
+// decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-f16 arithmetic; a point whose evaluation left the
+// f16 range gets NaN (not a clamped number)
+__global__ void __launch_bounds__(256, 1) k_eval_h3(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
+                                                    float* __restrict__ sdf, DecoderDev D, DecoderH3 H3) {
+  __shared__ SmemH3<2> S;
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * 64;
+  if (base >= n) return;
+  if (tid < 64) {
+    const int64_t r = base + tid;
+    const bool v = r < n;
+    S.xyz[tid] = v ? xyz[r * 3] : 0.f; S.xyz[64 + tid] = v ? xyz[r * 3 + 1] : 0.f; S.xyz[128 + tid] = v ? xyz[r * 3 + 2] : 0.f;
+  }
+  __syncthreads();
+  uint32_t masks[8][4];
+  const float pre = mlp_forward_h3<2, false>(D, H3, c0c4, c0c4 + HID, S, masks);
+  if (tid < 64 && base + tid < n) {
+    const float s = tanh_spec(pre);
+    const bool finite = fabsf(pre) <= 3.0e38f;
+    sdf[base + tid] = !finite ? __builtin_nanf("") : (clamp >= 0.f) ? clampf(s, -clamp, clamp) : s;
+  }
+}
+
+}  // namespace distr

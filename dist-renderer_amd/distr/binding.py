@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, '..', 'csrc')
 LIB_PATH = os.path.abspath(os.path.join(CSRC, 'libdistr.so'))
 
 MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
-ARITH = {'f32': 0, 'bf16x6': 1}
+ARITH = {'f32': 0, 'bf16x6': 1, 'f16x3': 2}
 EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
            'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
@@ -24,7 +24,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_loss_workspace_bytes', 'distr_single_loss_forward', 'distr_single_loss_backward',
            'distr_warp_loss_forward', 'distr_warp_loss_backward', 'distr_set_color_decoder', 'distr_color_eval', 'distr_debug_xchg_ts', 'distr_mlp_backward_workspace_bytes', 'distr_mlp_backward',
            'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
-           'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6']
+           'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6', 'distr_mlp_eval_f16x3']
 
 MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
 VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
@@ -82,12 +82,12 @@ def make_warp_cfg(img_hw, intrinsic, thres_depth):
 
 class RenderStats(C.Structure):
     _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
-                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64)]
+                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64), ('f16_overflows', C.c_int64)]
 
 
 def build_library(force=False, verbose=False):
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
-    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
+    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_mlp_h3.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -135,6 +135,7 @@ def lib():
             L.distr_mlp_workspace_bytes.restype = C.c_size_t
             L.distr_mlp_eval.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
             L.distr_mlp_eval_bf16x6.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
+            L.distr_mlp_eval_f16x3.argtypes = [vp, fp, fp, C.c_int64, C.c_float, fp, vp, C.c_size_t, vp]
             L.distr_mlp_grad.argtypes = [vp, fp, fp, C.c_int64, fp, fp, vp, C.c_size_t, vp]
             L.distr_debug_mlp_layer.argtypes = [vp, fp, fp, C.c_int64, C.c_int, fp, vp, C.c_size_t, vp]
             L.distr_debug_tile_timing.argtypes = [vp, fp, fp, C.c_int64, fp, vp, vp, C.c_size_t, vp]
@@ -193,7 +194,7 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
         cfg.row0, cfg.rows = int(band[0]), int(band[1])
     if arith not in ARITH:
         raise ValueError("arith must be one of %s" % sorted(ARITH))
-    cfg.arith = ARITH[arith]     # 'f32': exact (default); 'bf16x6': six-product split-bf16 march tiles (DISTR_ARITH_BF16X6)
+    cfg.arith = ARITH[arith]     # 'f32': exact (default); 'bf16x6' / 'f16x3': split-bf16 / split-f16 march tiles (DISTR_ARITH_*)
     return cfg
 
 

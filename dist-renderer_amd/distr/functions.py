@@ -393,9 +393,11 @@ def render_normal_call(engine, cfg, latent, R, T, zdepth, mask):
 
 def mlp_eval(engine, latent, points, clamp_dist=None, arith='f32'):
     """decode_sdf forward (core/utils/decoder_utils.py:53-74): points (n,3) -> (n,1). arith='f32' (default): exact f32 MFMA, bit-identical
-    to the oracle; 'bf16x6': six-product split-bf16 arithmetic (distr_mlp_eval_bf16x6: f32-equivalent accuracy, faster, not bit-identical)."""
-    if arith not in ('f32', 'bf16x6'):
-        raise ValueError("arith must be 'f32' or 'bf16x6'")
+    to the oracle; 'bf16x6': six-product split-bf16 arithmetic (distr_mlp_eval_bf16x6: f32-equivalent accuracy, faster, not bit-identical);
+    'f16x3': three-product split-f16 arithmetic (distr_mlp_eval_f16x3: the same for decoders inside the f16 range, faster again; NaN
+    for a point whose activations leave that range)."""
+    if arith not in binding.ARITH:
+        raise ValueError("arith must be one of %s" % sorted(binding.ARITH))
     dev = engine.device
     lat = _f32c(latent, dev).reshape(-1)
     x = _f32c(points, dev).reshape(-1, 3)
@@ -403,7 +405,7 @@ def mlp_eval(engine, latent, points, clamp_dist=None, arith='f32'):
     out = torch.empty(n, 1, dtype=torch.float32, device=dev)
     ws = torch.empty(engine.ctx.L.distr_mlp_workspace_bytes(n), dtype=torch.uint8, device=dev)
     p = binding.ptr
-    fn = engine.ctx.L.distr_mlp_eval if arith == 'f32' else engine.ctx.L.distr_mlp_eval_bf16x6
+    fn = {'f32': engine.ctx.L.distr_mlp_eval, 'bf16x6': engine.ctx.L.distr_mlp_eval_bf16x6, 'f16x3': engine.ctx.L.distr_mlp_eval_f16x3}[arith]
     engine.ctx.check(fn(engine.ctx.h, p(lat), p(x), n, -1.0 if clamp_dist is None else float(clamp_dist), p(out), p(ws), ws.numel(),
                         engine.ctx.stream()))
     return out

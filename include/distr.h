@@ -38,6 +38,9 @@ extern "C" {
 
 #define DISTR_ARITH_F32 0    /* exact f32 MFMA (default): bit-identical to a k-ordered fmaf chain */
 #define DISTR_ARITH_BF16X6 1 /* six-product split-bf16 (opt-in): f32-equivalent accuracy, ~1.6x the dense rate, not bit-identical */
+#define DISTR_ARITH_F16X3 2  /* three-product split-f16 (opt-in): f32-equivalent accuracy for decoders whose weights and activations stay
+                                below 1023 in magnitude (f16 range after the x64 scaling; checked: DISTR_ERR_UNSUPPORTED for the weights,
+                                distr_render_stats.f16_overflows / NaN for activations), not bit-identical */
 
 #define DISTR_MAX_BUFFER_SIZE 8
 #define DISTR_MAX_VIEWS 64 /* views per batched render (distr_render_forward_batch) */
@@ -97,7 +100,9 @@ typedef struct distr_render_cfg {
                                  one arithmetic: f32). 0 (default, also what a zeroed struct selects): exact f32. 1: every f32 product of
                                  the seven wide layers as six bf16 products with f32 accumulation (csrc/distr_mlp_b6.hpp): values within
                                  ~1e-6 of the exact ones, on 64- / 32-ray tiles only (no cluster tiles: meant for large, dense renders). The
-                                 backward pass is the exact dX chain on the ReLU masks this forward saved. */
+                                 backward pass is the split-bf16 dX chain on the ReLU masks this forward saved. 2: three f16 products per f32
+                                 product with the activations kept as two f16 planes in LDS (csrc/distr_mlp_h3.hpp): same accuracy class and
+                                 tile set as 1 for decoders inside the f16 range (see DISTR_ARITH_F16X3), backward = that of mode 1. */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */
@@ -110,6 +115,8 @@ typedef struct distr_render_stats {
   int64_t cluster_fallbacks;  /* cluster tiles (16 rays split over 8 / 4 compute units) whose workgroups were not co-resident in time
                                  (compute units held by other streams / ranks) or whose barrier timed out: the tile's lead workgroup
                                  evaluated it alone instead -- same values bit for bit, only slower. 0 on an otherwise idle GPU. */
+  int64_t f16_overflows;      /* arith = DISTR_ARITH_F16X3 only: decoder evaluations of the march whose result was not finite because an
+                                 activation left the f16 range. Anything but 0 means the render is not to be trusted: use arith 1 or 0. */
 } distr_render_stats;
 
 int distr_create(distr_ctx** out, int hip_device);
@@ -195,6 +202,12 @@ int distr_mlp_eval(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev
  * Used by the bulk SDF grid evaluation for meshing (core/evaluation/create_mesh.py: create_sdf_grid(..., arith='bf16x6')). */
 int distr_mlp_eval_bf16x6(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float clamp_dist,
                           float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* decode_sdf in THREE-PRODUCT SPLIT-f16 arithmetic (opt-in, DISTR_ARITH_F16X3): two f16 planes per operand (scaled by 64), three
+ * products per f32 product on v_mfma_f32_32x32x16_f16, activations kept as planes in LDS. Same accuracy class as the bf16 form at
+ * half its MFMA work; limited to decoders whose weights and activations stay below 1023 in magnitude: DISTR_ERR_UNSUPPORTED when a
+ * weight does not, NaN in sdf_dev for a point one of whose activations does not. Same arguments as distr_mlp_eval. */
+int distr_mlp_eval_f16x3(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float clamp_dist,
+                         float* sdf_dev, void* ws_dev, size_t ws_bytes, void* stream);
 int distr_mlp_grad(distr_ctx* ctx, const float* latent_dev, const float* xyz_dev, int64_t n, float* sdf_dev,
                    float* grad_dev, void* ws_dev, size_t ws_bytes, void* stream);
 /* Backward of decode_sdf for callers that differentiate through it (decoder_utils.py:53-74 without no_grad): g_sdf[n] is

@@ -1,0 +1,211 @@
+// Microbenchmark: one 512 x 512 decoder layer on a 64-ray tile as THREE f16 products per f32 product, with the split done ONCE by
+// the producer (write-back) instead of by every consumer wave:
+//
+//   y = W x,  W = (w0 + w1) / SW,  x = (a0 + a1) / SX   (f16 planes of the scaled operands; SW, SX powers of two so that the
+//   second planes stay out of the f16 denormals for this decoder's magnitudes),   y ~ (a0 w0 + a0 w1 + a1 w0) / (SW SX)
+//
+// Why it can be f32-equivalent with 3 products where bf16 needs 6: an f16 plane carries 11 significant bits, two planes 22, and the
+// dropped product a1 w1 is 2^-22 of a0 w0 -- the size of the f32 chain's own rounding (oracle study on the CPU restatement: max
+// |sdf - sdf_f64| 3.5e-7 for this form, 3.0e-7 for the f32 chain, 3.0e-7 for six bf16 products, 7.9e-6 for three bf16 products).
+// Two f16 planes of a 512 x 64 activation tile are 128 KiB -- the size of the f32 tile -- so the planes live in LDS and the k-loop has
+// no VALU work at all; the weights are two f16 planes = the bytes of f32 (the bf16 form streams 1.5 x).
+// What f16 costs: range. Scaled operands must stay below 65504 (|x| < 1023 at SX = 64); a product path would check that.
+// The harness is split_bf16_layer.hip's (same tile, same stream sizes, numerics of one layer against float64, whole chip timing).
+// Build: hipcc -O3 --offload-arch=gfx950 split_f16_layer.hip -o split_f16_layer
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HID = 512, TILE = 64, LAYERS = 8;
+constexpr float SX = 64.f, SW = 64.f;
+
+// plane layout in LDS, k-minor: P[k >> 3][ray][k & 7] f16 -> the 8 k-values a lane feeds to one MFMA are 16 contiguous bytes
+__device__ __host__ __forceinline__ int xidx(int k, int ray) { return ((k >> 3) * TILE + ray) * 8 + (k & 7); }
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t& p0, uint32_t& p1) {
+  const f32x2 v = {a, b};
+  const f16x2 h0 = __builtin_convertvector(v, f16x2);
+  const f32x2 r = v - __builtin_convertvector(h0, f32x2);
+  const f16x2 h1 = __builtin_convertvector(r, f16x2);
+  p0 = __builtin_bit_cast(uint32_t, h0);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+}
+
+// EXP bit 1: every block re-reads the layer's block 0 (no weight stream: all hits in the CU's L1)
+template <int EXP>
+__global__ void __launch_bounds__(256, 1) k_layers(const uint32_t* __restrict__ Wp, const uint16_t* __restrict__ x0, float* __restrict__ y_out,
+                                                   long long* __restrict__ cyc, int tiles, int layers) {
+  __shared__ __attribute__((aligned(16))) uint16_t P[2][HID * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  long long tsum = 0;
+  for (int t = 0; t < tiles; ++t) {
+    for (int i = tid; i < 2 * HID * TILE; i += 256) (&P[0][0])[i] = x0[i];
+    __syncthreads();
+    const long long c0 = __builtin_readcyclecounter();
+    for (int l = 0; l < layers; ++l) {
+      f32x16 acc[4][2];
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+      // per block of 16 features, lane (i, h) holds 8 f16 W_plane[o][16 kb + 8 h + 0..7] per (row block, plane)
+      const u32x4* wp = reinterpret_cast<const u32x4*>(Wp) + (size_t)l * (HID / 16) * 4 * 4 * 2 * 64 + (size_t)wave * 4 * 2 * 64 + lane;
+      constexpr int PW[3] = {0, 1, 0}, PA[3] = {0, 0, 1};     // w0a0 w1a0 w0a1
+      u32x4 a[4][2], b[2][2];
+      auto load_a = [&](u32x4 (&dst)[4][2], int kb) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * 4 + ob) * 2 + p) * 64];
+      };
+      auto load_b = [&](u32x4 (&dst)[2][2], int kb) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) dst[rb][p] = *reinterpret_cast<const u32x4*>(&P[p][xidx(16 * kb + 8 * h, 32 * rb + j)]);
+      };
+      load_a(a, 0);
+      load_b(b, 0);
+#pragma unroll 2
+      for (int kb = 0; kb < HID / 16; ++kb) {
+        u32x4 an[4][2], bn[2][2];
+        const int kn = (kb + 1 < HID / 16) ? kb + 1 : kb;
+        load_a(an, (EXP & 2) ? 0 : kn);
+        load_b(bn, kn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+              acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ob][PW[q]]), __builtin_bit_cast(f16x8, b[rb][PA[q]]),
+                                                                   acc[ob][rb], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) a[ob][p] = an[ob][p];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[rb][p] = bn[rb][p];
+      }
+      __syncthreads();
+      // write-back: ReLU, rescale to the planes' unit (acc = SW SX y -> SX relu(y) / 16; the 1/16 keeps 8 random layers bounded, as in
+      // split_bf16_layer.hip), split ONCE into the two planes. D rows of register r on lane (j, h): (r & 3) + 8 (r >> 2) + 4 h ->
+      // 4 consecutive k = one 8-byte store per plane
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[ob][rb][4 * q + i], 0.f) * (1.0f / (16.0f * SW));
+            u32x2 p0, p1;
+            uint32_t t0, t1;
+            split2(v[0], v[1], t0, t1); p0[0] = t0; p1[0] = t1;
+            split2(v[2], v[3], t0, t1); p0[1] = t0; p1[1] = t1;
+            const int row = wave * 128 + 32 * ob + 8 * q + 4 * h;
+            *reinterpret_cast<u32x2*>(&P[0][xidx(row, 32 * rb + j)]) = p0;
+            *reinterpret_cast<u32x2*>(&P[1][xidx(row, 32 * rb + j)]) = p1;
+          }
+      __syncthreads();
+    }
+    tsum += __builtin_readcyclecounter() - c0;
+  }
+  if (tid == 0) cyc[blockIdx.x] = tsum;
+  if (blockIdx.x == 0)
+    for (int i = tid; i < HID * TILE; i += 256)
+      y_out[i] = ((float)__builtin_bit_cast(_Float16, P[0][i]) + (float)__builtin_bit_cast(_Float16, P[1][i])) * (1.0f / SX);
+}
+
+static inline uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static inline float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+int main() {
+  const int NWG = 256;
+  std::vector<float> W((size_t)LAYERS * HID * HID);
+  uint32_t s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.0f; };
+  for (auto& w : W) { float u1 = rnd() + 1e-6f, u2 = rnd(); w = sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2) * sqrtf(2.0f / HID); }
+  std::vector<float> xk((size_t)HID * TILE);                    // x[k][ray]
+  for (auto& v : xk) v = rnd();
+  std::vector<uint16_t> xp((size_t)2 * HID * TILE);             // the two planes of SX x
+  for (int k = 0; k < HID; ++k) for (int r = 0; r < TILE; ++r) {
+    const float v = SX * xk[(size_t)k * TILE + r];
+    const uint16_t p0 = f2h(v), p1 = f2h(v - h2f(p0));
+    xp[xidx(k, r)] = p0; xp[(size_t)HID * TILE + xidx(k, r)] = p1;
+  }
+  std::vector<uint16_t> Wb((size_t)LAYERS * HID * HID * 2);     // two f16 planes of SW W, fragment order
+  for (int l = 0; l < LAYERS; ++l) {
+    const float* Wl = &W[(size_t)l * HID * HID];
+    for (int kb = 0; kb < HID / 16; ++kb) for (int w = 0; w < 4; ++w) for (int ob = 0; ob < 4; ++ob) for (int lane = 0; lane < 64; ++lane) {
+      const int o = w * 128 + 32 * ob + (lane & 31), h = lane >> 5;
+      for (int i = 0; i < 8; ++i) {
+        const float v = SW * Wl[(size_t)o * HID + 16 * kb + 8 * h + i];
+        const uint16_t p0 = f2h(v), p1 = f2h(v - h2f(p0));
+        const uint16_t pl[2] = {p0, p1};
+        for (int p = 0; p < 2; ++p)
+          Wb[(size_t)l * HID * HID * 2 + ((((((size_t)kb * 4 + w) * 4 + ob) * 2 + p) * 64 + lane) * 8) + i] = pl[p];
+      }
+    }
+  }
+  float* dy; uint16_t *dWb, *dx; long long* dcyc;
+  (void)hipMalloc(&dWb, Wb.size() * 2); (void)hipMalloc(&dx, xp.size() * 2); (void)hipMalloc(&dy, xk.size() * 4);
+  (void)hipMalloc(&dcyc, NWG * sizeof(long long));
+  (void)hipMemcpy(dWb, Wb.data(), Wb.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dx, xp.data(), xp.size() * 2, hipMemcpyHostToDevice);
+  std::vector<double> ref((size_t)HID * TILE);
+  for (int o = 0; o < HID; ++o) for (int r = 0; r < TILE; ++r) {
+    double a = 0; for (int k = 0; k < HID; ++k) a += (double)W[(size_t)o * HID + k] * (double)xk[(size_t)k * TILE + r];
+    ref[(size_t)o * TILE + r] = (a > 0 ? a : 0) / 16.0;
+  }
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  auto run = [&](int exp, const char* name) {
+    auto launch = [&](int tiles, int layers) {
+      if (exp == 0) hipLaunchKernelGGL(k_layers<0>, dim3(NWG), dim3(256), 0, 0, (const uint32_t*)dWb, dx, dy, dcyc, tiles, layers);
+      else hipLaunchKernelGGL(k_layers<2>, dim3(NWG), dim3(256), 0, 0, (const uint32_t*)dWb, dx, dy, dcyc, tiles, layers);
+    };
+    launch(1, 1); (void)hipDeviceSynchronize();
+    std::vector<float> y(xk.size()); (void)hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost);
+    double emax = 0, rmax = 0;
+    for (int o = 0; o < HID; ++o) for (int r = 0; r < TILE; ++r) {
+      const double got = y[xidx(o, r)], want = ref[(size_t)o * TILE + r];
+      emax = fmax(emax, fabs(got - want)); rmax = fmax(rmax, fabs(want));
+    }
+    const int tiles = 16;
+    double best_ms = 1e9; double cyc_layer = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipEventRecord(e0); launch(tiles, LAYERS); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      long long hc[NWG]; (void)hipMemcpy(hc, dcyc, sizeof(hc), hipMemcpyDeviceToHost);
+      double c = 0; for (int i = 0; i < NWG; ++i) c += (double)hc[i];
+      if (rep > 0 && ms < best_ms) { best_ms = ms; cyc_layer = c / NWG / tiles / LAYERS; }
+    }
+    const double flop = 2.0 * HID * HID * TILE * LAYERS * (double)tiles * NWG;
+    printf("%-28s max |err| vs float64 (one layer) %.3e (rel %.2e)   %8.0f cycles / 512x512 layer / tile (MFMA-only bound 24576)   %7.3f ms "
+           "(%.2f GHz) = %6.1f TFLOP/s-equivalent\n", name, emax, emax / rmax, cyc_layer, best_ms, cyc_layer * tiles * LAYERS / best_ms / 1e6,
+           flop / best_ms / 1e9);
+  };
+  run(0, "f16x3, producer-side split");
+  run(2, "  same, no weight stream");
+  return 0;
+}

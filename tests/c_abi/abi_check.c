@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
   RESOLVE(distr_debug_mlp_layer); RESOLVE(distr_debug_tile_timing); RESOLVE(distr_debug_xchg_ts);
   RESOLVE(distr_render_forward_batch); RESOLVE(distr_render_backward_batch); RESOLVE(distr_render_normal_batch);
   RESOLVE(distr_mlp_eval_bf16x6);
+  RESOLVE(distr_mlp_eval_f16x3);
   const char* (*version)(void);
   size_t (*mlp_ws)(int64_t);
   size_t (*loss_ws)(int32_t, int32_t);
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
   OFF(distr_render_cfg, save_for_backward); OFF(distr_render_cfg, row0); OFF(distr_render_cfg, rows); OFF(distr_render_cfg, arith);
   OFF(distr_decoder_desc, latent_size); OFF(distr_decoder_desc, hidden); OFF(distr_decoder_desc, num_linear); OFF(distr_decoder_desc, latent_in);
   OFF(distr_render_stats, num_in_sphere); OFF(distr_render_stats, num_march_launches); OFF(distr_render_stats, num_point_evals);
-  OFF(distr_render_stats, num_valid); OFF(distr_render_stats, num_grad_samples); OFF(distr_render_stats, cluster_fallbacks);
+  OFF(distr_render_stats, num_valid); OFF(distr_render_stats, num_grad_samples); OFF(distr_render_stats, cluster_fallbacks); OFF(distr_render_stats, f16_overflows);
   OFF(distr_warp_cfg, H); OFF(distr_warp_cfg, W); OFF(distr_warp_cfg, K); OFF(distr_warp_cfg, K_inv); OFF(distr_warp_cfg, thres_depth);
   printf("sizeof distr_decoder_desc %zu\nsizeof distr_render_stats %zu\nsizeof distr_warp_cfg %zu\n", sizeof(distr_decoder_desc),
          sizeof(distr_render_stats), sizeof(distr_warp_cfg));

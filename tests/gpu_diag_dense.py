@@ -40,16 +40,17 @@ def main():
         functions.mlp_eval(eng, lat, pts)
     med, mn = timeit(lambda: functions.mlp_eval(eng, lat, pts))
     print('distr_mlp_eval  n=%d: median %.3f ms (min %.3f) = %.1f TFLOP/s = %.3f of peak' % (args.n, med, mn, FLOP * args.n / med / 1e9, FLOP * args.n / med / 1e9 / PEAK))
-    for _ in range(3):
-        functions.mlp_eval(eng, lat, pts, arith='bf16x6')
     a = functions.mlp_eval(eng, lat, pts)
-    b = functions.mlp_eval(eng, lat, pts, arith='bf16x6')
-    d = (a - b).abs()
-    medb, mnb = timeit(lambda: functions.mlp_eval(eng, lat, pts, arith='bf16x6'))
-    print('distr_mlp_eval_bf16x6 n=%d: median %.3f ms (min %.3f) = %.1f TFLOP/s-equivalent (algorithmic FLOP counted once; %.3f of the 2500 TFLOP/s '
-          'bf16 peak, %.2f x the f32 kernel); max |sdf - sdf_f32| = %.3e (mean %.3e) over %d points with sdf in [%.3f, %.3f]'
-          % (args.n, medb, mnb, FLOP * args.n / medb / 1e9, FLOP * args.n / medb / 1e9 / 2500.0, med / medb, float(d.max()), float(d.mean()), args.n,
-             float(a.min()), float(a.max())))
+    for mode, peak_name in (('bf16x6', 'bf16'), ('f16x3', 'f16')):
+        for _ in range(3):
+            functions.mlp_eval(eng, lat, pts, arith=mode)
+        b = functions.mlp_eval(eng, lat, pts, arith=mode)
+        d = (a - b).abs()
+        medb, mnb = timeit(lambda: functions.mlp_eval(eng, lat, pts, arith=mode))
+        print('distr_mlp_eval_%s n=%d: median %.3f ms (min %.3f) = %.1f TFLOP/s-equivalent (algorithmic FLOP counted once; %.3f of the 2500 TFLOP/s '
+              '%s peak, %.2f x the f32 kernel); max |sdf - sdf_f32| = %.3e (mean %.3e, non-finite %d) over %d points with sdf in [%.3f, %.3f]'
+              % (mode, args.n, medb, mnb, FLOP * args.n / medb / 1e9, FLOP * args.n / medb / 1e9 / 2500.0, peak_name, med / medb, float(d[torch.isfinite(d)].max()),
+                 float(d[torch.isfinite(d)].mean()), int((~torch.isfinite(b)).sum()), args.n, float(a.min()), float(a.max())))
     med, mn = timeit(lambda: functions.mlp_grad(eng, lat, pts))
     print('distr_mlp_grad  n=%d: median %.3f ms (min %.3f) = %.1f TFLOP/s = %.3f of peak' % (args.n, med, mn, 2 * FLOP * args.n / med / 1e9, 2 * FLOP * args.n / med / 1e9 / PEAK))
     if args.stamps:

@@ -51,7 +51,7 @@ def _bench_camera(view):
 
 
 # ------------------------------------------------------------------------------------------------------------------ C2
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('name', ['g3_c2_recursive_d2n.npz', 'g3_c2_pyramid_recursive_d2n.npz'])
 def test_c2_hip_matches_reference_golden(engine, name, arith):
     """C2 through the HIP path against what the reference itself produced at 256x256/50 (G3): the 32x32 crop pixel by pixel,

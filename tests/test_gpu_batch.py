@@ -220,17 +220,18 @@ def _render_arith(engine, latent, H, W, cam, arith, **kw):
     dict(H=160, W=120, cam=(20, 10, 1.6, 5), kw=dict(march_step=40, buffer_size=2, marcher='recursive', use_depth2normal=False)),
     dict(H=48, W=48, cam=(0, 0, 1.6, 0), kw=dict(march_step=12, buffer_size=3, marcher='trivial', use_depth2normal=True)),
 ], ids=['c2-pyramid-d2n', 'recursive-agn', 'trivial'])
-def test_split_bf16_march_is_f32_equivalent(engine, fixture_decoder, case):
-    """distr_render_cfg.arith = DISTR_ARITH_BF16X6 (opt-in): the whole render -- march, selection, outputs, backward on the ReLU masks
+@pytest.mark.parametrize('arith', ['bf16x6', 'f16x3'])
+def test_split_bf16_march_is_f32_equivalent(engine, fixture_decoder, case, arith):
+    """distr_render_cfg.arith = DISTR_ARITH_BF16X6 / DISTR_ARITH_F16X3 (opt-in): the whole render -- march, selection, outputs, backward on the ReLU masks
     this forward saved -- against the exact f32 render (which the oracle pins bit for bit): at most a handful of stop-step /
     threshold flips, depth and min-sdf within 1e-4 on commonly valid pixels (north_star's bar; measured ~1e-6 on almost all),
     gradients within 2e-3; and the mode is self-consistent: two renders are bit-identical (64- and 32-ray tiles compute a ray
     identically, so the nondeterministic order of the live lists does not matter)."""
     _, _, latent = fixture_decoder
     H, W = case['H'], case['W']
-    a = _render_arith(engine, latent, H, W, case['cam'], 'bf16x6', **case['kw'])
+    a = _render_arith(engine, latent, H, W, case['cam'], arith, **case['kw'])
     b = _render_arith(engine, latent, H, W, case['cam'], 'f32', **case['kw'])
-    a2 = _render_arith(engine, latent, H, W, case['cam'], 'bf16x6', **case['kw'])
+    a2 = _render_arith(engine, latent, H, W, case['cam'], arith, **case['kw'])
     for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
         assert a[k].tobytes() == a2[k].tobytes(), k                          # reproducible bit for bit
     ma, mb = a['mask'].reshape(H, W).astype(bool), b['mask'].reshape(H, W).astype(bool)
@@ -242,7 +243,7 @@ def test_split_bf16_march_is_f32_equivalent(engine, fixture_decoder, case):
                zdepth_median=float(np.median(dz)), min_sdf_max=float(dq.max()))
     for k in ('g_latent', 'g_R', 'g_T'):
         res[k] = float(np.abs(a[k] - b[k]).max() / np.abs(b[k]).max())
-    print('bf16x6 vs f32', case['kw']['marcher'], res)
+    print(arith, 'vs f32', case['kw']['marcher'], res)
     assert flips <= max(2, int(0.001 * mb.sum())), res
     # (a ray whose |sdf| lands within ~1e-6 of the stop threshold stops a step earlier or later: ~0.1 % of the pixels move by ~1e-5,
     # the mechanism behind the reference's own noise floor, tests/golden/noise_floor_c1.npz: depth 6.7e-5 under 1e-7 weight noise)
@@ -250,8 +251,9 @@ def test_split_bf16_march_is_f32_equivalent(engine, fixture_decoder, case):
     assert max(res['g_latent'], res['g_R'], res['g_T']) <= (2e-2 if case['kw']['use_depth2normal'] else 2e-3), res
 
 
-def test_split_bf16_batch_and_band_consistency(engine, fixture_decoder):
-    """Within the split-bf16 arithmetic the structural identities of the exact path hold too: a batch of views equals the
+@pytest.mark.parametrize('arith', ['bf16x6', 'f16x3'])
+def test_split_bf16_batch_and_band_consistency(engine, fixture_decoder, arith):
+    """Within the split arithmetics the structural identities of the exact path hold too: a batch of views equals the
     stand-alone renders byte for byte, forward and backward."""
     _check_batch(engine, fixture_decoder, 96, 80, 3, False, None, march_step=30, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True,
-                 arith='bf16x6')
+                 arith=arith)

@@ -52,7 +52,7 @@ def _floor():
     return {k: float(v) for k, v in np.load(os.path.join(GOLDEN, 'noise_floor_f2.npz')).items()}
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1f2_*.npz'))))
 def test_f2_hip_matches_reference_goldens(engine_f2, f2, name, arith):
     """HIP path on F2 directly against outputs of the reference itself (64 x 64, 20 steps: three marchers + autograd normals), in the

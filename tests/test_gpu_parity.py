@@ -119,7 +119,7 @@ def test_render_c1_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, marc
     assert res['flips'] == 0, res
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))
                                           if re.match(r'g1[bc]?_', os.path.basename(p))))
 def test_render_matches_reference_goldens(engine, name, arith):
@@ -1495,8 +1495,9 @@ def test_backward_refuses_re_uploaded_decoder(fixture_decoder):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('fix', ['f1', 'f2'])
-def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix):
-    """distr_mlp_eval_bf16x6 (opt-in six-product split-bf16 decoder tile) against the exact f32 kernel -- which the oracle pins
+@pytest.mark.parametrize('arith', ['bf16x6', 'f16x3'])
+def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix, arith):
+    """distr_mlp_eval_bf16x6 / distr_mlp_eval_f16x3 (opt-in split-bf16 / split-f16 decoder tiles) against the exact f32 kernel -- which the oracle pins
     bit for bit -- on both fixtures: ragged point counts, the clamp, and the error bar (1e-5: two orders below the 1e-4 parity bar
     of the renderer; measured ~1e-6). Also through create_sdf_grid(arith='bf16x6')."""
     import torch
@@ -1510,17 +1511,17 @@ def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix):
     for n in (1, 63, 64, 65, 4097, 50000):
         pts = torch.from_numpy((rs.rand(n, 3) * 1.8 - 0.9).astype(np.float32)).cuda()
         a = functions.mlp_eval(eng, lat, pts)
-        b = functions.mlp_eval(eng, lat, pts, arith='bf16x6')
+        b = functions.mlp_eval(eng, lat, pts, arith=arith)
         assert b.shape == a.shape and float((a - b).abs().max()) <= 1e-5, (n, float((a - b).abs().max()))
         ac = functions.mlp_eval(eng, lat, pts, clamp_dist=0.05)
-        bc = functions.mlp_eval(eng, lat, pts, clamp_dist=0.05, arith='bf16x6')
+        bc = functions.mlp_eval(eng, lat, pts, clamp_dist=0.05, arith=arith)
         assert float((ac - bc).abs().max()) <= 1e-5 and float(bc.abs().max()) <= 0.05 + 1e-7
     if n >= 50000:
-        print('%s: max |sdf_bf16x6 - sdf_f32| over %d points = %.3e' % (fix, n, float((a - b).abs().max())))
+        print('%s: max |sdf_%s - sdf_f32| over %d points = %.3e' % (fix, arith, n, float((a - b).abs().max())))
     dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
     dec.load_state_dict({('lin%d.%s' % (l, n_)): torch.from_numpy(a_) for l, (W, b_) in enumerate(zip(Ws, bs)) for n_, a_ in (('weight', W), ('bias', b_))})
     dec = dec.cuda()
-    g0, g1 = create_sdf_grid(dec, lat, 48), create_sdf_grid(dec, lat, 48, arith='bf16x6')
+    g0, g1 = create_sdf_grid(dec, lat, 48), create_sdf_grid(dec, lat, 48, arith=arith)
     assert float((g0 - g1).abs().max()) <= 1e-5 and bool(((g0 > 0) == (g1 > 0)).float().mean() > 0.9999)
     with pytest.raises(ValueError):
         functions.mlp_eval(eng, lat, pts, arith='fp8')
