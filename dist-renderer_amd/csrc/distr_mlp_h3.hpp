@@ -56,13 +56,21 @@ __device__ __forceinline__ void split2_f16(float a, float b, uint32_t& p0, uint3
   p0 = __builtin_bit_cast(uint32_t, h0);
   p1 = __builtin_bit_cast(uint32_t, h1);
 }
-// four consecutive features of one ray -> one 8-byte store per plane
+// four consecutive features (>= 0: ReLU outputs) of one ray -> one 8-byte store per plane. `top` keeps the largest leading-plane
+// bit pattern seen (v_pk_max_u16; non-negative f16 order like unsigned integers, inf = 0x7c00 and NaN above it): the range check
+// of the tile costs one instruction per pair of values.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ bool top_overflowed(uint32_t top) { return (top & 0xffffu) >= 0x7c00u || (top >> 16) >= 0x7c00u; }
+
 template <int TILE>
-__device__ __forceinline__ void store4_h3(uint16_t (&P)[2][HID * TILE], int row, int ray, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ void store4_h3(uint16_t (&P)[2][HID * TILE], int row, int ray, float v0, float v1, float v2, float v3, uint32_t& top) {
   u32x2 p0, p1;
   uint32_t t0, t1;
-  split2_f16(v0, v1, t0, t1); p0[0] = t0; p1[0] = t1;
-  split2_f16(v2, v3, t0, t1); p0[1] = t0; p1[1] = t1;
+  split2_f16(v0, v1, t0, t1); p0[0] = t0; p1[0] = t1; top = pk_max_u16(top, t0);
+  split2_f16(v2, v3, t0, t1); p0[1] = t0; p1[1] = t1; top = pk_max_u16(top, t0);
   *reinterpret_cast<u32x2*>(&P[0][xk<TILE>(row, ray)]) = p0;
   *reinterpret_cast<u32x2*>(&P[1][xk<TILE>(row, ray)]) = p1;
 }
@@ -79,7 +87,9 @@ __device__ __forceinline__ void load_a_h3(const uint32_t* __restrict__ Wp, int k
 
 // acc[ob][rb] (started by the caller, in units of SW SX) += (SW W)[rows of this wave][0..K) x (SX X)[0..K)[rays], three f16 products
 // per f32 product. Register double buffer as in dense_b6 (block kb + 1 requested before the MFMAs of block kb; `a` = this layer's
-// block 0 on entry, the next layer's on return), with nothing but loads and MFMAs in the loop.
+// block 0 on entry, the next layer's on return), with nothing but loads and MFMAs in the loop. (A ring of three buffers, two blocks
+// ahead, is worth 13 % in the microbenchmark and 4.5 % in distr_mlp_eval_f16x3, but puts 380 bytes of k_step's state into scratch
+// and leaves the march unchanged: not used.)
 template <int K, int NOB, int RB, int NOBN>
 __device__ __forceinline__ void dense_h3(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const uint16_t (&P)[2][HID * 32 * RB],
                                          f32x16 (&acc)[NOB][RB], int wave, int lane, u32x4 (&a)[4][2]) {
@@ -124,7 +134,8 @@ __device__ __forceinline__ void dense_h3(const uint32_t* __restrict__ Wp, const 
 // ReLU, rescale (acc = SW SX y -> SX relu(y)), split into the two planes, write back. KEEP: mask bits in the common format
 // (distr_mlp.hpp::writeback: bit (rb * 16 + r) of mask[ob] = value > 0).
 template <int NOB, int RB, bool KEEP>
-__device__ __forceinline__ void writeback_h3(uint16_t (&P)[2][HID * 32 * RB], const f32x16 (&acc)[NOB][RB], int row0, int lane, uint32_t (&mask)[4]) {
+__device__ __forceinline__ void writeback_h3(uint16_t (&P)[2][HID * 32 * RB], const f32x16 (&acc)[NOB][RB], int row0, int lane, uint32_t (&mask)[4],
+                                             uint32_t (&top)[RB]) {
   constexpr int TILE = 32 * RB;
   const int j = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -141,7 +152,7 @@ __device__ __forceinline__ void writeback_h3(uint16_t (&P)[2][HID * 32 * RB], co
           v[i] = __int_as_float(rbits) * (1.0f / H3_SW);
           if (KEEP) m |= min((uint32_t)rbits, 1u) << (rb * 16 + 4 * q + i);
         }
-        store4_h3<TILE>(P, row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[0], v[1], v[2], v[3]);
+        store4_h3<TILE>(P, row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[0], v[1], v[2], v[3], top[rb]);
       }
     if (KEEP) {
       asm volatile("" : "+v"(m));
@@ -152,7 +163,7 @@ __device__ __forceinline__ void writeback_h3(uint16_t (&P)[2][HID * 32 * RB], co
 
 template <int K, int NOB, int RB, bool KEEP, int NOBN>
 __device__ __forceinline__ void layer_h3(const uint32_t* __restrict__ Wp, const uint32_t* __restrict__ WpNext, const float* __restrict__ bias, int nbias,
-                                         uint16_t (&P)[2][HID * 32 * RB], int wave, int lane, uint32_t (&mask)[4], u32x4 (&a)[4][2]) {
+                                         uint16_t (&P)[2][HID * 32 * RB], int wave, int lane, uint32_t (&mask)[4], uint32_t (&top)[RB], u32x4 (&a)[4][2]) {
   const int h = lane >> 5;
   f32x16 acc[NOB][RB];
   const int row0 = wave * 32 * NOB;
@@ -167,12 +178,13 @@ __device__ __forceinline__ void layer_h3(const uint32_t* __restrict__ Wp, const 
     }
   dense_h3<K, NOB, RB, NOBN>(Wp, WpNext, P, acc, wave, lane, a);
   __syncthreads();                         // everybody is done reading the layer input
-  writeback_h3<NOB, RB, KEEP>(P, acc, row0, lane, mask);
+  writeback_h3<NOB, RB, KEEP>(P, acc, row0, lane, mask, top);
   __syncthreads();
 }
 
-// Preconditions and results as mlp_forward_b6. A non-finite result (an activation left the f16 range) is returned as it is: the
-// callers test it.
+// Preconditions and results as mlp_forward_b6. Range check: every lane tracks the largest leading-plane pattern it wrote for each
+// of its rays (store4_h3); a ray with an activation at or beyond the f16 range (inf / NaN pattern) gets NaN as its result -- which the
+// callers test -- whatever the later layers made of the inf (a ReLU taken on the bit pattern turns a negative NaN into 0).
 template <int RB, bool KEEP>
 __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const DecoderH3& H3, const float* __restrict__ c0, const float* __restrict__ c4,
                                                 SmemH3<RB>& S, uint32_t (&masks)[8][4]) {
@@ -181,6 +193,11 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int j = lane & 31, h = lane >> 5;
+  uint32_t top[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) top[rb] = 0u;
+  uint32_t* over = reinterpret_cast<uint32_t*>(S.part + 4 * TILE);      // [TILE] per-ray overflow flags
+  if (tid < TILE) over[tid] = 0u;
   // lin0 (K = 3): the f32 fmaf chain of the exact tile in the accumulator layout of the wide layers, written as planes
   {
     float px[RB], py[RB], pz[RB];
@@ -207,7 +224,7 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
           }
         }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) store4_h3<TILE>(S.P, wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[rb][0], v[rb][1], v[rb][2], v[rb][3]);
+        for (int rb = 0; rb < RB; ++rb) store4_h3<TILE>(S.P, wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[rb][0], v[rb][1], v[rb][2], v[rb][3], top[rb]);
       }
       if (KEEP) {
         asm volatile("" : "+v"(m));
@@ -218,10 +235,10 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
   __syncthreads();
   u32x4 a[4][2];                           // first weight block of the next layer, travelling across the write-backs
   load_a_h3<4>(H3.Wp[1], 0, wave, lane, a);
-  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[1], H3.Wp[2], D.bias[1], HID, S.P, wave, lane, masks[1], a);
-  layer_h3<512, 4, RB, KEEP, 2>(H3.Wp[2], H3.Wp[3], D.bias[2], HID, S.P, wave, lane, masks[2], a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[1], H3.Wp[2], D.bias[1], HID, S.P, wave, lane, masks[1], top, a);
+  layer_h3<512, 4, RB, KEEP, 2>(H3.Wp[2], H3.Wp[3], D.bias[2], HID, S.P, wave, lane, masks[2], top, a);
   masks[3][2] = 0; masks[3][3] = 0;
-  layer_h3<512, 2, RB, KEEP, 4>(H3.Wp[3], H3.Wp[4], D.bias[3], 253, S.P, wave, lane, masks[3], a);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
+  layer_h3<512, 2, RB, KEEP, 4>(H3.Wp[3], H3.Wp[4], D.bias[3], 253, S.P, wave, lane, masks[3], top, a);      // lin3: 512 -> 253 (+ 3 rows that carry xyz into lin4)
   if (tid < 3 * TILE) {                    // rows 253..255 <- SX * xyz (signed), as planes
     const _Float16 h0 = (_Float16)(S.xyz[tid] * H3_SX);
     const _Float16 h1 = (_Float16)(S.xyz[tid] * H3_SX - (float)h0);
@@ -229,10 +246,10 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
     S.P[1][xk<TILE>(253 + tid / TILE, tid % TILE)] = __builtin_bit_cast(uint16_t, h1);
   }
   __syncthreads();
-  layer_h3<256, 4, RB, KEEP, 4>(H3.Wp[4], H3.Wp[5], c4, HID, S.P, wave, lane, masks[4], a);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
-  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[5], H3.Wp[6], D.bias[5], HID, S.P, wave, lane, masks[5], a);
-  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[6], H3.Wp[7], D.bias[6], HID, S.P, wave, lane, masks[6], a);
-  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[7], nullptr, D.bias[7], HID, S.P, wave, lane, masks[7], a);
+  layer_h3<256, 4, RB, KEEP, 4>(H3.Wp[4], H3.Wp[5], c4, HID, S.P, wave, lane, masks[4], top, a);             // lin4: [x3 (253) | xyz (3)] -> 512, latent part folded into c4
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[5], H3.Wp[6], D.bias[5], HID, S.P, wave, lane, masks[5], top, a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[6], H3.Wp[7], D.bias[6], HID, S.P, wave, lane, masks[6], top, a);
+  layer_h3<512, 4, RB, KEEP, 4>(H3.Wp[7], nullptr, D.bias[7], HID, S.P, wave, lane, masks[7], top, a);
   // lin8: four 128-long f32 chains per ray (one per wave) on x7 = (a0 + a1) / SX (the sum of the planes is exact in f32),
   // combined in the exact tile's order
   const int ray = tid & (TILE - 1);
@@ -246,9 +263,13 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
       p = __builtin_fmaf(w8[k], x, p);
     }
     S.part[wave * TILE + ray] = p;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+      if (top_overflowed(top[rb])) over[32 * rb + j] = 1u;
   }
   __syncthreads();
-  return ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+  const float y = ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
+  return over[ray] ? __builtin_nanf("") : y;
 }
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-f16 arithmetic; a point whose evaluation left the

@@ -137,6 +137,111 @@ __global__ void __launch_bounds__(256, 1) k_layers(const uint32_t* __restrict__ 
       y_out[i] = ((float)__builtin_bit_cast(_Float16, P[0][i]) + (float)__builtin_bit_cast(_Float16, P[1][i])) * (1.0f / SX);
 }
 
+// The same layer with the weight fragments in a RING of three register buffers, two blocks ahead of their use (one block of MFMAs is
+// 768 cycles = 0.4 us at 1.9 GHz, less than an L2 round trip under load). The ring runs across layers: a layer of 32 blocks finds its
+// blocks 0 / 1 in (R0, R1) and leaves the next layer's in (R2, R0), so three layers are written out per loop iteration.
+template <int EXP>
+__global__ void __launch_bounds__(256, 1) k_layers_ring(const uint32_t* __restrict__ Wp, const uint16_t* __restrict__ x0, float* __restrict__ y_out,
+                                                        long long* __restrict__ cyc, int tiles, int layers3) {
+  __shared__ __attribute__((aligned(16))) uint16_t P[2][HID * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  long long tsum = 0;
+  constexpr int NKB = HID / 16;
+  constexpr int PW[3] = {0, 1, 0}, PA[3] = {0, 0, 1};
+  auto wbase = [&](int l) { return reinterpret_cast<const u32x4*>(Wp) + (size_t)(l % LAYERS) * NKB * 4 * 4 * 2 * 64 + (size_t)wave * 4 * 2 * 64 + lane; };
+  auto load_a = [&](u32x4 (&dst)[4][2], const u32x4* wp, int kb) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) dst[ob][p] = wp[(((size_t)kb * 4 * 4 + ob) * 2 + p) * 64];
+  };
+  auto load_b = [&](u32x4 (&dst)[2][2], int kb) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) dst[rb][p] = *reinterpret_cast<const u32x4*>(&P[p][xidx(16 * kb + 8 * h, 32 * rb + j)]);
+  };
+  for (int t = 0; t < tiles; ++t) {
+    for (int i = tid; i < 2 * HID * TILE; i += 256) (&P[0][0])[i] = x0[i];
+    __syncthreads();
+    const long long c0 = __builtin_readcyclecounter();
+    u32x4 U[4][2], V[4][2], W[4][2];
+    load_a(U, wbase(0), 0);
+    load_a(V, wbase(0), 1);
+    auto layer = [&](int l, u32x4 (&R0)[4][2], u32x4 (&R1)[4][2], u32x4 (&R2)[4][2]) {
+      f32x16 acc[4][2];
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+      const u32x4* wp = wbase(l);
+      const u32x4* wn = wbase(l + 1);
+      u32x4 b[2][2];
+      load_b(b, 0);
+      auto stage = [&](u32x4 (&Rcur)[4][2], u32x4 (&Rfree)[4][2], int kb, bool tail) {
+        u32x4 bn[2][2];
+        if (!tail) load_a(Rfree, wp, (EXP & 2) ? 0 : kb + 2);
+        else load_a(Rfree, wn, (EXP & 2) ? 0 : kb + 2 - NKB);
+        load_b(bn, (kb + 1 < NKB) ? kb + 1 : kb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+              acc[ob][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Rcur[ob][PW[q]]), __builtin_bit_cast(f16x8, b[rb][PA[q]]),
+                                                                   acc[ob][rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[rb][p] = bn[rb][p];
+      };
+#pragma unroll 1
+      for (int tt = 0; tt < 10; ++tt) {
+        stage(R0, R2, 3 * tt, false);
+        stage(R1, R0, 3 * tt + 1, false);
+        stage(R2, R1, 3 * tt + 2, false);
+      }
+      stage(R0, R2, NKB - 2, true);
+      stage(R1, R0, NKB - 1, true);
+      __syncthreads();
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[ob][rb][4 * q + i], 0.f) * (1.0f / (16.0f * SW));
+            u32x2 p0, p1;
+            uint32_t t0, t1;
+            split2(v[0], v[1], t0, t1); p0[0] = t0; p1[0] = t1;
+            split2(v[2], v[3], t0, t1); p0[1] = t0; p1[1] = t1;
+            const int row = wave * 128 + 32 * ob + 8 * q + 4 * h;
+            *reinterpret_cast<u32x2*>(&P[0][xidx(row, 32 * rb + j)]) = p0;
+            *reinterpret_cast<u32x2*>(&P[1][xidx(row, 32 * rb + j)]) = p1;
+          }
+      __syncthreads();
+    };
+    for (int l3 = 0; l3 < layers3; ++l3) {     // next layer's blocks 0 / 1 land in (R2, R0) of the layer before
+      layer(3 * l3, U, V, W);
+      layer(3 * l3 + 1, W, U, V);
+      layer(3 * l3 + 2, V, W, U);
+    }
+    tsum += __builtin_readcyclecounter() - c0;
+    asm volatile("" :: "v"(U[0][0]), "v"(V[0][0]));
+  }
+  if (tid == 0) cyc[blockIdx.x] = tsum;
+  if (blockIdx.x == 0)
+    for (int i = tid; i < HID * TILE; i += 256)
+      y_out[i] = ((float)__builtin_bit_cast(_Float16, P[0][i]) + (float)__builtin_bit_cast(_Float16, P[1][i])) * (1.0f / SX);
+}
+
 static inline uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 static inline float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
@@ -207,5 +312,20 @@ int main() {
   };
   run(0, "f16x3, producer-side split");
   run(2, "  same, no weight stream");
+  {   // ring of three: 9 layers per tile (3 x 3), normalised per layer
+    const int tiles = 16;
+    double best_ms = 1e9, cyc_layer = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipEventRecord(e0);
+      hipLaunchKernelGGL(k_layers_ring<0>, dim3(NWG), dim3(256), 0, 0, (const uint32_t*)dWb, dx, dy, dcyc, tiles, 3);
+      (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      long long hc[NWG]; (void)hipMemcpy(hc, dcyc, sizeof(hc), hipMemcpyDeviceToHost);
+      double c = 0; for (int i = 0; i < NWG; ++i) c += (double)hc[i];
+      if (rep > 0 && ms < best_ms) { best_ms = ms; cyc_layer = c / NWG / tiles / 9; }
+    }
+    printf("  weight ring of three (2 blocks ahead), 9 layers: %8.0f cycles / layer / tile, %7.3f ms per 8 layers x 16 tiles (%.2f GHz)\n", cyc_layer, best_ms * 8 / 9,
+           cyc_layer * tiles * 9 / best_ms / 1e6);
+  }
   return 0;
 }

@@ -1525,3 +1525,55 @@ def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix, arith):
     assert float((g0 - g1).abs().max()) <= 1e-5 and bool(((g0 > 0) == (g1 > 0)).float().mean() > 0.9999)
     with pytest.raises(ValueError):
         functions.mlp_eval(eng, lat, pts, arith='fp8')
+
+
+@pytest.mark.gpu
+def test_split_f16_range_is_checked(fixture_decoder):
+    """The split-f16 arithmetic only covers decoders whose scaled weights and activations fit f16 (|.| < 1023): a decoder with a
+    larger weight makes the mode unavailable (DISTR_ERR_UNSUPPORTED from every call that asks for it, the other arithmetics keep
+    working); an activation that overflows is reported -- NaN from distr_mlp_eval_f16x3, f16_overflows > 0 in the render's counters --
+    never clamped into a plausible number."""
+    import ctypes as C
+    import torch
+    from distr import binding, fixture, functions
+    Ws, bs, latent = fixture_decoder
+    lat = torch.from_numpy(latent).cuda()
+    pts = torch.from_numpy((np.random.RandomState(1).rand(200, 3) * 1.2 - 0.6).astype(np.float32)).cuda()
+    H = W = 48
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(20.0, 10.0, 1.6, 0.0)
+
+    # (1) a weight beyond the range (2000 * 64 > 65504)
+    W1 = [w.copy() for w in Ws]
+    W1[2][5, 7] = 2000.0
+    eng = functions.engine_from_weights(W1, bs, 0)
+    assert torch.isfinite(functions.mlp_eval(eng, lat, pts)).all()
+    assert torch.isfinite(functions.mlp_eval(eng, lat, pts, arith='bf16x6')).all()
+    with pytest.raises(binding.DistrError, match='f16'):
+        functions.mlp_eval(eng, lat, pts, arith='f16x3')
+    with pytest.raises(binding.DistrError, match='f16'):
+        helpers.hip_render(eng, H, W, K, R, T, latent, arith='f16x3', march_step=10, buffer_size=2, marcher='recursive', use_depth2normal=True)
+
+    # (2) weights in range, activations not: lin0's bias pushed to 3000 -> x0 ~ 3000 -> 64 x0 > 65504
+    b2 = [b.copy() for b in bs]
+    b2[0] = b2[0] + 3000.0
+    eng = functions.engine_from_weights(Ws, b2, 0)
+    assert torch.isfinite(functions.mlp_eval(eng, lat, pts)).all()
+    assert torch.isfinite(functions.mlp_eval(eng, lat, pts, arith='bf16x6')).all()
+    assert torch.isnan(functions.mlp_eval(eng, lat, pts, arith='f16x3', clamp_dist=0.1)).all()
+    cfg = binding.make_cfg((H, W), K, march_step=10, buffer_size=2, marcher='recursive', use_depth2normal=True, arith='f16x3')
+    n = H * W
+    dev = eng.device
+    ws = torch.empty(eng.ctx.workspace_bytes(cfg)[0], dtype=torch.uint8, device=dev)
+    outs = [torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev),
+            torch.empty(n, 3, device=dev)]
+    p = binding.ptr
+    Rt, Tt = torch.from_numpy(R).to(dev).reshape(-1).contiguous(), torch.from_numpy(T).to(dev)
+    eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt), p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]),
+                                               p(ws), ws.numel(), eng.ctx.stream()))
+    st = eng.ctx.render_stats(cfg, ws)
+    assert st['f16_overflows'] > 0, st
+    cfg.arith = binding.ARITH['bf16x6']
+    eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt), p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]),
+                                               p(ws), ws.numel(), eng.ctx.stream()))
+    assert eng.ctx.render_stats(cfg, ws)['f16_overflows'] == 0
