@@ -523,13 +523,20 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
       hb.resize(offbt[l] + Wt.size() * 3, 0);
       pack_fragments_b6(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], hb.data() + offbt[l]);
     }
-    size_t offh[8] = {0};
-    if (H3) {   // split-f16 planes of lin1..lin7 (forward only; the backward of that mode is the split-bf16 dX chain): 6.3 MB
+    size_t offh[8] = {0}, offht[8] = {0};
+    if (H3) {   // split-f16 planes of lin1..lin7 and of their transposes: 2 x 6.3 MB
       *h3_ok = true;
       for (int l = 1; l < 8; ++l) {
         offh[l] = (hb.size() + 127) & ~(size_t)127;
         hb.resize(offh[l] + Wp[l].size() * 2, 0);
         if (!pack_fragments_h3(Wp[l].data(), Kp[l], Op[l], hb.data() + offh[l])) *h3_ok = false;
+      }
+      for (int l = 1; l < 8; ++l) {
+        std::vector<float> Wt((size_t)Kp[l] * Op[l]);
+        for (int o = 0; o < Op[l]; ++o) for (int k = 0; k < Kp[l]; ++k) Wt[(size_t)k * Op[l] + o] = Wp[l][(size_t)o * Kp[l] + k];
+        offht[l] = (hb.size() + 127) & ~(size_t)127;
+        hb.resize(offht[l] + Wt.size() * 2, 0);
+        (void)pack_fragments_h3(Wt.data(), /*K'=*/Op[l], /*O'=*/Kp[l], hb.data() + offht[l]);
       }
     }
     if (*dev_buf_b6) { HIP_TRY(hipFree(*dev_buf_b6)); *dev_buf_b6 = nullptr; }
@@ -541,8 +548,11 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
       B6->Wb[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offbt[l]);
     }
     if (H3) {
-      H3->Wp[0] = nullptr;
-      for (int l = 1; l < 8; ++l) H3->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offh[l]);
+      H3->Wp[0] = nullptr; H3->Wb[0] = nullptr;
+      for (int l = 1; l < 8; ++l) {
+        H3->Wp[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offh[l]);
+        H3->Wb[l] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(*dev_buf_b6) + offht[l]);
+      }
     }
   }
   return DISTR_OK;
@@ -853,12 +863,15 @@ int render_backward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews
   LAUNCH_CHECK("k_bwd_prep<emit>");
   BwdArgs B;
   memset(&B, 0, sizeof(B));
-  B.V = V; B.samples = W.samples; B.partial = W.partial; B.bstride = W.bstride; B.B6 = ctx->B6;
+  B.V = V; B.samples = W.samples; B.partial = W.partial; B.bstride = W.bstride; B.B6 = ctx->B6; B.H3 = ctx->H3;
   // tile-size split of every view's sample list (bwd_range): full rounds on 64-sample tiles, a small remainder on 32-sample tiles
   const bool bsplit = V.save_masks != 0;
   if (bsplit) {
     B.split = 1;
-    if (cfg->arith != DISTR_ARITH_F32) {        // split arithmetic: the split-bf16 dX chain (also for f16x3: loss gradients have no bounded range)
+    if (cfg->arith == DISTR_ARITH_F16X3) {      // the dX chain in the arithmetic of the forward it differentiates
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2, 2>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
+      hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1, 2>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
+    } else if (cfg->arith == DISTR_ARITH_BF16X6) {
       hipLaunchKernelGGL((k_bwd<BWD_SAVED, 2, 1>), dim3(NV * (unsigned)((smax + 63) / 64)), dim3(NTHREADS), 0, s, B, D);
       hipLaunchKernelGGL((k_bwd<BWD_SAVED, 1, 1>), dim3(NV * (unsigned)((std::min<size_t>(smax, 8192) + 31) / 32)), dim3(NTHREADS), 0, s, B, D);
     } else {

@@ -1339,6 +1339,7 @@ struct BwdArgs {
   float* out_sdf;            // POINTGRAD explicit: [n]   (pixel lists: V.n_sdf)
   float* out_g;              // POINTGRAD explicit: [n][3] (pixel lists: V.n_g)
   DecoderB6 B6;              // split-bf16 weight planes (k_bwd<BWD_SAVED, RB, 1>: distr_render_cfg.arith)
+  DecoderH3 H3;              // split-f16 weight planes (k_bwd<BWD_SAVED, RB, 2>)
 };
 
 __device__ __forceinline__ int32_t vget(int32_t x, int b, int B) { return (B <= 1) ? x : __shfl(x, b); }
@@ -1487,7 +1488,8 @@ __global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_bwd(Bw
   }
   float* part = (MODE != BWD_POINTGRAD || partial) ? partial + (size_t)tile * PSTRIDE : nullptr;
   if constexpr (ARITH == 0) mlp_backward<RB>(D, S, masks, part, part ? part + HID : nullptr);
-  else mlp_backward_b6<RB>(D, A.B6, S, masks, part, part ? part + HID : nullptr);
+  else if constexpr (ARITH == 1) mlp_backward_b6<RB>(D, A.B6, S, masks, part, part ? part + HID : nullptr);
+  else mlp_backward_h3<RB>(D, A.H3, S, masks, part, part ? part + HID : nullptr);
 
   if (tid >= 64) return;   // wave 0 stays whole for the shuffle reduction; lanes >= TILE carry zeros
   const int rl = tid & (TILE - 1);

@@ -19,8 +19,8 @@
 // mode fail), and an activation that overflows turns the evaluation's result non-finite, which the tiles COUNT
 // (Consts.f16_overflow -> distr_render_stats.f16_overflows; distr_mlp_eval_f16x3 writes NaN for the point) instead of hiding it
 // behind the clamps of the march.
-// The backward of a render in this mode is the split-bf16 dX chain (mlp_backward_b6: per-ray loss gradients have no bounded
-// range, bf16 planes keep f32's exponent) on the ReLU masks this forward saved -- the mask format is common to all three tiles.
+// The backward of a render in this mode (mlp_backward_h3) is the dX chain on the ReLU masks this forward saved, in the same
+// arithmetic, on deltas NORMALISED per ray by the loss gradient (whose range has no bound), with transposed weight planes.
 #pragma once
 #include "distr_mlp_b6.hpp"
 
@@ -33,8 +33,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float H3_SX = 64.f, H3_SW = 64.f;      // powers of two: every rescale below is exact
 
+constexpr float H3_SD = 1024.f;                  // scale of the backward's per-ray normalised deltas (|delta / d8| < 64)
+
 struct DecoderH3 {
   const uint32_t* Wp[8];   // two f16 A-fragment planes of SW * lin1..lin7 ([0] unused); lin3: O padded to 256; lin4: K = 256
+  const uint32_t* Wb[8];   // the same for the TRANSPOSED matrices (backward dX chain), index = layer whose weights are used (1..7)
 };
 
 template <int RB>
@@ -270,6 +273,176 @@ __device__ __forceinline__ float mlp_forward_h3(const DecoderDev& D, const Decod
   __syncthreads();
   const float y = ((S.part[ray] + S.part[TILE + ray]) + (S.part[2 * TILE + ray] + S.part[3 * TILE + ray])) + D.b8;
   return over[ray] ? __builtin_nanf("") : y;
+}
+
+// ---------------------------------------------------------------------------------------- backward tile (dX chain)
+// Signed values (deltas): four consecutive features of one ray -> one 8-byte store per plane
+template <int TILE>
+__device__ __forceinline__ void store4s_h3(uint16_t (&P)[2][HID * TILE], int row, int ray, float v0, float v1, float v2, float v3) {
+  u32x2 p0, p1;
+  uint32_t t0, t1;
+  split2_f16(v0, v1, t0, t1); p0[0] = t0; p1[0] = t1;
+  split2_f16(v2, v3, t0, t1); p0[1] = t0; p1[1] = t1;
+  *reinterpret_cast<u32x2*>(&P[0][xk<TILE>(row, ray)]) = p0;
+  *reinterpret_cast<u32x2*>(&P[1][xk<TILE>(row, ray)]) = p1;
+}
+// Gate + write-back of a backward layer: e = mask bit ? acc / SW : 0 (bits in the forward's format), as planes
+template <int NOB, int RB>
+__device__ __forceinline__ void writeback_gate_h3(uint16_t (&P)[2][HID * 32 * RB], const f32x16 (&acc)[NOB][RB], int row0, int lane, const uint32_t (&mask)[4]) {
+  constexpr int TILE = 32 * RB;
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    const uint32_t m = mask[ob];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gate(acc[ob][rb][4 * q + i] * (1.0f / H3_SW), (m >> (rb * 16 + 4 * q + i)) & 1u);
+        store4s_h3<TILE>(P, row0 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[0], v[1], v[2], v[3]);
+      }
+  }
+}
+// dst[row] = sum over the tile's rays of delta[row][ray] = sum of e[row][ray] * d8[ray]; d8s = d8 / SD (LDS), the exact tile's ray order
+template <int RB>
+__device__ __forceinline__ void row_sums_h3(const uint16_t (&P)[2][HID * 32 * RB], const float* d8s, float* __restrict__ dst, int tid) {
+  constexpr int TILE = 32 * RB;
+  const int lane = tid & 63;
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = tid + rr * 256;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < TILE; ++i) {
+      const int ray = (i + lane) & (TILE - 1);
+      const int x = xk<TILE>(row, ray);
+      s += ((float)__builtin_bit_cast(_Float16, P[0][x]) + (float)__builtin_bit_cast(_Float16, P[1][x])) * d8s[ray];
+    }
+    dst[row] = s;
+  }
+}
+
+// The dX chain of mlp_backward (distr_mlp.hpp) in split-f16 arithmetic. Interface of mlp_backward_b6: masks = the ReLU bitmasks of
+// the forward being differentiated; S.aux row 0 = d8[ray] = coef (1 - y^2); on return S.aux rows 1..3 hold d(coef f)/d xyz per ray,
+// sd0 / sd4 the row sums over the tile's rays of delta0 / delta4 (latent gradient).
+// d8 is a loss gradient: its magnitude has no bound, f16 has 5 exponent bits. The chain is linear in d8, so it runs on the
+// NORMALISED deltas e_l = delta_l / d8 (e7 = relu'(h7) w8: a property of the decoder alone, |e| ~ 1e-3 .. 1; planes hold SD e) and d8
+// multiplies the results per ray: the row sums are weighted sums, the xyz gradient is scaled at the end. An e beyond the range (SD |e|
+// > 65504) turns into inf / NaN planes, which the chain carries into non-finite gradients -- visible, not clamped.
+template <int RB>
+__device__ __forceinline__ void mlp_backward_h3(const DecoderDev& D, const DecoderH3& H3, SmemH3<RB>& S, uint32_t (&masks)[8][4],
+                                                float* __restrict__ sd0, float* __restrict__ sd4) {
+  constexpr int TILE = 32 * RB;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int h = lane >> 5, j = lane & 31;
+  const int ray = tid & (TILE - 1);
+  float* d8s = S.xyz;                      // (the saved-mask backward does not stage points: S.xyz is free)
+  if (tid < TILE) d8s[tid] = S.aux[tid] * (1.0f / H3_SD);
+  u32x4 a[4][2];
+  load_a_h3<4>(H3.Wb[7], 0, wave, lane, a);
+  // SD e7[k][ray] = relu'(h7) * w8[k] * SD
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) {
+    const uint32_t m = masks[7][ob];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[RB][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float w = D.w8[wave * 128 + 32 * ob + 8 * q + 4 * h + i] * H3_SD;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) v[rb][i] = gate(w, (m >> (16 * rb + 4 * q + i)) & 1u);
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) store4s_h3<TILE>(S.P, wave * 128 + 32 * ob + 8 * q + 4 * h, 32 * rb + j, v[rb][0], v[rb][1], v[rb][2], v[rb][3]);
+    }
+  }
+  __syncthreads();
+  auto zero4 = [&](f32x16 (&acc)[4][RB]) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+  };
+#pragma unroll
+  for (int l = 7; l >= 5; --l) {  // e_l (512) -> e_{l-1} (512)
+    f32x16 acc[4][RB];
+    zero4(acc);
+    if (l > 5) dense_h3<512, 4, RB, 4>(H3.Wb[l], H3.Wb[l - 1], S.P, acc, wave, lane, a);
+    else dense_h3<512, 4, RB, 2>(H3.Wb[5], H3.Wb[4], S.P, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_h3<4, RB>(S.P, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd4) row_sums_h3<RB>(S.P, d8s, sd4, tid);  // planes = e4
+  {  // lin4^T: e4 (512) -> [e3 (253) | d xyz (3)]
+    f32x16 acc[2][RB];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ob][rb][r] = 0.f;
+    dense_h3<512, 2, RB, 4>(H3.Wb[4], H3.Wb[3], S.P, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_h3<2, RB>(S.P, acc, wave * 64, lane, masks[3]);  // rows 253..255 have mask 0 -> written as 0
+    if (wave == 3 && h == 1) {
+#pragma unroll
+      for (int r = 13; r < 16; ++r)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) S.aux[(1 + r - 13) * TILE + 32 * rb + j] = acc[1][rb][r] * (1.0f / (H3_SW * H3_SD));   // (per unit d8)
+    }
+    __syncthreads();
+  }
+  {  // lin3^T: e3 (256 rows, 253 real) -> e2 (512)
+    f32x16 acc[4][RB];
+    zero4(acc);
+    dense_h3<256, 4, RB, 4>(H3.Wb[3], H3.Wb[2], S.P, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_h3<4, RB>(S.P, acc, wave * 128, lane, masks[2]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 2; l >= 1; --l) {
+    f32x16 acc[4][RB];
+    zero4(acc);
+    if (l > 1) dense_h3<512, 4, RB, 4>(H3.Wb[2], H3.Wb[1], S.P, acc, wave, lane, a);
+    else dense_h3<512, 4, RB, 4>(H3.Wb[1], nullptr, S.P, acc, wave, lane, a);
+    __syncthreads();
+    writeback_gate_h3<4, RB>(S.P, acc, wave * 128, lane, masks[l - 1]);
+    __syncthreads();
+  }
+  if (sd0) row_sums_h3<RB>(S.P, d8s, sd0, tid);  // planes = e0
+  // d xyz through lin0's xyz columns: 3 x four 128-long f32 chains per ray on e0
+  {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    const float* wx = D.W0x + wave * 128;
+#pragma unroll 4
+    for (int k = 0; k < 128; ++k) {
+      const int x = xk<TILE>(wave * 128 + k, ray);
+      const float d = (float)__builtin_bit_cast(_Float16, S.P[0][x]) + (float)__builtin_bit_cast(_Float16, S.P[1][x]);
+      p0 = __builtin_fmaf(wx[k], d, p0);
+      p1 = __builtin_fmaf(wx[HID + k], d, p1);
+      p2 = __builtin_fmaf(wx[2 * HID + k], d, p2);
+    }
+    S.part[(0 * 4 + wave) * TILE + ray] = p0;
+    S.part[(1 * 4 + wave) * TILE + ray] = p1;
+    S.part[(2 * 4 + wave) * TILE + ray] = p2;
+  }
+  __syncthreads();
+  if (tid < 3 * TILE) {
+    const int c = tid / TILE, r = tid % TILE;
+    const float* p = S.part + c * 4 * TILE + r;
+    const float unit = S.aux[(1 + c) * TILE + r] + ((p[0] + p[TILE]) + (p[2 * TILE] + p[3 * TILE])) * (1.0f / H3_SD);
+    S.aux[(1 + c) * TILE + r] = unit * S.aux[r];     // x d8 of the ray
+  }
+  __syncthreads();
 }
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-f16 arithmetic; a point whose evaluation left the
