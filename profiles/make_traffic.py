@@ -28,7 +28,7 @@ def main():
     d = {
         'kernel': "k_step / k_march (all tile-size roles of one march step = one 'launch' of bench.py's roofline)",
         'source': 'profiles/%s_pmc_fetch.md (FETCH_SIZE) + profiles/%s_pmc_write.md (WRITE_SIZE): rocprofv3 --pmc, separate passes, '
-                  '`bench.py --steps 5 --warmup 1 --no-cpu-baseline` (%d march launches: %d k_step + %d coarse k_march); profiles/make_traffic.py'
+                  '`bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass` (%d march launches: %d k_step + %d coarse k_march); profiles/make_traffic.py'
                   % (name, name, n, f[('k_step', 'FETCH_SIZE')][0], f[('k_march', 'FETCH_SIZE')][0]),
         'fetch_size_kb_total': fetch, 'write_size_kb_total': write, 'march_launches': n,
         'fetch_correction': 'x2: gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming loads (MI355X_MICROARCH.md, HBM '

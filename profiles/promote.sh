@@ -7,7 +7,10 @@ cp $F/bench.json $P/${R}_bench.json
 cp $F/kernel_stats.md $P/${R}_kernel_stats.md
 for k in fetch write mfma l2; do cp $F/pmc_$k.md $P/${R}_pmc_$k.md; done
 cp $F/steps_c3.md $P/${R}_steps_c3.md
-for k in c2 c1 137_100 137_100_nosticky; do [ -f $F/steps_$k.md ] && cp $F/steps_$k.md $P/${R}_steps_$k.md; done
+for k in c2 c1 137_100 137_100_nosticky c3_bf16x6 c3_f16x3; do [ -f $F/steps_$k.md ] && cp $F/steps_$k.md $P/${R}_steps_$k.md; done
+for k in c3_bf16x6 c3_f16x3; do [ -f $F/extra_$k.json ] && cp $F/extra_$k.json $P/${R}_extra_$k.json; done
+[ -f $F/kernel_stats_f16x3.md ] && cp $F/kernel_stats_f16x3.md $P/${R}_kernel_stats_f16x3.md
+for U in split_bf16_bounds split_f16_layer; do [ -f $F/ubench_$U.log ] && cp $F/ubench_$U.log $P/ubench/$U.log; done
 [ -f $F/batch_round.log ] && cp $F/batch_round.log $P/${R}_batch_round.log
 [ -f $F/extra_c3_f2.json ] && cp $F/extra_c3_f2.json $P/${R}_extra_c3_f2.json
 cp $F/dense.log $P/${R}_dense.log

@@ -2,11 +2,14 @@
 # Collects the judged evidence of a round on the GPU box (run from the repo root THROUGH gpurun; everything lands in <out>/, which
 # gpurun merges back; copy what is kept into profiles/ afterwards):
 #   bench.json           default `python bench.py` (C3, 20 steps, cpu baselines)
-#   kernel_stats.md      rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu-baseline`, condensed by summarize.py
+#   kernel_stats.md      rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass`, condensed by summarize.py
 #   pmc_fetch / pmc_write / pmc_mfma .md   separate rocprofv3 --pmc passes of the same command (never combined with tracing domains)
 #   steps_c3.md (+ steps_c2 / _c1 / _137_100[_nosticky])   per-launch table of one forward (tests/gpu_diag_steps.py)
 #   batch_round.log      phases, evaluations and march roofline of one batched multi-view round (tests/gpu_diag_batch.py)
-#   dense.log            dense decoder rate + in-kernel phase stamps (tests/gpu_diag_dense.py)
+#   dense.log            dense decoder rate (exact f32, bf16x6, f16x3) + in-kernel phase stamps (tests/gpu_diag_dense.py)
+#   steps_c3_bf16x6 / _f16x3 .md   the C3 per-launch table in the opt-in arithmetic modes
+#   ubench_*.log         profiles/ubench/split_bf16_bounds.hip, split_f16_layer.hip
+#   kernel_stats_f16x3.md   rocprofv3 --kernel-trace --stats of the bench in the split-f16 mode
 #   extra_*.json         other configurations through the same bench.py
 # Usage: bash profiles/run_round.sh gpurun_out/r02_final
 set -u
@@ -20,7 +23,13 @@ python tests/gpu_diag_steps.py --size 64 --march-step 20 --out "$OUT/steps_c1.md
 python tests/gpu_diag_steps.py --size 137 --march-step 100 --out "$OUT/steps_137_100.md" > /dev/null 2>&1
 DISTR_STICKY=0 python tests/gpu_diag_steps.py --size 137 --march-step 100 --out "$OUT/steps_137_100_nosticky.md" > /dev/null 2>&1
 python tests/gpu_diag_dense.py --stamps 2>&1 | grep -v amdgpu.ids > "$OUT/dense.log"
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# the opt-in arithmetic modes, same per-launch table
+python tests/gpu_diag_steps.py --arith bf16x6 --out "$OUT/steps_c3_bf16x6.md" > /dev/null 2>&1
+python tests/gpu_diag_steps.py --arith f16x3 --out "$OUT/steps_c3_f16x3.md" > /dev/null 2>&1
+for U in split_bf16_bounds split_f16_layer; do
+  ( cd profiles/ubench && hipcc -O3 --offload-arch=gfx950 $U.hip -o /tmp/$U 2>/dev/null && /tmp/$U ) > "$OUT/ubench_$U.log" 2>&1
+done
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass"      # the headline (exact f32) kernels only
 R=$(pwd)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- bash -c "cd $R && $CMD" > "$R/$OUT/rocprof_kt.log" 2>&1 )
 python profiles/summarize.py /tmp/prof_kt "$OUT/kernel_stats.md" > /dev/null 2>&1
@@ -36,6 +45,10 @@ python bench.py --size 64 --march-step 20 --no-cpu-baseline > "$OUT/extra_c1_64.
 python bench.py --marcher recursive --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/extra_c3_recursive.json" 2>/dev/null
 python bench.py --marcher trivial --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/extra_c3_trivial.json" 2>/dev/null
 python bench.py --fixture f2 --no-cpu-baseline > "$OUT/extra_c3_f2.json" 2>/dev/null
+python bench.py --arith bf16x6 --no-cpu-baseline > "$OUT/extra_c3_bf16x6.json" 2>/dev/null
+python bench.py --arith f16x3 --no-cpu-baseline > "$OUT/extra_c3_f16x3.json" 2>/dev/null
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt_h3 -- bash -c "cd $R && python bench.py --arith f16x3 --steps 5 --warmup 1 --no-cpu-baseline" > "$R/$OUT/rocprof_kt_f16x3.log" 2>&1 )
+python profiles/summarize.py /tmp/prof_kt_h3 "$OUT/kernel_stats_f16x3.md" > /dev/null 2>&1
 python tests/gpu_diag_loop.py 64 137 224 > "$OUT/loop.log" 2>&1
 python tests/gpu_diag_multiview.py > "$OUT/multiview.log" 2>&1
 python tests/gpu_diag_batch.py 137 8 recursive 2>&1 | grep -v "amdgpu.ids\|Warning\|warn\|Consider\|return Variable" > "$OUT/batch_round.log"
