@@ -18,6 +18,9 @@ Extra objects on the JSON line:
   roofline     the dominant kernel (fused march/MLP kernel k_march): algorithmic FLOP (3 146 752 per decoder
                evaluation, latent hoisted) / summed hipEvent kernel time on the launch stream, vs the 157.3 TFLOP/s
                f32-MFMA peak (the instruction the kernel uses: v_mfma_f32_32x32x2_f32)
+  split_bf16, split_f16   the same K steps in the two OPT-IN f32-equivalent arithmetics (distr_render_cfg.arith = 1 / 2: six bf16
+               products, or three f16 products on LDS-resident planes, per f32 product), same protocol; reported beside `value`,
+               never as it: `value` is exact f32, bit-identical to the oracle (--no-split-bf16-pass skips both passes)
   cpu_baseline the CPU oracle (oracle/, "port": C++, OpenMP) timed on this host's cores on one fwd+bwd of the same workload;
                cpu_baseline_torch: the PyTorch-CPU restatement (baseline 2) on a bounded sample + config C1
 """
@@ -185,7 +188,7 @@ def main():
     ap.add_argument('--arith', default='f32', choices=['f32', 'bf16x6', 'f16x3'],
                     help='f32 (default, the headline): exact f32 decoder evaluations; bf16x6: the opt-in six-product split-bf16 march tiles '
                          '(values within ~1e-6 of the exact ones; reported under its own name, never as the headline metric)')
-    ap.add_argument('--no-split-bf16-pass', action='store_true', help='skip the extra, separately reported pass with the opt-in split-bf16 march tiles')
+    ap.add_argument('--no-split-bf16-pass', action='store_true', help='skip the two extra, separately reported passes with the opt-in split-bf16 / split-f16 march tiles')
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
@@ -416,10 +419,10 @@ def main():
             stats = st if stats is None else {k: stats[k] + st[k] for k in st}
         return stats
 
-    # ---- extra pass (not part of `value`, reported under its own key): the same K steps with the OPT-IN split-bf16 march tiles
-    # (distr_render_cfg.arith = DISTR_ARITH_BF16X6: six bf16 products per f32 product, f32 accumulation; values within ~1e-6 of the
-    # exact ones, parity against the reference's goldens at the 1e-4 bar: tests). Same protocol: warm-up, barrier + synchronize on both
-    # sides, max over ranks. The headline stays the exact-f32 number above.
+    # ---- extra passes (not part of `value`, reported under their own keys): the same K steps with the OPT-IN split-bf16 and split-f16
+    # march tiles (distr_render_cfg.arith = DISTR_ARITH_BF16X6 / _F16X3: six bf16 / three f16 products per f32 product, f32 accumulation;
+    # values within ~1e-6 of the exact ones, parity against the reference's goldens at the 1e-4 bar: tests). Same protocol: warm-up,
+    # barrier + synchronize on both sides, max over ranks. The headline stays the exact-f32 number above.
     split_modes = {}
     if args.arith == 'f32' and not args.no_split_bf16_pass:
         for mode in ('bf16x6', 'f16x3'):

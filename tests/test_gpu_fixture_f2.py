@@ -56,7 +56,7 @@ def _floor():
 @pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1f2_*.npz'))))
 def test_f2_hip_matches_reference_goldens(engine_f2, f2, name, arith):
     """HIP path on F2 directly against outputs of the reference itself (64 x 64, 20 steps: three marchers + autograd normals), in the
-    exact f32 arithmetic and in the opt-in split-bf16 arithmetic."""
+    exact f32 arithmetic and in the two opt-in split arithmetics (outputs at the same bars, gradients at 5e-3)."""
     from distr import fixture
     g = dict(np.load(os.path.join(GOLDEN, name)))
     assert str(g['fixture']) == 'f2' and fixture.weights_sha256(f2[0], f2[1]) == str(g['weights_sha256'])
@@ -70,6 +70,11 @@ def test_f2_hip_matches_reference_goldens(engine_f2, f2, name, arith):
     key = 'c1_%s_%s' % (str(g['marcher']), 'd2n' if bool(g['use_depth2normal']) else 'agn')
     # gradient bar: 2 x what the reference moves by itself under 1e-7 weight noise on this fixture (not below 2e-3)
     tol_grad = max(2e-3, 2.0 * max(fl.get(key + '_g_latent_rel', 0.0), fl.get(key + '_g_R_rel', 0.0), fl.get(key + '_g_T_rel', 0.0)))
+    if arith != 'f32':
+        # the split arithmetics move sdf values by up to ~9e-7 -- several times the 1e-7 relative weight noise the floors were
+        # recorded with -- so one more stop-step / selected-row event than the reference's own noise produces is expected on a 64 x 64
+        # image; through depth2normal such an event is worth a few 1e-3 of the gradient (measured: bf16x6 2.7e-3 on the pyramid case)
+        tol_grad = max(tol_grad, 5e-3)
     fx = float(g['K'][0, 0])
     res = helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=tol_grad,
                           normal_p99=max(1e-4, 1e-5 * fx) if bool(g['use_depth2normal']) else 1e-4)
