@@ -257,3 +257,42 @@ def test_split_bf16_batch_and_band_consistency(engine, fixture_decoder, arith):
     stand-alone renders byte for byte, forward and backward."""
     _check_batch(engine, fixture_decoder, 96, 80, 3, False, None, march_step=30, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True,
                  arith=arith)
+
+
+@pytest.mark.parametrize('arith', ['bf16x6', 'f16x3'])
+def test_split_arithmetics_over_several_shapes(engine, fixture_decoder, arith):
+    """The opt-in arithmetics on the other shape codes of BASELINE config C5 (latent seeds 1235..1237) and from two more cameras: as
+    close to the exact render as on the fixture's own code (<= 0.1 % flips, depth p99 <= 5e-6, max <= 1e-4), and -- for the split-f16
+    form, whose validity depends on the activations' range -- not one overflow."""
+    import ctypes as C
+    import torch
+    from distr import binding, fixture, functions
+    _, _, latent0 = fixture_decoder
+    H = W = 160
+    K = fixture.make_intrinsic(H, W)
+    dev = engine.device
+    p = binding.ptr
+    for i, seed in enumerate((1235, 1236, 1237)):
+        latent = fixture.make_latent(seed)
+        cam = ((35.0 * i, 15.0, 1.6, 0.0), (-60.0, 30.0 - 10.0 * i, 1.7, 5.0))[i % 2]
+        a = _render_arith(engine, latent, H, W, cam, arith, march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+        b = _render_arith(engine, latent, H, W, cam, 'f32', march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+        ma, mb = a['mask'].reshape(H, W).astype(bool), b['mask'].reshape(H, W).astype(bool)
+        both = ma & mb
+        dz = np.abs(a['zdepth'].reshape(H, W) - b['zdepth'].reshape(H, W))[both]
+        res = dict(seed=seed, valid=int(mb.sum()), flips=int((ma != mb).sum()), p99=float(np.percentile(dz, 99)), zmax=float(dz.max()),
+                   g=float(np.abs(a['g_latent'] - b['g_latent']).max() / np.abs(b['g_latent']).max()))
+        print(arith, res)
+        assert mb.sum() > 500 and res['flips'] <= max(2, int(0.001 * mb.sum())) and res['p99'] <= 5e-6 and res['zmax'] <= 1e-4, res
+        assert np.isfinite(a['g_latent']).all() and res['g'] <= 2e-2, res
+        if arith == 'f16x3':      # the range check of the march: counters of one forward
+            R, T = fixture.make_camera(*cam)
+            cfg = binding.make_cfg((H, W), K, march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True, arith=arith)
+            n = H * W
+            ws = torch.empty(engine.ctx.workspace_bytes(cfg)[0], dtype=torch.uint8, device=dev)
+            outs = [torch.empty(n, device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev),
+                    torch.empty(n, 3, device=dev)]
+            engine.ctx.check(engine.ctx.L.distr_render_forward(engine.ctx.h, C.byref(cfg), p(torch.from_numpy(latent).to(dev)),
+                                                               p(torch.from_numpy(R).to(dev).reshape(-1).contiguous()), p(torch.from_numpy(T).to(dev)),
+                                                               p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(), engine.ctx.stream()))
+            assert engine.ctx.render_stats(cfg, ws)['f16_overflows'] == 0
