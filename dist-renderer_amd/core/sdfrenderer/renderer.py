@@ -5,19 +5,34 @@ method), but nothing is marched in PyTorch: `render` / `render_depth` / `render_
 libdistr.so (distr.functions), which run the whole march loop, sample selection and backward on the GPU without
 host synchronisation.
 """
+import os
+
 import numpy as np
 import torch
 
 from distr import binding, functions
 
 
+def default_arith():
+    """Arithmetic of a renderer constructed without `arith=` -- what the reference's drivers do when they run unchanged
+    (`python -m distr.launch [--arith f16x3] run_single_shape.py ...` sets DISTR_ARITH for them): 'f32' unless the environment says
+    otherwise; an unknown name is an error, not a silent fallback."""
+    a = os.environ.get('DISTR_ARITH') or 'f32'
+    if a not in binding.ARITH:
+        raise ValueError("DISTR_ARITH=%r: must be one of %s" % (a, sorted(binding.ARITH)))
+    return a
+
+
 class SDFRenderer(object):
     # reference: renderer.py:13
     def __init__(self, decoder, intrinsic, img_hw=None, transform_matrix=None, march_step=50, buffer_size=5,
                  ray_marching_ratio=1.5, use_depth2normal=False, max_sample_dist=0.2, radius=1.0, threshold=5e-5,
-                 scale_list=[4, 2, 1], march_step_list=[3, 3, -1], use_gpu=True, is_eval=True, arith='f32'):
-        # arith (not in the reference): 'f32' = exact f32 decoder evaluations (default); 'bf16x6' = the six-product split-bf16 march
-        # tiles (values within ~1e-6, ~1.5x the dense rate, no cluster tiles: for large dense renders); also settable later (self.arith)
+                 scale_list=[4, 2, 1], march_step_list=[3, 3, -1], use_gpu=True, is_eval=True, arith=None):
+        # arith (not in the reference): 'f32' = exact f32 decoder evaluations (default); 'bf16x6' / 'f16x3' = the opt-in split-bf16 /
+        # split-f16 march tiles (values within ~1e-6, 1.5x / 2x the step rate, no cluster tiles: for large dense renders; f16x3 only for
+        # decoders inside the f16 range, see distr_render_stats.f16_overflows); None = default_arith(); also settable later (self.arith)
+        if arith is None:
+            arith = default_arith()
         if arith not in binding.ARITH:
             raise ValueError("arith must be one of %s" % sorted(binding.ARITH))
         self.arith = arith

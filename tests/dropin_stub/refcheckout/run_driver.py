@@ -39,4 +39,5 @@ print(json.dumps({
     'SDFRenderer': where(SDFRenderer), 'SDFRenderer_warp': where(SDFRenderer_warp), 'load_decoder': where(load_decoder),
     'downsize_camera_intrinsic': where(downsize_camera_intrinsic), 'get_tensor_from_camera': where(get_tensor_from_camera),
     'create_mesh_speedup': where(create_mesh_speedup),
+    'default_arith': sys.modules[SDFRenderer.__module__].default_arith(),      # (this build's launcher option, not in the reference)
 }))

@@ -296,3 +296,36 @@ def test_split_arithmetics_over_several_shapes(engine, fixture_decoder, arith):
                                                                p(torch.from_numpy(R).to(dev).reshape(-1).contiguous()), p(torch.from_numpy(T).to(dev)),
                                                                p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(ws), ws.numel(), engine.ctx.stream()))
             assert engine.ctx.render_stats(cfg, ws)['f16_overflows'] == 0
+
+
+def test_renderer_takes_its_default_arithmetic_from_the_environment(fixture_decoder, monkeypatch):
+    """What `python -m distr.launch --arith f16x3 <driver>` arranges for renderers the driver constructs without `arith=`: the
+    renderer really renders in that mode (depth within the mode's distance of the exact render, not equal to it), an explicit
+    `arith=` wins, an unknown name raises."""
+    import torch
+    from core.graph.deep_sdf_decoder import Decoder
+    from core.sdfrenderer import SDFRenderer
+    from distr import fixture
+    Ws, bs, latent = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W), ('bias', b))})
+    dec = dec.cuda()
+    size = 96
+    K = fixture.make_intrinsic(size, size)
+    R, T = fixture.make_camera(30.0, 20.0, 1.6, 0.0)
+    lat, Rt, Tt = (torch.from_numpy(a).cuda() for a in (latent, R, T))
+    monkeypatch.delenv('DISTR_ARITH', raising=False)
+    exact = SDFRenderer(dec, K, img_hw=(size, size), march_step=30, buffer_size=3)
+    assert exact.arith == 'f32'
+    monkeypatch.setenv('DISTR_ARITH', 'f16x3')
+    fast = SDFRenderer(dec, K, img_hw=(size, size), march_step=30, buffer_size=3)
+    assert fast.arith == 'f16x3' and SDFRenderer(dec, K, img_hw=(size, size), arith='f32').arith == 'f32'
+    with torch.no_grad():
+        da, ma = exact.render_depth(lat, Rt, Tt)[:2]
+        db, mb = fast.render_depth(lat, Rt, Tt)[:2]
+    both = (ma.reshape(-1) > 0) & (mb.reshape(-1) > 0)
+    d = (da.reshape(-1) - db.reshape(-1)).abs()[both]
+    assert int(both.sum()) > 500 and float(d.max()) <= 1e-4 and float(d.max()) > 0.0
+    monkeypatch.setenv('DISTR_ARITH', 'fp8')
+    with pytest.raises(ValueError, match='DISTR_ARITH'):
+        SDFRenderer(dec, K, img_hw=(size, size))

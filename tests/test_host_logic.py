@@ -223,8 +223,18 @@ def test_dropin_coexists_with_reference_checkout():
     while every mirrored module -- also through the reference's FLAT imports (`from create_mesh import ...`,
     `from decoder_utils import decode_sdf`) -- resolves to this build. Reference checkout = tests/dropin_stub (stubs)."""
     j = _run_driver([sys.executable, '-m', 'distr.launch', os.path.join(STUB, 'run_driver.py'), '--gpu', '0'])
-    assert j['argv'] == ['--gpu', '0']
+    assert j['argv'] == ['--gpu', '0'] and j['default_arith'] == 'f32'
     _check_driver_resolution(j)
+    # the launcher's own option: an opt-in arithmetic for renderers the driver constructs without `arith=`; the driver's arguments pass through
+    j = _run_driver([sys.executable, '-m', 'distr.launch', '--arith', 'f16x3', os.path.join(STUB, 'run_driver.py'), '--gpu', '0'], {'DISTR_ARITH': ''})
+    assert j['argv'] == ['--gpu', '0'] and j['default_arith'] == 'f16x3'
+    import subprocess
+    bad = subprocess.run([sys.executable, '-m', 'distr.launch', '--arith', 'fp8', os.path.join(STUB, 'run_driver.py')], env=dict(os.environ, PYTHONPATH=PKG),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and 'arith' in bad.stderr
+    bad = subprocess.run([sys.executable, '-m', 'distr.launch', os.path.join(STUB, 'run_driver.py')], env=dict(os.environ, PYTHONPATH=PKG, DISTR_ARITH='fp8'),
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and 'DISTR_ARITH' in bad.stderr          # an unknown name is an error, not a silent fallback to f32
 
 
 def test_dropin_with_explicit_sys_path_order():
