@@ -38,20 +38,20 @@ def create_sdf_grid(decoder, latent_vec, N=256, transform=False, arith='f32'):
     return infer_samples(decoder, latent_vec, get_samples(N, transform=transform, device=dev), arith=arith).reshape(N, N, N)
 
 
-def create_sdf_grid_speedup(decoder, latent_vec, N=256, transform=False, relaxation=1.5):
+def create_sdf_grid_speedup(decoder, latent_vec, N=256, transform=False, relaxation=1.5, arith='f32'):
     """Coarse-to-fine grid (create_mesh.py:100-131): evaluate N/2 per axis, nearest-upsample, and evaluate the full
-    grid only where |sdf_half| <= relaxation * coarse voxel size; elsewhere +-0.1."""
+    grid only where |sdf_half| <= relaxation * coarse voxel size; elsewhere +-0.1. `arith`: as in create_sdf_grid."""
     assert N % 2 == 0
     dev = next(decoder.parameters()).device
     Nh = N // 2
     vs_half = 2.0 / (Nh - 1)
-    half = infer_samples(decoder, latent_vec, get_samples(Nh, voxel_size=vs_half, transform=transform, device=dev)).reshape(Nh, Nh, Nh)
+    half = infer_samples(decoder, latent_vec, get_samples(Nh, voxel_size=vs_half, transform=transform, device=dev), arith=arith).reshape(Nh, Nh, Nh)
     up = half.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(-1)
     band = up.abs() <= vs_half * relaxation
     grid = torch.where(up > 0, torch.full_like(up, 0.1), torch.full_like(up, -0.1))
     pts = get_samples(N, transform=transform, device=dev)
     if bool(band.any()):
-        grid[band] = infer_samples(decoder, latent_vec, pts[band])
+        grid[band] = infer_samples(decoder, latent_vec, pts[band], arith=arith)
     return grid.reshape(N, N, N)
 
 

@@ -1,6 +1,6 @@
 """Row f1 timing (not a pytest file): the 256^3 SDF grid the reference's create_mesh evaluates for marching cubes (16.8 M points,
 core/evaluation/create_mesh.py:56-68; there: 512 batches of 32^3 points with a host round trip each), plain and coarse-to-fine.
-    python tests/gpu_diag_grid.py"""
+    python tests/gpu_diag_grid.py [arith]      (arith: f32 (default) | bf16x6 | f16x3, passed to create_sdf_grid / _speedup)"""
 import os
 import sys
 import time
@@ -22,6 +22,11 @@ def main():
     dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W), ('bias', b))})
     dec = dec.cuda()
     lat = torch.from_numpy(latent).cuda()
+    arith = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+    import functools
+    create_sdf_grid = functools.partial(create_sdf_grid, arith=arith)
+    create_sdf_grid_speedup = functools.partial(create_sdf_grid_speedup, arith=arith)
+    print('arith', arith)
     for name, fn in (('create_sdf_grid', create_sdf_grid), ('create_sdf_grid_speedup', create_sdf_grid_speedup)):
         for N in (128, 256):
             fn(dec, lat, N)

@@ -1523,6 +1523,9 @@ def test_decode_sdf_split_bf16_is_f32_equivalent(fixture_decoder, fix, arith):
     dec = dec.cuda()
     g0, g1 = create_sdf_grid(dec, lat, 48), create_sdf_grid(dec, lat, 48, arith=arith)
     assert float((g0 - g1).abs().max()) <= 1e-5 and bool(((g0 > 0) == (g1 > 0)).float().mean() > 0.9999)
+    from core.evaluation import create_sdf_grid_speedup
+    h0, h1 = create_sdf_grid_speedup(dec, lat, 48), create_sdf_grid_speedup(dec, lat, 48, arith=arith)      # coarse-to-fine variant: same band (up to a voxel at its edge), same values
+    assert bool(((h0 - h1).abs() <= 1e-5).float().mean() > 0.999) and bool(((h0 > 0) == (h1 > 0)).float().mean() > 0.9999)
     with pytest.raises(ValueError):
         functions.mlp_eval(eng, lat, pts, arith='fp8')
 
