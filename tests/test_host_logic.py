@@ -444,3 +444,23 @@ def test_balance_views_properties_random():
         assert load.max() <= max(times) * (1.0 + 1e-9)
         moved += sum(len(p) > 1 for p in plan) > 0
     assert moved > 100          # the sweep really exercises plans that move rows
+
+
+def test_split_study_pieces_reconstruct_their_operand():
+    """The splitting the numerics study (oracle/study_split_bf16.py) and the kernels' host-side packers are built on: three bf16
+    pieces carry a f32 value exactly; two f16 pieces of the x64-scaled value carry 22 bits (relative error <= 2^-21) down to where
+    the second piece enters the f16 denormals (|x| ~ 2e-3), below that an absolute error of half a denormal step (2^-25 / 64 = 4.7e-10)
+    -- over the magnitudes the decoder has (weights ~1e-4 .. 0.5, activations ~1e-4 .. 10)."""
+    import torch
+    from oracle.study_split_bf16 import pieces, pieces16
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(20000, generator=g) * s for s in (1e-4, 1e-2, 0.5, 10.0)])
+    p3 = pieces(x, 3)
+    assert torch.equal(p3[0] + p3[1] + p3[2], x)
+    for q in p3:
+        assert torch.equal(q.detach().to(torch.bfloat16).to(torch.float32), q.detach())      # every piece is a bf16 number
+    h2 = pieces16(x, 2)
+    err = ((h2[0] + h2[1]) - x).abs()
+    assert bool((err <= torch.maximum(x.abs() * 2.0 ** -21, torch.full_like(x, 2.0 ** -25 / 64))).all())
+    for q in h2:
+        assert torch.equal((q.detach() * 64).to(torch.float16).to(torch.float32) / 64, q.detach())
