@@ -194,6 +194,9 @@ struct Carver {
 
 int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (!c) return fail(ctx, DISTR_ERR_INVALID_ARG, "cfg is null");
+  if (c->struct_size != sizeof(distr_render_cfg))      // ABI handshake (include/distr.h): a caller built against another header
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_render_cfg.struct_size is %u, this library (ABI %u) expects %zu: caller compiled against "
+                "another include/distr.h, or the struct was not initialised with DISTR_INIT", c->struct_size, DISTR_ABI_VERSION, sizeof(distr_render_cfg));
   if (c->H < 1 || c->W < 1 || (int64_t)c->H * c->W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", c->H, c->W);
   if (c->buffer_size < 1 || c->buffer_size > MAX_BS) return fail(ctx, DISTR_ERR_UNSUPPORTED, "buffer_size %d not in [1,%d]", c->buffer_size, MAX_BS);
   if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
@@ -380,13 +383,21 @@ struct MarchTimer {  // optional hipEvent bracket around the march kernel launch
 
 extern "C" {
 
-const char* distr_version(void) { return "distr 0.1 (gfx950, f32 MFMA)"; }
+const char* distr_version(void) { return "distr 0.4 (ABI 4; gfx950, f32 MFMA)"; }
 
-int distr_create(distr_ctx** out, int hip_device) {
+uint32_t distr_abi_version(void) { return DISTR_ABI_VERSION; }
+
+int distr_create_abi(distr_ctx** out, int hip_device, uint32_t abi_version) {
   if (!out) return DISTR_ERR_INVALID_ARG;
   *out = nullptr;
   distr_ctx* ctx = new distr_ctx();
   ctx->device = hip_device;
+  if (abi_version != DISTR_ABI_VERSION) {
+    ctx->err = "caller was built for distr ABI " + std::to_string(abi_version) + ", this library implements ABI " +
+               std::to_string(DISTR_ABI_VERSION) + ": rebuild the caller against this include/distr.h";
+    *out = ctx;
+    return DISTR_ERR_INVALID_ARG;
+  }
   if (const char* e = getenv("DISTR_HYBRID_THRESHOLD")) ctx->hybrid_threshold = atoi(e);
   if (const char* e = getenv("DISTR_TAIL16_THRESHOLD")) ctx->tail16_threshold = atoi(e);
   if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
@@ -561,6 +572,7 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
 int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
   if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
   EntryGuard guard_(ctx);
+  if (desc->struct_size != sizeof(distr_decoder_desc)) return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_decoder_desc.struct_size is %u, expected %zu", desc->struct_size, sizeof(distr_decoder_desc));
   if (desc->latent_size != LAT || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: kernels are "
                 "specialised for DeepSDF 8x512 (latent 256, latent_in=[4])", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
@@ -573,6 +585,7 @@ int distr_set_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const floa
 int distr_set_color_decoder(distr_ctx* ctx, const distr_decoder_desc* desc, const float* w, size_t n_floats) {
   if (!ctx || !desc || !w) return fail(ctx, DISTR_ERR_INVALID_ARG, "null argument");
   EntryGuard guard_(ctx);
+  if (desc->struct_size != sizeof(distr_decoder_desc)) return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_decoder_desc.struct_size is %u, expected %zu", desc->struct_size, sizeof(distr_decoder_desc));
   if (desc->latent_size <= LAT || desc->latent_size > 4096 || desc->hidden != HID || desc->num_linear != 9 || desc->latent_in != 4)
     return fail(ctx, DISTR_ERR_UNSUPPORTED, "colour decoder (latent %d, hidden %d, %d linears, latent_in %d) unsupported: expected the "
                 "DeepSDF 8x512 shape with latent = 256 + color_size and last_dim = 3", desc->latent_size, desc->hidden, desc->num_linear, desc->latent_in);
@@ -1136,6 +1149,8 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   EntryGuard guard_(ctx);
   int rc = check_cfg(ctx, cfg);
   if (rc) return rc;
+  if (out->struct_size != sizeof(distr_render_stats))   // never write past what the caller allocated
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_render_stats.struct_size is %u, expected %zu (set it before the call)", out->struct_size, sizeof(distr_render_stats));
   View V;
   make_view(*cfg, const_cast<void*>(ws), V, ctx->save_masks);
   hipStream_t s = (hipStream_t)stream;
@@ -1145,6 +1160,7 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   HIP_TRY(hipStreamSynchronize(s));
   const Consts* C = (const Consts*)hostbuf.data();
   memset(out, 0, sizeof(*out));
+  out->struct_size = (uint32_t)sizeof(*out);
   out->num_in_sphere = C->cnt_level[0];
   int64_t ev = 0, launches = 0;
   for (int l = 1; l < V.nlev; ++l) { ev += (int64_t)V.lv[l].steps * C->cnt_level[l]; launches += V.lv[l].steps; }
@@ -1293,6 +1309,7 @@ int distr_warp_loss_forward(distr_ctx* ctx, const distr_warp_cfg* cfg, const flo
                             void* ws, size_t ws_bytes, void* stream) {
   if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
   EntryGuard guard_(ctx);
+  if (cfg->struct_size != sizeof(distr_warp_cfg)) return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_warp_cfg.struct_size is %u, expected %zu", cfg->struct_size, sizeof(distr_warp_cfg));
   int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
   if (rc) return rc;
   if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3)
@@ -1313,6 +1330,7 @@ int distr_warp_loss_backward(distr_ctx* ctx, const distr_warp_cfg* cfg, const fl
                              float* g_cam, void* ws, size_t ws_bytes, void* stream) {
   if (!ctx || !cfg) return DISTR_ERR_INVALID_ARG;
   EntryGuard guard_(ctx);
+  if (cfg->struct_size != sizeof(distr_warp_cfg)) return fail(ctx, DISTR_ERR_INVALID_ARG, "distr_warp_cfg.struct_size is %u, expected %zu", cfg->struct_size, sizeof(distr_warp_cfg));
   int rc = loss_args(ctx, cfg->H, cfg->W, ws, ws_bytes);
   if (rc) return rc;
   if (!zdepth1 || !mask1 || !zdepth2 || !img1 || !img2 || !R1 || !T1 || !R2 || !T2 || !out3 || !g_loss || !g_cam)

@@ -17,7 +17,7 @@ LIB_PATH = os.path.abspath(os.path.join(CSRC, 'libdistr.so'))
 
 MARCHERS = {'trivial': 0, 'recursive': 1, 'pyramid_recursive': 2}
 ARITH = {'f32': 0, 'bf16x6': 1, 'f16x3': 2}
-EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
+EXPORTS = ['distr_version', 'distr_abi_version', 'distr_create_abi', 'distr_destroy', 'distr_last_error', 'distr_set_decoder',
            'distr_workspace_bytes', 'distr_render_forward', 'distr_render_backward', 'distr_render_normal',
            'distr_mlp_workspace_bytes', 'distr_mlp_eval', 'distr_mlp_grad', 'distr_get_render_stats',
            'distr_profile_enable', 'distr_profile_read', 'distr_debug_mlp_layer', 'distr_debug_tile_timing',
@@ -26,6 +26,7 @@ EXPORTS = ['distr_version', 'distr_create', 'distr_destroy', 'distr_last_error',
            'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
            'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6', 'distr_mlp_eval_f16x3']
 
+ABI_VERSION = 4                                   # DISTR_ABI_VERSION of include/distr.h this mirror was written against
 MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
 VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
 
@@ -34,12 +35,21 @@ class DistrError(RuntimeError):
     pass
 
 
-class DecoderDesc(C.Structure):
-    _fields_ = [('latent_size', C.c_int32), ('hidden', C.c_int32), ('num_linear', C.c_int32), ('latent_in', C.c_int32)]
+class _Sized(C.Structure):
+    """Boundary structs start with `uint32_t struct_size` = sizeof(struct) (ABI handshake, include/distr.h): set on construction."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(type(self))
 
 
-class RenderCfg(C.Structure):
+class DecoderDesc(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('latent_size', C.c_int32), ('hidden', C.c_int32), ('num_linear', C.c_int32), ('latent_in', C.c_int32)]
+
+
+class RenderCfg(_Sized):
     _fields_ = [
+        ('struct_size', C.c_uint32),
         ('H', C.c_int32), ('W', C.c_int32),
         ('K_inv', C.c_float * 9),
         ('fx', C.c_float), ('fy', C.c_float),
@@ -66,8 +76,8 @@ class RenderCfg(C.Structure):
         return c
 
 
-class WarpCfg(C.Structure):
-    _fields_ = [('H', C.c_int32), ('W', C.c_int32), ('K', C.c_float * 9), ('K_inv', C.c_float * 9), ('thres_depth', C.c_float)]
+class WarpCfg(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('H', C.c_int32), ('W', C.c_int32), ('K', C.c_float * 9), ('K_inv', C.c_float * 9), ('thres_depth', C.c_float)]
 
 
 def make_warp_cfg(img_hw, intrinsic, thres_depth):
@@ -80,8 +90,8 @@ def make_warp_cfg(img_hw, intrinsic, thres_depth):
     return cfg
 
 
-class RenderStats(C.Structure):
-    _fields_ = [('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
+class RenderStats(_Sized):
+    _fields_ = [('struct_size', C.c_uint32), ('reserved', C.c_uint32), ('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
                 ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64), ('f16_overflows', C.c_int64)]
 
 
@@ -115,7 +125,15 @@ def lib():
             L = C.CDLL(LIB_PATH)
             vp, fp, u8p = C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
             L.distr_version.restype = C.c_char_p
-            L.distr_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+            try:
+                L.distr_abi_version.restype = C.c_uint32
+                got = int(L.distr_abi_version())
+            except AttributeError:
+                got = None
+            if got != ABI_VERSION:      # a stale libdistr.so next to newer Python (or the reverse): refuse before any struct crosses
+                raise DistrError('libdistr.so at %s implements ABI %s, this binding was written for ABI %d: rebuild it '
+                                 '(python __graft_entry__.py build)' % (LIB_PATH, got, ABI_VERSION))
+            L.distr_create_abi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint32]
             L.distr_destroy.argtypes = [vp]
             L.distr_destroy.restype = None
             L.distr_last_error.argtypes = [vp]
@@ -208,7 +226,7 @@ class Context(object):
         self.device_index = int(device_index)
         self.L = lib()
         h = C.c_void_p()
-        rc = self.L.distr_create(C.byref(h), self.device_index)
+        rc = self.L.distr_create_abi(C.byref(h), self.device_index, ABI_VERSION)
         self.h = h
         if rc != 0:
             msg = self.L.distr_last_error(h).decode() if h else 'distr_create failed'
@@ -229,12 +247,12 @@ class Context(object):
 
     def set_decoder(self, flat_weights):
         w = np.ascontiguousarray(flat_weights, dtype=np.float32)
-        desc = DecoderDesc(256, 512, 9, 4)
+        desc = DecoderDesc(latent_size=256, hidden=512, num_linear=9, latent_in=4)
         self.check(self.L.distr_set_decoder(self.h, C.byref(desc), w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
 
     def set_color_decoder(self, flat_weights, latent_size):
         w = np.ascontiguousarray(flat_weights, dtype=np.float32)
-        desc = DecoderDesc(int(latent_size), 512, 9, 4)
+        desc = DecoderDesc(latent_size=int(latent_size), hidden=512, num_linear=9, latent_in=4)
         self.check(self.L.distr_set_color_decoder(self.h, C.byref(desc), w.ctypes.data_as(C.POINTER(C.c_float)), w.size))
 
     def workspace_bytes(self, cfg):
@@ -269,7 +287,7 @@ class Context(object):
     def render_stats(self, cfg, ws):
         st = RenderStats()
         self.check(self.L.distr_get_render_stats(self.h, C.byref(cfg), C.c_void_p(ws.data_ptr()), C.byref(st), self.stream()))
-        return {k: getattr(st, k) for k, _ in RenderStats._fields_}
+        return {k: getattr(st, k) for k, _ in RenderStats._fields_ if k not in ('struct_size', 'reserved')}
 
 
 def ptr(t):

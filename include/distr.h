@@ -14,16 +14,31 @@
  *   - all functions return 0 (DISTR_OK) or a negative error code; distr_last_error() gives text;
  *   - a context is bound to one HIP device; it is not thread-safe, distinct contexts are independent;
  *   - everything is float32 except masks (uint8) -- the same types the reference computes in.
+ *
+ * ABI handshake (the reference's counterpart is the constructor contract SDFRenderer.__init__, renderer.py:13: a caller that
+ * passes the wrong arguments gets a TypeError, not a corrupted render). Two checks, so that a caller compiled against an older
+ * header fails loudly instead of passing shifted fields:
+ *   - distr_create is a macro over distr_create_abi(out, device, DISTR_ABI_VERSION): the library refuses (DISTR_ERR_INVALID_ARG)
+ *     a caller built for another ABI version; a binary that still links the old `distr_create` symbol does not load at all;
+ *   - every struct that crosses the boundary starts with `uint32_t struct_size`, which the caller sets to sizeof(the struct)
+ *     (DISTR_INIT zeroes a struct and sets it); every entry point that takes the struct checks it (DISTR_ERR_INVALID_ARG), and
+ *     distr_get_render_stats never writes past the size the caller announced.
  */
 #ifndef DISTR_H_
 #define DISTR_H_
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define DISTR_ABI_VERSION 4u /* bumped whenever a struct layout or an entry point's signature changes (4: struct_size fields, distr_create_abi) */
+
+/* zero a boundary struct and announce its size: distr_render_cfg cfg; DISTR_INIT(cfg); cfg.H = ...; */
+#define DISTR_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); } while (0)
 
 #define DISTR_OK 0
 #define DISTR_ERR_INVALID_ARG (-1)
@@ -58,6 +73,7 @@ typedef struct distr_ctx distr_ctx;
  * specs.json handling of load_decoder (core/utils/decoder_utils.py:7-27). The kernels are specialised
  * for DeepSDF "8x512": latent 256, hidden 512, latent_in=[4], ReLU, final tanh, no LayerNorm. */
 typedef struct distr_decoder_desc {
+  uint32_t struct_size; /* sizeof(distr_decoder_desc) */
   int32_t latent_size;  /* 256 */
   int32_t hidden;       /* 512 */
   int32_t num_linear;   /* 9  (lin0..lin8) */
@@ -67,6 +83,7 @@ typedef struct distr_decoder_desc {
 /* Per-renderer + per-call options: SDFRenderer.__init__ (renderer.py:13-59) and the keyword arguments
  * of render / render_depth (renderer.py:836, 943). */
 typedef struct distr_render_cfg {
+  uint32_t struct_size;       /* sizeof(distr_render_cfg): checked by every entry point that takes a cfg (ABI handshake, top of this file) */
   int32_t H, W;               /* img_hw                                                     renderer.py:31-35 */
   float K_inv[9];             /* float32(inv(K)), row-major                                 renderer.py:161-164 */
   float fx, fy;               /* K[0,0], K[1,1] (depth2normal)                              renderer.py:973-974 */
@@ -107,6 +124,8 @@ typedef struct distr_render_cfg {
 
 /* Counters of one forward call (read back with distr_get_render_stats). */
 typedef struct distr_render_stats {
+  uint32_t struct_size;       /* IN: sizeof(distr_render_stats) of the caller; distr_get_render_stats refuses any other size */
+  uint32_t reserved;
   int64_t num_in_sphere;      /* rays hitting the unit sphere (N of renderer.py:473)   */
   int64_t num_march_launches; /* launches of the fused march/MLP kernel                */
   int64_t num_point_evals;    /* decoder evaluations executed by the march kernel      */
@@ -119,7 +138,11 @@ typedef struct distr_render_stats {
                                  activation left the f16 range. Anything but 0 means the render is not to be trusted: use arith 1 or 0. */
 } distr_render_stats;
 
-int distr_create(distr_ctx** out, int hip_device);
+/* distr_create(&ctx, device): a macro, so that the ABI version the CALLER was compiled with reaches the library. A context is
+ * returned even on failure (read distr_last_error, then distr_destroy). */
+int distr_create_abi(distr_ctx** out, int hip_device, uint32_t abi_version);
+#define distr_create(out, hip_device) distr_create_abi((out), (hip_device), DISTR_ABI_VERSION)
+uint32_t distr_abi_version(void); /* DISTR_ABI_VERSION the LIBRARY was built with */
 void distr_destroy(distr_ctx* ctx);
 const char* distr_last_error(const distr_ctx* ctx);
 const char* distr_version(void);
@@ -295,6 +318,7 @@ int distr_single_loss_backward(distr_ctx* ctx, int32_t H, int32_t W, const float
  * points whose projected depth disagrees by (err^2 >= thres_depth) are dropped, and the loss is the mean L1 colour
  * difference of the kept points. */
 typedef struct distr_warp_cfg {
+  uint32_t struct_size; /* sizeof(distr_warp_cfg) */
   int32_t H, W;
   float K[9];        /* float32(K), row-major            renderer.py:37-39  */
   float K_inv[9];    /* float32(inv(K))                  renderer.py:161-164 */

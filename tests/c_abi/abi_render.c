@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   if (argc < 4) return 1;
   void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
-  int (*create)(distr_ctx**, int);
+  int (*create_abi)(distr_ctx**, int, uint32_t);
   void (*destroy)(distr_ctx*);
   const char* (*last_error)(const distr_ctx*);
   int (*set_decoder)(distr_ctx*, const distr_decoder_desc*, const float*, size_t);
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
                         float*, void*, size_t, void*);
   int (*render_backward)(distr_ctx*, const distr_render_cfg*, const void*, size_t, const float*, const float*, const float*, const float*,
                          float*, float*, float*, void*, size_t, void*);
-  SYM(create) SYM(destroy) SYM(last_error) SYM(set_decoder) SYM(workspace_bytes) SYM(render_forward) SYM(render_backward)
+  SYM(create_abi) SYM(destroy) SYM(last_error) SYM(set_decoder) SYM(workspace_bytes) SYM(render_forward) SYM(render_backward)
 
   /* in.bin: int64 n_weights | distr_render_cfg bytes | weights | latent[256] | R[9] | T[3] | g_depth[P] | g_min_sdf[P] | g_normal[3P] */
   FILE* f = fopen(argv[2], "rb");
@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
   fclose(f);
 
   distr_ctx* ctx = NULL;
-  CHECK(create(&ctx, 0));
-  distr_decoder_desc desc = {256, 512, 9, 4};
+  CHECK(create_abi(&ctx, 0, DISTR_ABI_VERSION));     /* = the distr_create macro, through dlsym */
+  distr_decoder_desc desc = {sizeof(distr_decoder_desc), 256, 512, 9, 4};
   CHECK(set_decoder(ctx, &desc, w, (size_t)nw));
   size_t fwd = 0, bwd = 0;
   CHECK(workspace_bytes(ctx, &cfg, &fwd, &bwd));

@@ -21,8 +21,9 @@ def libdistr():
 def test_library_exports_every_declared_symbol(libdistr):
     hdr = open(os.path.join(ROOT, 'include', 'distr.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    hdr = re.sub(r'^\s*#define.*$', '', hdr, flags=re.M)        # distr_create is a macro over distr_create_abi (ABI handshake)
     declared = set(re.findall(r'\b(distr_[a-z0-9_]+)\s*\(', hdr))
-    assert {'distr_create', 'distr_render_forward', 'distr_render_backward', 'distr_mlp_eval'} <= declared
+    assert {'distr_create_abi', 'distr_abi_version', 'distr_render_forward', 'distr_render_backward', 'distr_mlp_eval'} <= declared
     for name in declared:
         assert hasattr(libdistr, name), name
     from distr import binding
@@ -42,7 +43,7 @@ def test_cfg_struct_matches_header():
         for n in decl.split(None, 1)[1].split(','):
             names.append(n.strip().split('[')[0])
     assert names == [f[0] for f in binding.RenderCfg._fields_]
-    assert C.sizeof(binding.RenderCfg) == 4 * (2 + 9 + 2 + 9 + 2 + 4 + 1 + 2 + 3 + 3 + 1 + 2 + 1)
+    assert C.sizeof(binding.RenderCfg) == 4 * (1 + 2 + 9 + 2 + 9 + 2 + 4 + 1 + 2 + 3 + 3 + 1 + 2 + 1)
 
 
 def test_create_without_gpu_fails_loudly(libdistr):
@@ -50,13 +51,41 @@ def test_create_without_gpu_fails_loudly(libdistr):
     if torch.cuda.is_available():
         pytest.skip('GPU present')
     h = C.c_void_p()
-    rc = libdistr.distr_create(C.byref(h), 0)
+    from distr import binding
+    rc = libdistr.distr_create_abi(C.byref(h), 0, binding.ABI_VERSION)
     assert rc != 0
     assert b'device' in libdistr.distr_last_error(h)
     libdistr.distr_destroy(h)
-    from distr import binding
     with pytest.raises(binding.DistrError):
         binding.Context(0)
+
+
+def test_abi_handshake(libdistr):
+    """A caller built against another include/distr.h is refused before any field is interpreted (needs no GPU): wrong ABI version
+    at distr_create_abi, wrong / unset struct_size on every struct that crosses the boundary."""
+    from distr import binding
+    assert libdistr.distr_abi_version() == binding.ABI_VERSION
+    assert ('ABI %d' % binding.ABI_VERSION).encode() in libdistr.distr_version()
+    hdr = open(os.path.join(ROOT, 'include', 'distr.h')).read()
+    assert int(re.search(r'#define DISTR_ABI_VERSION (\d+)u', hdr).group(1)) == binding.ABI_VERSION
+    h = C.c_void_p()
+    assert libdistr.distr_create_abi(C.byref(h), 0, binding.ABI_VERSION - 1) == -1            # DISTR_ERR_INVALID_ARG
+    assert b'ABI' in libdistr.distr_last_error(h)
+    libdistr.distr_destroy(h)
+    h = C.c_void_p()
+    libdistr.distr_create_abi(C.byref(h), 0, binding.ABI_VERSION)                               # (fails for lack of a device; the context still answers)
+    cfg = binding.make_cfg((64, 64), np.array([[64., 0, 32], [0, 64., 32], [0, 0, 1]]), march_step=20, buffer_size=3)
+    assert cfg.struct_size == C.sizeof(binding.RenderCfg)
+    f, b = C.c_size_t(), C.c_size_t()
+    assert libdistr.distr_workspace_bytes(h, C.byref(cfg), C.byref(f), C.byref(b)) == 0 and f.value > 0
+    assert cfg.clone().struct_size == cfg.struct_size
+    for bad in (0, cfg.struct_size - 4, cfg.struct_size + 8, 64):     # zeroed struct, round 2's struct (no `arith`), a future one, an old H
+        cfg.struct_size = bad
+        assert libdistr.distr_workspace_bytes(h, C.byref(cfg), C.byref(f), C.byref(b)) == -1
+        assert b'struct_size' in libdistr.distr_last_error(h)
+    libdistr.distr_destroy(h)
+    for cls in (binding.DecoderDesc, binding.RenderStats, binding.WarpCfg):
+        assert cls().struct_size == C.sizeof(cls) and cls._fields_[0][0] == 'struct_size'
 
 
 def test_no_cpu_fallback_and_no_oracle_in_product():
