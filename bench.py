@@ -74,15 +74,24 @@ def cpu_baseline(fixture, Ws, bs, latent, size, march_step, marcher):
             'host': host_description()}
 
 
-def collective_info(world):
-    """What the collective layer itself reports (so that a reader can see RCCL saw N ranks): torch.distributed's backend and world
-    size, the RCCL version torch was built against, devices visible to rank 0."""
+def collective_info(world, local):
+    """What the collective layer itself reports (so that a reader can see RCCL saw N ranks on N distinct GPUs): torch.distributed's
+    backend and world size, the RCCL version torch was built against, and -- all-gathered -- the device every rank computes on."""
     import torch.distributed as dist
     info = {'backend': None, 'world_size': 1, 'devices_visible': torch.cuda.device_count()}
     if world > 1 and dist.is_initialized():
         info['backend'] = dist.get_backend()
         info['world_size'] = dist.get_world_size()
         info['backend_is_rccl'] = info['backend'] == 'nccl'       # torch's "nccl" backend IS RCCL on ROCm
+        props = torch.cuda.get_device_properties(local)
+        mine = {'rank': dist.get_rank(), 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device_index': int(local),
+                'device_name': props.name, 'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid()}
+        ranks = [None] * info['world_size']
+        dist.all_gather_object(ranks, mine)
+        info['ranks'] = ranks
+        info['distinct_devices'] = len({(r['device_index'], r['pci_bus_id']) for r in ranks})
+        # a scaling measurement needs RCCL and one GPU per rank; test rigs that time-share one GPU (DISTR_DIST_BACKEND=gloo) say so here
+        info['one_gpu_per_rank'] = bool(info['backend_is_rccl'] and info['distinct_devices'] == info['world_size'])
     try:
         info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
     except Exception:
@@ -211,6 +220,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback path exists)')
     backend = torch.distributed.get_backend() if world > 1 else None
+    if world > 1 and torch.distributed.get_world_size() != args.gpus:
+        raise SystemExit('--gpus %d but torch.distributed reports world size %d' % (args.gpus, torch.distributed.get_world_size()))
+    if world > 1 and backend != 'nccl' and not os.environ.get('DISTR_DIST_BACKEND'):
+        raise SystemExit('--gpus %d needs RCCL (torch.distributed backend "nccl"), got %r' % (world, backend))
     if world > 1 and backend == 'nccl' and torch.cuda.device_count() < world:
         raise SystemExit('--gpus %d but only %d HIP device(s) are visible: RCCL ranks cannot share a device (tests that time-share one '
                          'GPU set DISTR_DIST_BACKEND=gloo; such a run is not a scaling measurement)' % (world, torch.cuda.device_count()))
@@ -332,13 +345,48 @@ def main():
         last['grads'] = [l.grad for l in lats]
         return total
 
-    # ---- calibration (view-parallel runs only: c3, N > 1, dense loss), BEFORE the W warm-up steps and like them untimed. The eight
-    # cameras differ by up to 25 % in cost and every step ends in the all-reduce, so the slowest view would pace the job. The ranks
-    # all-gather their own step times and the row cost profile of their view (from its rendered mask), every rank computes the same
-    # plan (distr.parallel.balance_views), and the slowest views hand row bands (bit-identical to the same rows of the full render,
-    # gradients sum exactly) to the fastest ranks; the plan is refined once from the times measured under it
-    # (distr.parallel.refine_profiles). Total work is unchanged: N whole views per step. Five steps: 0-1 measure the whole views,
-    # 2 warms the first plan (new band shapes: allocator), 3 measures it, 4 warms the refined plan.
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides (nothing is recorded inside);
+        the MAX over ranks, plus what the all-reduce of the last step left on this rank (loss sum, latent gradients)."""
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        parallel.barrier()
+        return parallel.allreduce_max_scalar(el, device=dev), {'loss': float(loss_buf.item()), 'grads': [g.detach().clone() for g in last['grads']]}
+
+    def rank_diagnostics(n=3):
+        """(N > 1, outside the timed regions) what every rank spends on ITS OWN work of a step (hipEvents around render + loss +
+        backward) and how long it then sits in the all-reduce waiting for the slowest rank -- all-gathered, so that a bad scaling
+        curve can be read off the one JSON line: a straggler shows as one large local_ms, a slow fabric as a large wait everywhere."""
+        loc, wall = [], []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            parallel.barrier()
+            t0 = time.perf_counter()
+            step(measure=True)
+            torch.cuda.synchronize()
+            wall.append(1e3 * (time.perf_counter() - t0))
+            loc.append(local_ms[-1])
+        l_all = parallel.allgather_scalar(float(np.median(loc)), device=dev)
+        w_all = parallel.allgather_scalar(float(np.median(wall)), device=dev)
+        return {'local_ms': l_all, 'step_wall_ms': w_all, 'allreduce_and_wait_ms': [w - l for w, l in zip(w_all, l_all)]}
+
+    # ---- the timed region(s). N = 1, c5, --no-balance: ONE region (W warm-up + exactly K timed steps).
+    # View-parallel runs (c3, N > 1, dense loss) time the step TWICE with the same protocol: first unbalanced (exactly one whole view
+    # per GPU), then -- after five untimed calibration steps -- balanced: the eight cameras differ by up to 25 % in cost and every step
+    # ends in the all-reduce, so the slowest view paces the job. In the calibration the ranks all-gather their own step times and the
+    # row cost profile of their view (from its rendered mask), every rank computes the same plan (distr.parallel.balance_views), and
+    # the slowest views hand row bands (bit-identical to the same rows of the full render, gradients sum exactly) to the fastest
+    # ranks; the plan is refined once from the times measured under it (distr.parallel.refine_profiles). Total work is unchanged:
+    # N whole views per step. Five steps: 0-1 measure the whole views, 2 warms the first plan (new band shapes: allocator), 3
+    # measures it, 4 warms the refined plan. BOTH timings are reported (config.unbalanced_ms_per_step / balanced_ms_per_step);
+    # `value` is the better of the two and the passes after it run in that mode.
     balance = (not c5) and world > 1 and not args.no_balance and args.loss == 'dense' and not args.items
     plan = None
     view_of = lambda r: (r + args.view_offset) % 8
@@ -353,7 +401,16 @@ def main():
         pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
 
     calibration_steps = 0
+    elapsed, snap = timed_region()
+    timing = {'unbalanced': None, 'balanced': None}
+    diag = {}
+    snaps = {'chosen': snap}
+    if world > 1:
+        diag['unbalanced' if not c5 else 'row_bands'] = rank_diagnostics()
     if balance:
+        timing['unbalanced'] = elapsed
+        snaps['unbalanced'] = snap
+        plan0 = [[(r, 0, H)] for r in range(world)]
         step(measure=True)
         step(measure=True)
         times = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(local_ms[-1], device=dev)
@@ -373,20 +430,57 @@ def main():
             step()
             calibration_steps = 5
         if all(len(p) == 1 for p in plan):
-            plan = None                                              # nothing moved: plain one-view-per-GPU run
-    # ---- W warm-up steps
-    for w in range(args.warmup):
-        step()
-    # ---- the timed region: exactly K steps between barrier + synchronize on both sides; nothing is recorded inside it
-    torch.cuda.synchronize()
-    parallel.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    parallel.barrier()
-    elapsed = parallel.allreduce_max_scalar(elapsed, device=dev)
+            plan = None                                              # nothing moved: plain one-view-per-GPU run, already timed
+            apply_plan(plan0)
+        else:
+            el_b, snap_b = timed_region()
+            timing['balanced'] = el_b
+            snaps['balanced'] = snap_b
+            diag['balanced'] = rank_diagnostics()
+            if el_b < elapsed or fake:                               # (forced times: the tests want to see the plan's run)
+                elapsed, snaps['chosen'] = el_b, snap_b
+            else:
+                plan_tried, plan = plan, None                        # the balancer did not pay on this node: report it, run unbalanced
+                apply_plan(plan0)
+                timing['balance_plan_tried'] = plan_tried
+
+    # ---- serial check (N > 1, outside the timed regions): rank 0 renders ALL the job's images itself, one whole image after the
+    # other (the sum the reference accumulates serially before its single backward(), core/inv_optimizer/optimize_multi.py:62-81),
+    # and compares loss and shape-code gradients with what the all-reduce left after the timed steps. A sharded run that dropped a
+    # band, double-counted a view or reduced over the wrong ranks fails here, in the run that produces the number.
+    serial_check = None
+    if world > 1:
+        serial_check = {'images': (n_shapes if c5 else args.gpus), 'tolerance': {'loss_rel': 1e-5, 'grad_rel': 1e-4}}
+        if rank == 0:
+            for l in lats:
+                l.grad = None
+            tot = 0.0
+            todo = [(sh, 0) for sh in range(n_shapes)] if c5 else [(0, view_of(r)) for r in range(world)]
+            for (sh, v) in todo:
+                if v not in cams:
+                    Rv, Tv = view_camera(fixture, v)
+                    cams[v] = (torch.from_numpy(Rv).to(dev).requires_grad_(True), torch.from_numpy(Tv).to(dev).requires_grad_(True))
+                if args.loss == 'reference' and (sh, v) not in gts:
+                    pert = torch.from_numpy(0.1 * np.random.RandomState(900 + sh).standard_normal((1, 256)).astype(np.float32)).to(dev)
+                    with torch.no_grad():
+                        _, gm, _, gd, gn = functions.render_call(eng, cfg, lats[sh].detach() + pert, cams[v][0].detach(), cams[v][1].detach())
+                    gts[(sh, v)] = (gd.clone(), gn.clone(), gm.reshape(H, W).clone())
+                Ls = image_loss(functions.render_call(eng, cfg, lats[sh], cams[v][0], cams[v][1]), 0, H, (sh, v))
+                Ls.backward()
+                tot += float(Ls.detach())
+            gser = [(l.grad if l.grad is not None else zero_grad).detach().clone() for l in lats]
+            gmax = max(float(g.abs().max()) for g in gser)
+            for name, sn in snaps.items():
+                serial_check[name] = {'loss_rel': abs(sn['loss'] - tot) / max(abs(tot), 1e-30),
+                                      'grad_rel': max(float((a - b).abs().max()) for a, b in zip(sn['grads'], gser)) / max(gmax, 1e-30)}
+            serial_check['loss_serial_rank0'] = tot
+            serial_check['ok'] = all(v['loss_rel'] <= 1e-5 and v['grad_rel'] <= 1e-4 for k, v in serial_check.items() if k in snaps)
+            for l in lats:
+                l.grad = None
+            for (Rt, Tt) in cams.values():
+                Rt.grad = None
+                Tt.grad = None
+        parallel.barrier()
 
     # ---- second pass (not part of `value`): per-step wall times -> median (SURVEY.md 8d asks for the median of >= 20 iterations)
     per_step = []
@@ -424,7 +518,7 @@ def main():
     # values within ~1e-6 of the exact ones, parity against the reference's goldens at the 1e-4 bar: tests). Same protocol: warm-up,
     # barrier + synchronize on both sides, max over ranks. The headline stays the exact-f32 number above.
     split_modes = {}
-    if args.arith == 'f32' and not args.no_split_bf16_pass:
+    if args.arith == 'f32' and not args.no_split_bf16_pass and world == 1:     # (N > 1: the scaling run times the exact path only)
         for mode in ('bf16x6', 'f16x3'):
             cfg_m = cfg.clone()
             cfg_m.arith = binding.ARITH[mode]
@@ -489,6 +583,7 @@ def main():
             traffic = json.load(open(tpath))['bytes_per_launch']
         except Exception:
             traffic = None
+    rccl_info = collective_info(world, local)           # (collective: every rank takes part in the all-gather)
     if rank == 0:
         evals = stats['num_point_evals'] * ROOF_STEPS
         flops = FLOP_PER_EVAL * evals
@@ -509,7 +604,7 @@ def main():
                                                          ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
                                                           'ranks' if plan else '1 view per GPU')),
                        'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
-                       'rccl': collective_info(world),
+                       'rccl': rccl_info,
                        'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'calibration_steps_before_warmup': calibration_steps, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
                        'rays_in_sphere': stats['num_in_sphere'], 'valid_px': stats['num_valid'], 'fixture': args.fixture, 'arith': args.arith,
@@ -521,7 +616,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0, 'unit': 'TFLOP/s',
                          'frac': achieved / (PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0), 'traffic': traffic,
                          'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16 / f16 MFMA dense peak; algorithmic FLOP counted once (the six bf16 / three f16 products per f32 product are not counted several times)',
-                         'traffic_note': 'fabric-side bytes per march launch from a separate rocprofv3 PMC pass (%s)' % os.path.relpath(tpath, ROOT),
+                         'traffic_note': 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
                          'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
                                    % (ROOF_STEPS, launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
@@ -538,11 +633,26 @@ def main():
                 m = split_modes[mode]
                 m.update(value=rays / m.pop('elapsed_s'), unit='rays/s', speedup_vs_exact_f32=(elapsed / args.steps) / (m['ms_per_step'] * 1e-3), note=notes[mode])
                 out[key] = m
+        if world > 1:
+            c = out['config']
+            c['serial_check'] = serial_check
+            c['per_rank'] = diag
+            c['scaling_measurement'] = bool(rccl_info.get('one_gpu_per_rank'))       # false on test rigs whose ranks time-share one GPU over gloo
+            if balance:
+                c['unbalanced_ms_per_step'] = 1e3 * timing['unbalanced'] / args.steps
+                c['balanced_ms_per_step'] = (1e3 * timing['balanced'] / args.steps) if timing['balanced'] is not None else None
+                c['value_is'] = 'balanced' if plan else 'unbalanced'
+                if timing.get('balance_plan_tried'):
+                    c['balance_plan_tried'] = timing['balance_plan_tried']
         if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)
             out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np, H, MARCH_STEP, args.marcher)
             out['cpu_baseline_torch'] = cpu_baseline_torch(fixture, Ws, bs, latent_np, MARCH_STEP, args.marcher)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     parallel.barrier()
+    if world > 1:
+        ok = parallel.allreduce_max_scalar(0.0 if (rank != 0 or serial_check.get('ok')) else 1.0, device=dev) == 0.0
+        if not ok:
+            raise SystemExit('bench.py: the all-reduced loss / gradients do not match the serial sum over all images (config.serial_check)')
 
 
 if __name__ == '__main__':

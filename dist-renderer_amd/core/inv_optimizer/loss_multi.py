@@ -58,7 +58,7 @@ def compute_loss_color_warp_batch(sdf_renderer, shape_code, images, cameras, pai
     for (idx1, idx2) in pairs:
         (R1, T1), (R2, T2) = pair_cameras(cameras, idx1, idx2, dev, sim3, sim3_scale)
         args.append((R1, T1, R2, T2, images[idx1], images[idx2]))
-    outs = sdf_renderer.render_warp_batch(shape_code, args)
+    outs = sdf_renderer.render_warp_batch(shape_code, args, want_vis=False)     # only out[0] (the loss) is consumed here
     loss_l2reg = torch.mean(shape_code.pow(2))
     res = []
     for out in outs:

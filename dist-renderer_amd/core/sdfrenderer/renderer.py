@@ -36,6 +36,7 @@ class SDFRenderer(object):
         if arith not in binding.ARITH:
             raise ValueError("arith must be one of %s" % sorted(binding.ARITH))
         self.arith = arith
+        self._warn_small_split(img_hw, intrinsic)
         if not use_gpu:
             raise ValueError('SDFRenderer(use_gpu=False): this build has no CPU path (MI355X kernels only).')
         if torch.cuda.device_count() == 0:
@@ -127,6 +128,25 @@ class SDFRenderer(object):
             points = self.inv_transform_points(points)
         return points
 
+    _warned_small_split = False
+
+    def _warn_small_split(self, img_hw, intrinsic):
+        """The opt-in arithmetics pay on compute-bound renders only: their tiles have no cluster / sticky tail, so a small image --
+        every step a tail step -- gets SLOWER. One warning per process, with the measured numbers."""
+        if self.arith == 'f32' or SDFRenderer._warned_small_split:
+            return
+        try:
+            h, w = (int(img_hw[0]), int(img_hw[1])) if img_hw is not None else (int(2 * intrinsic[1][2]), int(2 * intrinsic[0][2]))
+        except Exception:           # noqa: BLE001
+            return
+        if h * w < 200 * 200:
+            import warnings
+            SDFRenderer._warned_small_split = True
+            warnings.warn("SDFRenderer(arith=%r) on a %dx%d image: the split arithmetics are meant for large, dense renders. Measured single-view "
+                          "iteration (render + losses + backward + Adam, MI355X, profiles/r03_arith_loops.log): 137x137 f32 9.2 ms, bf16x6 15.5 ms, "
+                          "f16x3 13.5 ms; 64x64 f32 5.5 / 14.0 / 12.3 ms. They win from about 256x256 up (512x512: 52.7 / 35.6 / 26.1 ms). "
+                          "Use arith='f32' (the default, exact) here." % (self.arith, h, w), RuntimeWarning, stacklevel=3)
+
     # ---- C-struct for one call
     def _cfg(self, clamp_dist, ray_marching_type, use_transform, want_normal, normalize_normal=True,
              no_grad_depth=False, no_grad_mask=False, no_grad_camera=False):
@@ -184,6 +204,15 @@ class SDFRenderer(object):
         zdepth, mask, min_sdf, _, _ = functions.render_batch_call(self._engine, cfg, latent, Rs, Ts, flags)
         # (a view rendered with no_grad_depth ignores the upstream gradient of its Zdepth row in the backward kernel: the
         # per-view flag does what the reference's .detach() does, renderer.py:876-877)
+        # min_sdf of a view with BOTH no_grad_mask and no_grad_camera is detached by render_depth (renderer.py:388-389 + 863: with the
+        # mask gradient off only the camera term of the rays that miss the sphere is left, and no_grad_camera removes that too): per
+        # view here, by routing those rows around the autograd node
+        dead = [ngm[v] and ngc[v] for v in range(B)]
+        if any(dead) and not all(dead):
+            keep = torch.tensor([not d for d in dead], device=min_sdf.device).reshape(B, 1)
+            min_sdf = torch.where(keep, min_sdf, min_sdf.detach())
+        elif all(dead):
+            min_sdf = min_sdf.detach()
         return zdepth, mask.bool(), min_sdf
 
     def render_normal_batch(self, latent, Rs, Ts, Zdepth, valid_mask, clamp_dist=0.1, normalize=True, use_transform=True):
@@ -192,6 +221,7 @@ class SDFRenderer(object):
         Ts = torch.stack(list(Ts)) if not torch.is_tensor(Ts) else Ts
         cfg = self._cfg(clamp_dist, 'recursive', use_transform, want_normal=True, normalize_normal=normalize)
         cfg.use_depth2normal = 0
+        cfg.save_for_backward = 0          # gradient-free pass: no ReLU-mask store in the workspace (512 B x P x (buffer_size + 1) per view)
         return functions.render_normal_batch_call(self._engine, cfg, latent, Rs, Ts, Zdepth, valid_mask)
 
     # reference: renderer.py:880
@@ -199,6 +229,7 @@ class SDFRenderer(object):
                       normalize=True, use_transform=True):
         cfg = self._cfg(clamp_dist, 'recursive', use_transform, want_normal=True, normalize_normal=normalize)
         cfg.use_depth2normal = 0
+        cfg.save_for_backward = 0          # gradient-free pass: no ReLU-mask store in the workspace
         return functions.render_normal_call(self._engine, cfg, latent, R, T, Zdepth, valid_mask)   # (3, H*W)
 
     # reference: renderer.py:943

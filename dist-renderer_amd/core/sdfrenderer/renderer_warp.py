@@ -41,12 +41,14 @@ class SDFRenderer_warp(SDFRenderer):
         return (loss_color, color1, color2, m1.reshape(h, w).to(torch.uint8), m2.reshape(h, w).to(torch.uint8),
                 q1.reshape(h, w), q2.reshape(h, w), n1, depth1)
 
-    def render_warp_batch(self, latent, pairs, clamp_dist=0.1, thres_depth=0.001):
+    def render_warp_batch(self, latent, pairs, clamp_dist=0.1, thres_depth=0.001, want_vis=True):
         """render_warp for several view pairs that share the shape code -- the body of the multi-view round
         (core/inv_optimizer/optimize_multi.py:62-81 calls render_warp once per pair; renderer_warp.py:108-109 renders both views of a
         pair with the same latent) -- with ALL 2n depth renders in one batched launch sequence and all n visualisation normals in
         another. `pairs` = [(R1, T1, R2, T2, img1, img2), ...]. Returns one 9-tuple per pair, each identical (bit for bit, values
-        and gradients) to render_warp(latent, *pair)."""
+        and gradients) to render_warp(latent, *pair). want_vis=False (the optimisation loop, which only consumes the
+        loss): the visualisation normal / depth images (entries 7, 8) are None and their normal pass (2.3 ms of a 93 ms round, plus its
+        workspace) is skipped."""
         h, w = self.img_hw
         dev = self.calib_map.device
         n = len(pairs)
@@ -55,15 +57,17 @@ class SDFRenderer_warp(SDFRenderer):
         ngd = [False, True] * n                      # view 2 of every pair: no_grad_depth (renderer_warp.py:109)
         Z, M, Q = self.render_depth_batch(latent, Rs, Ts, clamp_dist=clamp_dist, no_grad_depth=ngd)
         wcfg = binding.make_warp_cfg((h, w), self.intrinsic, thres_depth)
-        N1 = self.render_normal_batch(latent, Rs[0::2], Ts[0::2], Z[0::2].detach(), M[0::2], clamp_dist=clamp_dist)
+        N1 = self.render_normal_batch(latent, Rs[0::2], Ts[0::2], Z[0::2].detach(), M[0::2], clamp_dist=clamp_dist) if want_vis else None
         outs = []
         for i, (R1, T1, R2, T2, img1, img2) in enumerate(pairs):
             Z1, m1, q1, Z2, m2, q2 = Z[2 * i], M[2 * i], Q[2 * i], Z[2 * i + 1], M[2 * i + 1], Q[2 * i + 1]
             loss_color, keep, color1, color2 = functions.warp_loss(self._engine, wcfg, Z1, m1, Z2, img1.to(dev), img2.to(dev),
                                                                    R1, T1, R2, T2)
-            n1 = torch.matmul(R1.detach(), N1[i])
-            n1 = torch.cat([-n1[:1], n1[1:]], 0).reshape(3, h, w).permute(1, 2, 0)
-            depth1 = torch.where(m1, Z1.detach() * self.calib_map, torch.zeros_like(Z1)).reshape(h, w)
+            n1 = depth1 = None
+            if want_vis:
+                n1 = torch.matmul(R1.detach(), N1[i])
+                n1 = torch.cat([-n1[:1], n1[1:]], 0).reshape(3, h, w).permute(1, 2, 0)
+                depth1 = torch.where(m1, Z1.detach() * self.calib_map, torch.zeros_like(Z1)).reshape(h, w)
             outs.append((loss_color, color1, color2, m1.reshape(h, w).to(torch.uint8), m2.reshape(h, w).to(torch.uint8),
                          q1.reshape(h, w), q2.reshape(h, w), n1, depth1))
         return outs

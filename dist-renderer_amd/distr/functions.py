@@ -176,6 +176,35 @@ def _check_generation(ctx):
                            'forward and its backward; back-propagate before changing the decoder, or render again')
 
 
+F16_CHECK_EVERY = 256          # renders between two range checks of the split-f16 arithmetic (DISTR_F16_CHECK_EVERY; the first render of
+                               # every decoder upload is always checked)
+
+
+def _check_f16_range(engine, cfg, ws, nviews=1, view_bytes=0):
+    """arith = 'f16x3' only. A decoder activation that leaves the f16 range makes the march see a NaN sdf, which fails both `stay`
+    comparisons and silently ends the ray -- a driver would optimise on corrupted renders. The march kernel counts such evaluations
+    (distr_render_stats.f16_overflows); reading the counter costs a device sync, so it is read on the first render after every
+    decoder upload and then every F16_CHECK_EVERY renders, and anything but zero RAISES (use arith='bf16x6' or 'f32' for this decoder)."""
+    if cfg.arith != binding.ARITH['f16x3']:
+        return
+    import os
+    every = int(os.environ.get('DISTR_F16_CHECK_EVERY', F16_CHECK_EVERY))
+    gen = getattr(engine, 'generation', 0)
+    st = engine.__dict__.setdefault('_f16_state', {'gen': None, 'n': 0})
+    first = st['gen'] != gen
+    if first:
+        st['gen'], st['n'] = gen, 0
+    st['n'] += 1
+    if not (first or (every > 0 and st['n'] % every == 0)):
+        return
+    bad = 0
+    for v in range(nviews):
+        bad += engine.ctx.render_stats(cfg, ws[v * view_bytes:] if nviews > 1 else ws)['f16_overflows']
+    if bad:
+        raise binding.DistrError("arith='f16x3': %d decoder evaluation(s) of this render left the f16 range (|activation| x 64 >= 65504): the "
+                                 "render is not to be trusted. Use arith='bf16x6' or 'f32' for this decoder / shape code." % bad)
+
+
 class RenderFunction(torch.autograd.Function):
     """(latent, R, T) -> (zdepth[P], mask[P] uint8, min_sdf[P], depth[H,W], normal[H,W,3])"""
 
@@ -203,6 +232,7 @@ class RenderFunction(torch.autograd.Function):
             engine.ctx.h, C.byref(cfg), p(lat), p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None,
             p(ws), ws.numel(), engine.ctx.stream()))
+        _check_f16_range(engine, cfg, ws)
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes = engine, cfg, ws, bwd_bytes
         ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)
@@ -278,6 +308,7 @@ class RenderBatchFunction(torch.autograd.Function):
         engine.ctx.check(engine.ctx.L.distr_render_forward_batch(
             engine.ctx.h, C.byref(cfg), B, flags, p(lat), 0 if shared else 256, p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None, p(ws), ws.numel(), engine.ctx.stream()))
+        _check_f16_range(engine, cfg, ws, B, fwd_bytes)
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes, ctx.B, ctx.shared = engine, cfg, ws, bwd_bytes, B, shared
         ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)

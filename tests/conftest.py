@@ -28,3 +28,22 @@ def cpu_oracle(fixture_decoder):
     orc.build()
     Ws, bs, _ = fixture_decoder
     return orc.Oracle(Ws, bs)
+
+
+@pytest.fixture(scope='session')
+def engine(fixture_decoder):
+    """ONE packed decoder / distr_ctx on cuda:0 for the whole GPU session (fixture F1); every test module used to build its own."""
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    from distr import binding, functions
+    assert os.path.exists(binding.LIB_PATH), 'libdistr.so missing: run __graft_entry__.build()'
+    Ws, bs, _ = fixture_decoder
+    return functions.engine_from_weights(Ws, bs, 0)
+
+
+@pytest.fixture(scope='session')
+def orc():
+    """The oracle module itself (make_cfg etc.), built. Test infrastructure only."""
+    from oracle import oracle
+    oracle.build()
+    return oracle

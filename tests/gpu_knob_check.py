@@ -1,7 +1,9 @@
 """Run by tests/test_gpu_knobs.py in a subprocess with one DISTR_* environment knob set (the knobs are read at distr_create):
 one golden of the reference (G1 pyramid_recursive + depth2normal, 64 x 64) and two oracle comparisons (a 20-step C1 render and
 a long march at a small size that spends most steps on cluster / 16-ray tiles) through whatever kernel configuration the
-knob selects. Prints KNOB_OK <residuals> on success."""
+knob selects. Prints KNOB_OK <residuals> on success. The oracle's side of the three comparisons does not depend on the knob: with
+DISTR_KNOB_ORACLE_CACHE=<file.npz> the first run stores it and the later ones (one subprocess per knob) load it, which is most of
+the wall time of those runs."""
 import os
 import sys
 
@@ -30,6 +32,14 @@ def main():
     b = dict(mask=g['mask'], depth=g['depth'], zdepth=g['zdepth'], min_sdf=g['min_abs_query'], normal=g['normal'],
              g_latent=g['g_latent'], g_R=g['g_R'], g_T=g['g_T'])
     res['golden'] = helpers.compare(a, b, H, W, tol_depth=1e-4, tol_grad=2e-3, normal_p99=max(1e-4, 1e-5 * float(g['K'][0, 0])))
+    KEYS = ('mask', 'depth', 'zdepth', 'min_sdf', 'normal', 'g_latent', 'g_R', 'g_T')
+    cache = os.environ.get('DISTR_KNOB_ORACLE_CACHE')
+    cached, fresh = {}, {}
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        for key in z.files:
+            nm, k = key.split('.', 1)
+            cached.setdefault(nm, {})[k] = z[key]
     for name, (H, W, kw, cam) in {
             'c1': (64, 64, dict(march_step=20, buffer_size=3, marcher='recursive', use_depth2normal=False), (30, 20, 1.6, 10)),
             'tail': (150, 130, dict(march_step=70, buffer_size=2, marcher='pyramid_recursive', use_depth2normal=True), (-40, 25, 1.6, 0)),
@@ -37,10 +47,20 @@ def main():
         K = fixture.make_intrinsic(H, W)
         R, T = fixture.make_camera(*cam)
         a = helpers.hip_render(eng, H, W, K, R, T, latent, **kw)
-        b = helpers.oracle_render(O, orc, H, W, K, R, T, latent, **kw)
+        if name in cached:
+            b = cached[name]
+        else:
+            b = helpers.oracle_render(O, orc, H, W, K, R, T, latent, **kw)
+            fresh[name] = {k: b[k] for k in KEYS}
         r = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=2e-4, normal_p99=1e-5, max_flip_frac=0.0)
         assert r['flips'] == 0, r
         res[name] = r
+    if cache and fresh:
+        tmp = cache + '.%d.tmp.npz' % os.getpid()
+        allr = dict(cached)
+        allr.update(fresh)
+        np.savez(tmp, **{'%s.%s' % (nm, k): v for nm, d in allr.items() for k, v in d.items()})
+        os.replace(tmp, cache)
     print('KNOB_OK', {k: {kk: float('%.3g' % vv) for kk, vv in v.items()} for k, v in res.items()})
 
 

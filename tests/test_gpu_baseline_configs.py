@@ -24,23 +24,6 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def engine(fixture_decoder):
-    import torch
-    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
-    from distr import binding, functions
-    assert os.path.exists(binding.LIB_PATH), 'libdistr.so missing: run __graft_entry__.build()'
-    Ws, bs, _ = fixture_decoder
-    return functions.engine_from_weights(Ws, bs, 0)
-
-
-@pytest.fixture(scope='module')
-def orc():
-    from oracle import oracle
-    oracle.build()
-    return oracle
-
-
 def _bench_camera(view):
     """The C4 camera circle exactly as bench.py builds it (view 0 = the C3 camera)."""
     if ROOT not in sys.path:
@@ -51,8 +34,8 @@ def _bench_camera(view):
 
 
 # ------------------------------------------------------------------------------------------------------------------ C2
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('name', ['g3_c2_recursive_d2n.npz', 'g3_c2_pyramid_recursive_d2n.npz'])
+@pytest.mark.parametrize('name,arith', [('g3_c2_recursive_d2n.npz', 'f32'), ('g3_c2_pyramid_recursive_d2n.npz', 'f32'),
+                                        ('g3_c2_pyramid_recursive_d2n.npz', 'bf16x6'), ('g3_c2_pyramid_recursive_d2n.npz', 'f16x3')])
 def test_c2_hip_matches_reference_golden(engine, name, arith):
     """C2 through the HIP path against what the reference itself produced at 256x256/50 (G3): the 32x32 crop pixel by pixel,
     the whole-image summaries, and the latent / camera gradients (bar = 2x the reference's own noise floor for this config,
@@ -125,6 +108,14 @@ def test_c3_hip_matches_oracle_full_image(engine, cpu_oracle, orc, fixture_decod
     assert abs(int(st['num_point_evals']) - int(b['num_evals'])) <= 3, (st['num_point_evals'], b['num_evals'])
     assert st['num_valid'] == int(b['mask'].sum()) and st['cluster_fallbacks'] == 0
     print('C3 residuals vs oracle:', res)
+    # ... and BOTH against what the reference itself produced at this very configuration (G15: SDFRenderer.render +
+    # backward of the same loss at 512x512 / 50 steps with the bench camera, core/sdfrenderer/renderer.py:943-999): the headline
+    # size is pinned by the reference directly, not only through HIP == oracle here and oracle == reference at <= 256^2
+    g = dict(np.load(os.path.join(GOLDEN, 'g15_c3_512_pyramid_d2n.npz')))
+    assert np.array_equal(g['R'], R) and np.array_equal(g['T'], T) and np.array_equal(g['K'], K) and np.array_equal(g['latent'], latent)
+    for side, d in (('HIP', a), ('oracle', b)):
+        r = helpers.compare_big_golden(d, g, 'G15 ' + side)
+        print('C3 %s vs the reference at 512x512 (G15):' % side, r)
 
 
 # ------------------------------------------------------------------------------------------------------------------ C4
@@ -285,7 +276,7 @@ def test_c5_four_shapes_row_bands_full_size(engine, fixture_decoder):
         L = torch.where(mb, d * wd[r0:r1], torch.zeros_like(d)).sum() + (q.reshape(rows, W) * wq[r0:r1]).sum() + (n * wn[r0:r1]).sum()
         L.backward()
         out = [t.detach().reshape(rows, -1).cpu().numpy() for t in (z, m, q, d, n)]
-        return out, [g.grad.double().cpu().numpy() for g in (lat, Rt, Tt)]
+        return out, [g.grad.double().cpu().numpy() for g in (lat, Rt, Tt)], float(L.detach())
 
     pieces = {s: [] for s in range(n_shapes)}
     cover = np.zeros((n_shapes, H), np.int32)
@@ -297,9 +288,18 @@ def test_c5_four_shapes_row_bands_full_size(engine, fixture_decoder):
             cover[s, r0:r1] += 1
     assert (cover == 1).all()
     for s in range(n_shapes):
-        full, gfull = run(s, 0, H)
+        full, gfull, lfull = run(s, 0, H)
         valid = int(full[1].sum())
         assert 0.10 * H * W < valid < 0.45 * H * W, (s, valid)
+        if s == 0:
+            # shape 0 = the image the REFERENCE itself rendered at this size (G16: SDFRenderer.render + backward at 1024x1024 / 100
+            # steps, core/sdfrenderer/renderer.py:943-999; oracle/gen_golden_big.py c5): the C5 size pinned by the reference directly
+            g = dict(np.load(os.path.join(GOLDEN, 'g16_c5_1024_pyramid_d2n.npz')))
+            assert np.array_equal(g['R'], R) and np.array_equal(g['T'], T) and np.array_equal(g['K'], K) and np.array_equal(g['latent'], latent0)
+            assert (int(g['H']), int(g['march_step']), int(g['buffer_size'])) == (H, 100, 3)
+            a = dict(zdepth=full[0], mask=full[1], min_sdf=full[2], depth=full[3].reshape(H, W), normal=full[4].reshape(H, W, 3),
+                     g_latent=gfull[0], g_R=gfull[1], g_T=gfull[2], loss=lfull)
+            print('C5 image 0, HIP vs the reference at 1024x1024 / 100 steps (G16):', helpers.compare_big_golden(a, g, 'G16 HIP'))
         parts = [run(s, r0, r1) for (r0, r1) in sorted(pieces[s])]
         for k, name in enumerate(('zdepth', 'mask', 'min_sdf', 'depth', 'normal')):
             cat = np.concatenate([p_[0][k] for p_ in parts], axis=0)

@@ -11,13 +11,6 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def engine(fixture_decoder):
-    from distr import functions
-    Ws, bs, _ = fixture_decoder
-    return functions.engine_from_weights(Ws, bs, 0)
-
-
 def _cams(n, elev=20.0):
     from distr import fixture
     return [fixture.make_camera(360.0 / n * i + 7.0, elev if i % 3 else -15.0, 1.6 if i % 4 else 1.45, 5.0 * i) for i in range(n)]

@@ -25,13 +25,21 @@ KNOBS = [
 ]
 
 
+@pytest.fixture(scope='module')
+def oracle_cache(tmp_path_factory):
+    """The oracle's results of gpu_knob_check.py do not depend on the knob: the first run (the default configuration) stores them
+    here, the other nine load them (~15 s of CPU oracle per run otherwise)."""
+    return str(tmp_path_factory.mktemp('knobs') / 'oracle.npz')
+
+
 @pytest.mark.parametrize('knobs', KNOBS, ids=lambda k: ','.join('%s=%s' % kv for kv in k.items()).replace('DISTR_', '') or 'default')
-def test_knob_configuration_matches_golden_and_oracle(knobs):
+def test_knob_configuration_matches_golden_and_oracle(knobs, oracle_cache):
     env = dict(os.environ)
     for k in list(env):
         if k.startswith('DISTR_'):
             env.pop(k)
     env.update(knobs)
+    env['DISTR_KNOB_ORACLE_CACHE'] = oracle_cache
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'gpu_knob_check.py')], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and 'KNOB_OK' in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 

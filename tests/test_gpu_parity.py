@@ -20,23 +20,6 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def engine(fixture_decoder):
-    import torch
-    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
-    from distr import binding, functions
-    assert os.path.exists(binding.LIB_PATH), 'libdistr.so missing: run __graft_entry__.build()'
-    Ws, bs, _ = fixture_decoder
-    return functions.engine_from_weights(Ws, bs, 0)
-
-
-@pytest.fixture(scope='module')
-def orc():
-    from oracle import oracle
-    oracle.build()
-    return oracle
-
-
 
 
 def _floors():
@@ -119,9 +102,13 @@ def test_render_c1_matches_oracle(engine, cpu_oracle, orc, fixture_decoder, marc
     assert res['flips'] == 0, res
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('name', sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz'))
-                                          if re.match(r'g1[bc]?_', os.path.basename(p))))
+G1_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'g1*_*.npz')) if re.match(r'g1[bc]?_', os.path.basename(p)))
+# every G1 golden in the exact f32 arithmetic (the product default, the credited path); the two opt-in split arithmetics on a
+# representative pair (one marcher with compaction + finite-difference normals, one dense marcher with autograd normals)
+G1_RUNS = [(n, 'f32') for n in G1_FILES] + [(n, a) for n in ('g1_c1_pyramid_recursive_d2n.npz', 'g1_c1_trivial_agn.npz') for a in ('bf16x6', 'f16x3')]
+
+
+@pytest.mark.parametrize('name,arith', G1_RUNS)
 def test_render_matches_reference_goldens(engine, name, arith):
     """HIP path directly against outputs of the reference itself (tests/golden, made by oracle/gen_golden.py) -- in the default exact
     f32 arithmetic and in the opt-in split-bf16 arithmetic, both at the north-star bar (1e-4, <= 0.1 % mask flips)."""
@@ -431,32 +418,31 @@ def test_bulk_sdf_grid(cpu_oracle, fixture_decoder):
     big = create_sdf_grid(dec, lat, 128)                                        # 2.1 M points in one launch
     assert big.shape == (128, 128, 128) and torch.isfinite(big).all()
 
-    # ---- against the oracle on the REFERENCE's sample ordering (create_mesh.py:16-33: x slowest, z fastest, integer division; the
-    # transform swaps (x, y, z) -> (x, z, -y), :10-14), for the plain and the coarse-to-fine variant (create_mesh.py:100-142)
-    def ref_samples(n, voxel_size, transform):
-        idx = np.arange(n ** 3)
-        xyz = np.stack([(idx // n // n) % n, (idx // n) % n, idx % n], 1).astype(np.float32) * np.float32(voxel_size) + np.float32(-1.0)
-        return np.stack([xyz[:, 0], xyz[:, 2], -xyz[:, 1]], 1) if transform else xyz
-
-    def ref_speedup(n, transform):
-        vs, vs_half, nh = 2.0 / (n - 1), 2.0 / (n / 2 - 1), n // 2
-        half = cpu_oracle.decode_sdf(latent, ref_samples(nh, vs_half, transform), clamp_dist=0.1).reshape(nh, nh, nh)
-        up = np.repeat(np.repeat(np.repeat(half, 2, 0), 2, 1), 2, 2).reshape(-1)            # upsample_cubic: nearest
-        pos, neg, valid = up > vs_half * 1.5, -up > vs_half * 1.5, np.abs(up) <= vs_half * 1.5
-        out = np.zeros(n ** 3, np.float32)
-        out[pos], out[neg] = 0.1, -0.1
-        out[valid] = cpu_oracle.decode_sdf(latent, ref_samples(n, vs, transform)[valid], clamp_dist=0.1)
-        return out.reshape(n, n, n), int(valid.sum())
+    # ---- against the REFERENCE's own create_mesh / create_mesh_speedup (core/evaluation/create_mesh.py:56-68, 110-142): the SDF
+    # volumes it hands to marching cubes (G14, oracle/gen_golden_big.py g14: convert_sdf_samples_to_ply replaced by a recorder,
+    # torch-1.1 integer division shimmed). Sample ordering (x slowest, z fastest, :16-33; transform (x, y, z) -> (x, z, -y), :10-14),
+    # half-resolution pass, nearest upsampling, check_valid's 1.5-voxel band and the +-0.1 fill are the reference's, not a restatement.
+    g = dict(np.load(os.path.join(GOLDEN, 'g14_create_mesh_speedup.npz')))
+    assert np.array_equal(g['latent'], latent)
+    assert np.abs(get_samples(8, transform=True).cpu().numpy() - g['samples_N8_t1']).max() <= 1e-6
+    got = create_sdf_grid(dec, lat, 32).cpu().numpy()
+    assert np.abs(got - g['plain_N32_t0']).max() <= 2e-6, np.abs(got - g['plain_N32_t0']).max()
     for transform in (False, True):
-        n = 48
-        want = cpu_oracle.decode_sdf(latent, ref_samples(n, 2.0 / (n - 1), transform), clamp_dist=0.1).reshape(n, n, n)
-        got = create_sdf_grid(dec, lat, n, transform=transform).cpu().numpy()
-        assert np.abs(got - want).max() <= 1e-7, transform
-        n = 96          # (below ~N = 64 the band 1.5 * coarse voxel exceeds the 0.1 clamp: every point is re-evaluated, as in the reference)
-        want_s, nvalid = ref_speedup(n, transform)
-        got_s = create_sdf_grid_speedup(dec, lat, n, transform=transform).cpu().numpy()
-        assert 0 < nvalid < n ** 3 // 2
-        assert np.abs(got_s - want_s).max() <= 1e-7, transform
+        want = g['speedup_N64_t%d' % int(transform)]
+        got = create_sdf_grid_speedup(dec, lat, 64, transform=transform).cpu().numpy()
+        evaluated = np.abs(want) != np.float32(0.1)
+        assert 5000 < int(evaluated.sum()) < 64 ** 3 // 4                      # the band is a thin shell: most points are filled, not evaluated
+        diff = np.abs(got - want)
+        # a coarse point whose |sdf| sits within rounding of the band edge (1.5 coarse voxels = 0.0968) may be filled on one side and
+        # evaluated on the other: both values are then within 0.004 of +-0.1. Everything else agrees to rounding.
+        off = diff > 2e-6
+        assert int(off.sum()) <= 8 and diff.max() <= 0.004, (transform, int(off.sum()), float(diff.max()))
+        print('G14 create_mesh_speedup N=64 transform=%d: max |d| %.2e over %d evaluated points, %d band-edge points' %
+              (transform, float(diff[~off].max()), int(evaluated.sum()), int(off.sum())))
+    n = 96          # a size where most of the volume is filled: same rules, checked against the plain grid
+    fast, full96 = create_sdf_grid_speedup(dec, lat, n), create_sdf_grid(dec, lat, n)
+    ev = fast.abs() != 0.1
+    assert 0 < int(ev.sum()) < n ** 3 // 2 and torch.equal(fast[ev], full96[ev])
     assert not np.array_equal(create_sdf_grid(dec, lat, 48, transform=True).cpu().numpy(), create_sdf_grid(dec, lat, 48).cpu().numpy())
 
 
@@ -933,30 +919,67 @@ def test_decode_sdf_autograd_matches_reference_golden(fixture_decoder):
         assert not decode_sdf(dec, torch.from_numpy(g['latent']).cuda().requires_grad_(True), x.detach()).requires_grad
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('workload', ['c3', 'c5'])
-def test_bench_two_ranks_on_one_gpu(workload):
-    """bench.py's multi-rank path end to end: two ranks (time-sharing this one GPU, gloo for the packed all-reduce since two
-    RCCL ranks cannot share a device) through torch.distributed.run; checks the contract fields of the JSON line. c5
-    exercises the shape / row-band partition (each rank renders two of the four shapes)."""
+def _bench_ranks(n, args, env_extra=None, launcher=True, timeout=600, expect_rc=0):
+    """`bench.py --gpus n` with n ranks time-sharing this one GPU (gloo for the collectives: RCCL ranks cannot share a device). Small
+    images, one timed step: these tests check the multi-rank PROTOCOL of the driver's scaling run, not its speed."""
     import json
     import subprocess
     from conftest import ROOT
     env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    port = 29700 + (os.getpid() % 200) + (1 if workload == 'c5' else 0)
-    size = ['--size', '128', '--march-step', '30'] if workload == 'c5' else ['--size', '160', '--march-step', '30']
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--workload', workload] + size
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
-    j = json.loads(line)
-    assert j['n_gpus'] == 2 and j['steps'] == 2 and j['unit'] == 'rays/s' and j['value'] > 0
+    env.update(env_extra or {})
+    if launcher:
+        port = 29700 + (os.getpid() * 7 + _bench_ranks.calls * 13) % 290
+        _bench_ranks.calls += 1
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(n)] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    if expect_rc is None:
+        return out
+    assert out.returncode == expect_rc, (out.stdout[-1500:], out.stderr[-2500:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+
+
+_bench_ranks.calls = 0
+
+
+def _check_multi_rank_line(j, n, balanced_possible):
+    """The keys the first real N > 1 run must be readable from: the serial check of the all-reduced loss /
+    gradients, who ran where, per-rank local milliseconds and all-reduce wait, and -- for the view-parallel workload -- BOTH the
+    unbalanced and the balanced timing."""
+    c = j['config']
+    assert j['n_gpus'] == n and c['rccl']['world_size'] == n and len(c['rccl']['ranks']) == n
+    assert sorted(r['rank'] for r in c['rccl']['ranks']) == list(range(n))
+    assert c['rccl']['backend'] == 'gloo' and c['rccl']['backend_is_rccl'] is False and c['scaling_measurement'] is False     # one GPU, gloo: said so
+    sc = c['serial_check']
+    assert sc['ok'] is True and sc['chosen']['loss_rel'] <= 1e-5 and sc['chosen']['grad_rel'] <= 1e-4, sc
+    for mode, d in c['per_rank'].items():
+        assert len(d['local_ms']) == n and len(d['allreduce_and_wait_ms']) == n and all(x > 0 for x in d['local_ms']), (mode, d)
+    assert 'split_bf16' not in j and 'split_f16' not in j and 'cpu_baseline' not in j           # N > 1 times the exact path only
+    if balanced_possible:
+        assert c['unbalanced_ms_per_step'] > 0 and 'balanced_ms_per_step' in c and c['value_is'] in ('balanced', 'unbalanced')
+        assert 'unbalanced' in sc and sc['unbalanced']['loss_rel'] <= 1e-5 and sc['unbalanced']['grad_rel'] <= 1e-4
+        best = min(x for x in (c['unbalanced_ms_per_step'], c['balanced_ms_per_step']) if x)
+        if not os.environ.get('DISTR_BENCH_FAKE_TIMES') and c['value_is'] == 'unbalanced':
+            assert abs(j['ms_per_step'] - c['unbalanced_ms_per_step']) <= 1e-6 * best
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['c3', 'c5'])
+def test_bench_two_ranks_on_one_gpu(workload):
+    """bench.py's multi-rank path end to end: two ranks (time-sharing this one GPU, gloo for the packed all-reduce since two
+    RCCL ranks cannot share a device) through torch.distributed.run; checks the contract fields of the JSON line and the
+    self-validation keys of an N > 1 run. c5 exercises the shape / row-band partition (each rank renders two of the four shapes)."""
+    size = ['--size', '128', '--march-step', '30']
+    j = _bench_ranks(2, ['--steps', '1', '--warmup', '0', '--workload', workload] + size)
+    assert j['n_gpus'] == 2 and j['steps'] == 1 and j['unit'] == 'rays/s' and j['value'] > 0
     assert j['scaling'] == ('strong' if workload == 'c5' else 'weak')
     assert 'cpu_baseline' not in j and j['roofline']['achieved'] > 0
-    rays = (4 if workload == 'c5' else 2) * int(size[1]) ** 2 * 2
-    assert abs(j['value'] * j['ms_per_step'] * 1e-3 * 2 - rays) <= 1e-6 * rays
+    assert j['roofline']['traffic_note'].startswith('STATIC')
+    rays = (4 if workload == 'c5' else 2) * 128 ** 2
+    assert abs(j['value'] * j['ms_per_step'] * 1e-3 - rays) <= 1e-6 * rays
+    _check_multi_rank_line(j, 2, balanced_possible=(workload == 'c3'))
 
 
 @pytest.mark.gpu
@@ -965,19 +988,22 @@ def test_bench_spawns_its_own_ranks():
     ranks: rc 0, n_gpus 2, and the collective layer's own report (config.rccl) shows two ranks. On this one-GPU box the ranks
     time-share the device over gloo (DISTR_DIST_BACKEND); without that override a box with fewer GPUs than ranks is refused with a
     clear message instead of an RCCL hang."""
-    import json
+    drop = {k: None for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')}
+    args = ['--steps', '1', '--warmup', '0', '--size', '128', '--march-step', '30', '--no-balance']
     import subprocess
     from conftest import ROOT
     env = dict(os.environ, DISTR_DIST_BACKEND='gloo')
-    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY'):
+    for k in drop:
         env.pop(k, None)                                   # bench.py must set what it needs itself
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '128']
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    import json
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert j['n_gpus'] == 2 and j['value'] > 0
     r = j['config']['rccl']
     assert r['world_size'] == 2 and r['backend'] == 'gloo' and r['launcher'].startswith('self-spawned'), r
+    _check_multi_rank_line(j, 2, balanced_possible=False)
     import torch
     if torch.cuda.device_count() < 2:
         env.pop('DISTR_DIST_BACKEND')
@@ -988,78 +1014,56 @@ def test_bench_spawns_its_own_ranks():
 @pytest.mark.gpu
 def test_bench_view_balancing_two_ranks():
     """bench.py's row-band load balancing of the view-parallel step (distr.parallel.balance_views): two ranks sharing this GPU
-    (gloo), step times forced to 70 / 40 ms so that rank 0 hands the bottom rows of its view to rank 1. The all-reduced loss and
-    latent gradient of a step must equal the unbalanced run's (the work moved, nothing else)."""
-    import json
-    import subprocess
-    from conftest import ROOT
-    outs = []
-    for extra, fake in ((['--no-balance'], None), ([], '70,40'), (['--warmup', '5', '--view-offset', '6'], None)):
-        env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-        if fake:
-            env['DISTR_BENCH_FAKE_TIMES'] = fake
-        port = 29860 + (os.getpid() % 60) + len(outs)
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3', '--size', '192',
-               '--march-step', '30'] + extra
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
-    plain, bal, free = outs
-    # third run: measured times (two ranks contending for one GPU: arbitrary) through the plan + refinement schedule of a 5-step
-    # warm-up; whatever the plan, it must tile both views (views 6 and 7) exactly once
+    (gloo), step times forced to 70 / 40 ms so that rank 0 hands the bottom rows of its view to rank 1. The run times the step
+    unbalanced AND balanced; the all-reduced loss and latent gradient of BOTH must equal the serial sum over the two views that rank 0
+    renders itself (config.serial_check: the work moved, nothing else)."""
+    bal = _bench_ranks(2, ['--steps', '1', '--warmup', '1', '--size', '192', '--march-step', '30'], {'DISTR_BENCH_FAKE_TIMES': '70,40'})
+    free = _bench_ranks(2, ['--steps', '1', '--warmup', '1', '--size', '192', '--march-step', '30', '--view-offset', '6'])
+    # second run: measured times (two ranks contending for one GPU: arbitrary) through the plan + refinement schedule; whatever the
+    # plan (used or only tried), it must tile both views (views 6 and 7) exactly once
     cover = np.zeros((2, 192), np.int32)
-    for p in (free['config']['balance_plan'] or [[[0, 0, 192]], [[1, 0, 192]]]):
+    for p in (free['config']['balance_plan'] or free['config'].get('balance_plan_tried') or [[[0, 0, 192]], [[1, 0, 192]]]):
         for (v, r0, r1) in p:
             cover[v, r0:r1] += 1
     assert (cover == 1).all() and np.isfinite(free['config']['loss_sum_all_ranks'])
-    assert plain['config']['balance_plan'] is None and plain['config']['rank0_items'] == [[0, 0, 0, 192]]
+    _check_multi_rank_line(free, 2, balanced_possible=True)
     plan = bal['config']['balance_plan']
     cut = plan[0][0][2]                                   # (where exactly depends on the row cost profile of the rendered view)
     assert plan[0] == [[0, 0, cut]] and 96 <= cut < 192 and cut % 4 == 0 and plan[1] == [[1, 0, 192], [0, cut, 192]], plan
     assert bal['config']['rank0_items'] == [[0, 0, 0, cut]] and 'load balancing' in bal['config']['parallelism']
-    a, b = plain['config']['loss_sum_all_ranks'], bal['config']['loss_sum_all_ranks']
-    assert abs(a - b) <= 1e-5 * abs(a), (a, b)
-    ga, gb = plain['config']['latent_grad_norm_all_ranks'], bal['config']['latent_grad_norm_all_ranks']
-    assert abs(ga - gb) <= 1e-4 * abs(ga), (ga, gb)
+    assert bal['config']['value_is'] == 'balanced' and bal['config']['balanced_ms_per_step'] > 0
+    _check_multi_rank_line(bal, 2, balanced_possible=True)
+    sc = bal['config']['serial_check']
+    assert 'balanced' in sc and sc['balanced']['loss_rel'] <= 1e-5 and sc['balanced']['grad_rel'] <= 1e-4, sc
 
 
 @pytest.mark.gpu
 def test_bench_view_balancing_eight_ranks():
     """The shape of the driver's 8-GPU run, on this one GPU: eight ranks (gloo), the step times of the eight C4 views as measured on
     one MI355X (profiles/r02_view_balance.md) forced in, so that the plan has one donor and two receivers. Every row of every view
-    is rendered exactly once, and the all-reduced loss / latent gradient equal the unbalanced run's."""
-    import json
-    import subprocess
-    from conftest import ROOT
-    H = 512
+    is rendered exactly once, and the all-reduced loss / latent gradient of the unbalanced AND the balanced step equal the serial sum
+    over the eight views (config.serial_check, computed inside the run)."""
+    H = 256
     times = [52.71, 54.40, 51.19, 50.40, 47.98, 46.50, 49.57, 58.67]
-    outs = []
-    for extra, fake in ((['--no-balance'], None), ([], ','.join('%.2f' % t for t in times))):
-        env = dict(os.environ, DISTR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-        if fake:
-            env['DISTR_BENCH_FAKE_TIMES'] = fake
-        port = 29930 + (os.getpid() % 40) + len(outs)
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '3', '--size', str(H),
-               '--march-step', '30'] + extra
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-2000:]
-        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1]))
-    plain, bal = outs
-    assert plain['n_gpus'] == 8 and plain['config']['balance_plan'] is None
+    bal = _bench_ranks(8, ['--steps', '1', '--warmup', '0', '--size', str(H), '--march-step', '30'],
+                       {'DISTR_BENCH_FAKE_TIMES': ','.join('%.2f' % t for t in times)}, timeout=900)
+    assert bal['n_gpus'] == 8
+    _check_multi_rank_line(bal, 8, balanced_possible=True)
     plan = [[tuple(x) for x in p] for p in bal['config']['balance_plan']]
-    assert plan[7][0][2] < H and sum(len(p) for p in plan) >= 10, plan      # view 7 gives rows away; at least two bands move
     cover = np.zeros((8, H), np.int32)
-    for p in plan:
+    for r, p in enumerate(plan):
+        assert p[0][0] == r and p[0][1] == 0                       # first item: what is left of the rank's own view
         for (v, r0, r1) in p:
+            assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H)
             cover[v, r0:r1] += 1
     assert (cover == 1).all()
-    a, b = plain['config']['loss_sum_all_ranks'], bal['config']['loss_sum_all_ranks']
-    assert abs(a - b) <= 1e-5 * abs(a), (a, b)
-    ga, gb = plain['config']['latent_grad_norm_all_ranks'], bal['config']['latent_grad_norm_all_ranks']
-    assert abs(ga - gb) <= 1e-4 * abs(ga), (ga, gb)
+    donors = [r for r, p in enumerate(plan) if p[0][2] < H]
+    receivers = [r for r, p in enumerate(plan) if len(p) > 1]
+    mean = sum(times) / 8
+    assert 7 in donors and receivers and all(times[r] < mean for r in receivers) and all(times[r] > mean for r in donors), plan
     assert abs(bal['value'] - 8 * H * H / (bal['ms_per_step'] * 1e-3)) <= 1e-6 * bal['value']      # whole-job rays / max-over-ranks time
+    sc = bal['config']['serial_check']
+    assert sc['images'] == 8 and sc['balanced']['grad_rel'] <= 1e-4 and sc['unbalanced']['grad_rel'] <= 1e-4, sc
 
 
 @pytest.mark.gpu
@@ -1321,18 +1325,19 @@ def test_cluster_fallback_is_bit_identical(engine, fixture_decoder):
 @pytest.mark.gpu
 def test_cluster_tiles_under_oversubscription():
     """ADVICE r1 (medium) / VERDICT r1 item 2: eight streams, 512x512 dense renders mixed with small tail-dominated renders,
-    GPU_MAX_HW_QUEUES=8, 200 iterations -- clusters that cannot assemble fall back on the device; every one of the 1600 renders
+    GPU_MAX_HW_QUEUES=8, 100 iterations (soak: DISTR_TEST_STRESS_ITERS) -- clusters that cannot assemble fall back on the device; every one of the 800 renders
     is bit-identical to its stand-alone result (tests/gpu_stress_clusters.py)."""
     import json
     import subprocess
     from conftest import ROOT
     env = dict(os.environ, GPU_MAX_HW_QUEUES='8')
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'gpu_stress_clusters.py'), '--iters', '200', '--streams', '8'],
+    iters = os.environ.get('DISTR_TEST_STRESS_ITERS', '100')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'gpu_stress_clusters.py'), '--iters', iters, '--streams', '8'],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     print('oversubscription stress:', j)
-    assert j['mismatching_renders'] == 0 and j['renders'] == 1600
+    assert j['mismatching_renders'] == 0 and j['renders'] == 8 * int(iters)
 
 
 @pytest.mark.gpu

@@ -266,6 +266,49 @@ def test_dropin_coexists_with_reference_checkout():
     assert bad.returncode != 0 and 'DISTR_ARITH' in bad.stderr          # an unknown name is an error, not a silent fallback to f32
 
 
+REFERENCE = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason='the reference checkout exists in the build container only (it never travels)')
+@pytest.mark.parametrize('driver', ['run_single_shape.py', 'run_multi_pmodata.py', 'run_single_camera.py', 'run_multi_realdata.py'])
+def test_real_reference_driver_imports_resolve(driver):
+    """The REAL drivers of the reference, unmodified, in the real checkout (run_single_shape.py:5-14, run_multi_pmodata.py:8-15):
+    their import blocks, executed under distr.launch, resolve every hot-path module to THIS build (also through the reference's flat
+    imports, e.g. core/evaluation/evaluator.py's `from create_mesh import ...`) and everything else -- datasets, visualiser,
+    evaluator -- to the reference. Container-only: nothing is copied, nothing ships (tests/real_driver_imports.py reads the import
+    block at run time)."""
+    path = os.path.join(REFERENCE, driver)
+    if not os.path.exists(path):
+        pytest.skip('driver not in this checkout')
+    j = _run_driver([sys.executable, '-m', 'distr.launch', os.path.join(ROOT, 'tests', 'real_driver_imports.py'), path])
+    ours, ref = os.path.join(PKG, 'core') + os.sep, os.path.join(REFERENCE, 'core') + os.sep
+    mods, names = j['modules'], j['names']
+    assert j['statements'] >= 8
+    # packages and modules of the hot path -> this build
+    for m in ('core', 'core.sdfrenderer', 'core.sdfrenderer.renderer', 'core.utils.decoder_utils', 'core.utils.render_utils', 'core.inv_optimizer',
+              'core.evaluation', 'core.utils'):
+        assert m in mods and mods[m].startswith(ours), (m, mods.get(m))
+    assert all(v.startswith(ours) or v.startswith(ref) for v in mods.values()), mods          # nothing from anywhere else
+    if 'create_mesh' in mods:                                   # the reference's flat import of the meshing module lands here too
+        assert mods['create_mesh'].startswith(ours), mods['create_mesh']
+    # the rest of the reference's `core` -> the reference checkout
+    for m in ('core.dataset', 'core.visualize', 'core.visualize.vis_utils'):
+        assert m in mods and mods[m].startswith(ref), (m, mods.get(m))
+    want_ours = {'run_single_shape.py': ['SDFRenderer', 'optimize_single_view', 'load_decoder'],
+                 'run_single_camera.py': ['SDFRenderer', 'load_decoder'],
+                 'run_multi_pmodata.py': ['SDFRenderer_warp', 'optimize_multi_view', 'load_decoder'],
+                 'run_multi_realdata.py': ['SDFRenderer_warp', 'load_decoder']}[driver]
+    for n in want_ours:
+        assert names[n].startswith(ours), (n, names[n])
+    for n in ('Visualizer', 'Evaluator'):
+        if n in names:
+            assert names[n].startswith(ref), (n, names[n])
+    loaders = [n for n in names if n.startswith('Loader')]
+    assert loaders and all(names[n].startswith(ref) for n in loaders), loaders
+    if 'create_mesh_speedup' in names:
+        assert names['create_mesh_speedup'].startswith(ours)
+
+
 def test_dropin_with_explicit_sys_path_order():
     """Same resolution when a caller orders sys.path itself (this build first, the reference checkout later)."""
     code = ("import sys, runpy; sys.path.insert(0, %r); sys.argv = ['run_driver.py']; "
