@@ -77,6 +77,7 @@ def compare_big_golden(a, g, label, grad_floor_mult=2.0):
     depth, z, q, nrm = a['depth'].reshape(H, W), a['zdepth'].reshape(H, W), a['min_sdf'].reshape(H, W), a['normal'].reshape(H, W, 3)
     fx = float(g['K'][0, 0])
     bar_q = max(1e-4, 2.0 * float(g['floor_min_sdf']))
+    bar_d = max(1e-4, 2.0 * float(g['floor_depth']))
     bar_n = max(1e-4, 1e-5 * fx, 2.0 * float(g['floor_normal_p99']))      # finite differences amplify depth noise by fx / 2
 
     def region(ad, az, aq, an, am_, gd, gz, gq, gn, gmask, name):
@@ -86,10 +87,14 @@ def compare_big_golden(a, g, label, grad_floor_mult=2.0):
         if both.any():
             r['depth'] = float(np.abs(ad - gd)[both].max())
             r['zdepth'] = float(np.abs(az - gz)[both].max())
+            r['depth_px_over_1e-4'] = int((np.abs(ad - gd)[both] > 1e-4).sum())
             dn = np.abs(an - gn)[both]
             r['normal_p99'] = float(np.percentile(dn, 99))
             r['normal_max'] = float(dn.max())
-            assert r['depth'] <= 1e-4 and r['zdepth'] <= 1e-4, (label, name, r)
+            # 1e-4, except where the reference's own depth moves by more under 1e-7 weight noise (a stop-step event on an isolated
+            # pixel: G16's floor is 1.46e-4): then 2 x that floor, and at most 1 pixel in 10 000 above 1e-4
+            assert r['depth'] <= bar_d and r['zdepth'] <= bar_d, (label, name, r, bar_d)
+            assert r['depth_px_over_1e-4'] <= max(1, int(1e-4 * int(both.sum()))), (label, name, r)
             assert r['normal_p99'] <= bar_n, (label, name, r, bar_n)
         r['min_sdf'] = float(np.abs(aq - gq).max())
         assert r['min_sdf'] <= bar_q, (label, name, r, bar_q)
@@ -115,6 +120,8 @@ def compare_big_golden(a, g, label, grad_floor_mult=2.0):
         res['loss_rel'] = float(abs(a['loss'] - float(g['loss'])) / abs(float(g['loss'])))
         assert res['loss_rel'] <= max(1e-5, grad_floor_mult * float(g['floor_loss_rel'])), (label, res)
     for k in ('g_latent', 'g_R', 'g_T'):
+        if k not in g:                 # a forward-only golden (G16: the reference's autograd tape at 1024^2 does not fit the build container)
+            continue
         rel = float(np.abs(a[k].reshape(-1) - g[k].reshape(-1)).max() / np.abs(g[k]).max())
         fl = float(g['floor_%s_rel' % k])
         res[k] = rel

@@ -260,3 +260,19 @@ def test_march_structure_vs_reference_golden():
         iz = st.init_z.reshape(-1)
         m = g['in_sphere'].reshape(-1).astype(bool)
         assert np.abs(iz[m] - g['init_zdepth'].reshape(-1)[m]).max() <= 1e-6
+
+
+@pytest.mark.skipif(not os.environ.get('DISTR_TEST_BIG_GOLDENS') and (os.cpu_count() or 1) < 32,
+                    reason='oracle at 512x512: minutes on a small host (set DISTR_TEST_BIG_GOLDENS=1); the GPU suite runs the same comparison '
+                           'on the GPU box (test_c3_hip_matches_oracle_full_image)')
+@pytest.mark.parametrize('name', ['g15_c3_512_pyramid_d2n.npz', 'g17_c5steps_512_view3.npz'])
+def test_oracle_matches_reference_at_headline_size(cpu_oracle, name):
+    """The CPU oracle against what the reference itself produced at the size the metric is quoted on (G15: C3 = 512x512 / 50 steps,
+    bench camera) and at C5's step count (G17): pins the oracle at these sizes directly, not through smaller images."""
+    import helpers
+    from oracle import oracle as orc
+    g = dict(np.load(os.path.join(GOLDEN, name)))
+    H, W = int(g['H']), int(g['W'])
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']), march_step=int(g['march_step']),
+                              buffer_size=int(g['buffer_size']), ratio=float(g['ratio']), marcher=str(g['marcher']), use_depth2normal=True)
+    print(name, helpers.compare_big_golden(b, g, name + ' oracle'))
