@@ -255,8 +255,11 @@ class SDFRenderer(object):
             print('march kernel: {0} launches\t: {1:.4f} ms'.format(n, ms))
         if no_grad_depth:
             depth = depth.detach()
-        if no_grad_normal and not self.use_depth2normal:
-            normal = normal.detach()
+        # no_grad_normal: the reference detaches the normals INSIDE render_normal (renderer.py:908-909), i.e. before `R @ normal`
+        # (:978) -- the explicit gradient of that product w.r.t. R survives the flag (golden G18: g_R is the same with and without it).
+        # The autograd normal of this build carries exactly that term and nothing else (the terms through the decoder are identically
+        # ~0 for a ReLU decoder after normalisation), so the flag has nothing left to remove here. (Round 3 detached the
+        # whole image, which also dropped the R term: found by G18.)
         if no_grad_mask and no_grad_camera:
             min_sdf = min_sdf.detach()
         if num_forward_sampling != 0:

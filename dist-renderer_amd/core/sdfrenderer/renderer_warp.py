@@ -35,7 +35,7 @@ class SDFRenderer_warp(SDFRenderer):
                                                                R1, T1, R2, T2)
         # visualisation outputs (renderer_warp.py:131-144)
         n1 = self.render_normal(latent, R1, T1, Z1, m1, no_grad=no_grad_normal, clamp_dist=clamp_dist)
-        n1 = torch.matmul(R1.detach(), n1)
+        n1 = torch.matmul(R1, n1)
         n1 = torch.cat([-n1[:1], n1[1:]], 0).reshape(3, h, w).permute(1, 2, 0)
         depth1 = torch.where(m1, Z1.detach() * self.calib_map, torch.zeros_like(Z1)).reshape(h, w)
         return (loss_color, color1, color2, m1.reshape(h, w).to(torch.uint8), m2.reshape(h, w).to(torch.uint8),
@@ -65,7 +65,7 @@ class SDFRenderer_warp(SDFRenderer):
                                                                    R1, T1, R2, T2)
             n1 = depth1 = None
             if want_vis:
-                n1 = torch.matmul(R1.detach(), N1[i])
+                n1 = torch.matmul(R1, N1[i])
                 n1 = torch.cat([-n1[:1], n1[1:]], 0).reshape(3, h, w).permute(1, 2, 0)
                 depth1 = torch.where(m1, Z1.detach() * self.calib_map, torch.zeros_like(Z1)).reshape(h, w)
             outs.append((loss_color, color1, color2, m1.reshape(h, w).to(torch.uint8), m2.reshape(h, w).to(torch.uint8),

@@ -13,6 +13,6 @@ for e in c3_reference_loss c5_n1 c2_256 c1_64 c3_recursive c3_trivial c3_f2; do 
 grep -v amdgpu.ids $F/loop.log > $P/${R}_single_view_loop.log
 cp $F/batch_round.log $P/${R}_batch_round.log
 # the timed GPU test run: summary line, slowest tests, wall clock
-( grep -E "passed|failed" $F/pytest_gpu.log | tail -1; grep -E "Elapsed \(wall clock\)" $F/pytest_gpu.log; echo; grep -E "^[0-9.]+s (call|setup)" $F/pytest_gpu.log ) > $P/${R}_pytest_gpu_durations.log
+( grep -E "passed|failed" $F/pytest_gpu.log | tail -1; grep -E "^real" $F/pytest_gpu.log; echo; grep -E "^[0-9.]+s (call|setup)" $F/pytest_gpu.log ) > $P/${R}_pytest_gpu_durations.log
 python $P/make_traffic.py $P/$R > /dev/null
 ls -la $P | grep " ${R}_" | wc -l

@@ -15,7 +15,7 @@ set -u
 OUT=${1:-gpurun_out/r04_round}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-( /usr/bin/time -v python -m pytest tests -m gpu -q --durations=30 > "$OUT/pytest_gpu.log" 2>&1 )
+( time python -m pytest tests -m gpu -q --durations=30 ) > "$OUT/pytest_gpu.log" 2>&1
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 DISTR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 > "$OUT/bench_n2_gloo.json" 2> "$OUT/bench_n2_gloo.err"
 DISTR_DIST_BACKEND=gloo python bench.py --gpus 8 --steps 3 --warmup 1 > "$OUT/bench_n8_gloo.json" 2> "$OUT/bench_n8_gloo.err"

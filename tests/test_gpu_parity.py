@@ -1585,3 +1585,55 @@ def test_split_f16_range_is_checked(fixture_decoder):
     eng.ctx.check(eng.ctx.L.distr_render_forward(eng.ctx.h, C.byref(cfg), p(lat), p(Rt), p(Tt), p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]),
                                                p(ws), ws.numel(), eng.ctx.stream()))
     assert eng.ctx.render_stats(cfg, ws)['f16_overflows'] == 0
+
+
+def _g18_cases():
+    import test_oracle_vs_golden as tg
+    return tg._g18_cases()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('marcher,d2n', sorted({(c[0], c[1]) for c in _g18_cases()}))
+def test_no_grad_flags_match_reference_golden(fixture_decoder, marcher, d2n):
+    """G18 through the drop-in class: SDFRenderer.render(..., no_grad_depth / _normal / _mask / _camera = True) (renderer.py:943-999, as
+    loss_single.py:17 and renderer_warp.py:109 call it) against the reference's own gradients for every flag set of the golden --
+    loss value, latent / R / T gradients (bar: 2 x the reference's noise floor of that very case, not below 1e-3 of the flag-free
+    gradient's size), and the forward depth, which no_grad_depth changes in its last bits."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.graph.deep_sdf_decoder import Decoder
+    Ws, bs, latent = fixture_decoder
+    g = np.load(os.path.join(GOLDEN, 'g18_no_grad_flags.npz'))
+    assert np.array_equal(g['latent'], latent)
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W_, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W_), ('bias', b))})
+    dec = dec.cuda()
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer(dec, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']),
+                    ray_marching_ratio=float(g['ratio']), use_depth2normal=d2n)
+    wd, wq, wn = (torch.from_numpy(a).cuda() for a in helpers.loss_weights(H, W, int(g['loss_seed'])))
+    base = '%s_%s_flag_free.' % (marcher, 'd2n' if d2n else 'agn')
+    worst = {}
+    for flagset in [str(f) for f in g['flag_sets']]:
+        key = '%s_%s_%s' % (marcher, 'd2n' if d2n else 'agn', flagset)
+        lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+        Rt = torch.from_numpy(g['R']).cuda().requires_grad_(True)
+        Tt = torch.from_numpy(g['T']).cuda().requires_grad_(True)
+        depth, normal, mask, mq = r.render(lat, Rt, Tt, ray_marching_type=marcher, **{'no_grad_' + f: True for f in flagset.split('+')})
+        mb = mask.bool()
+        L = (depth * wd)[mb].sum() + (mq * wq).sum() + (normal * wn).sum()
+        assert bool(L.requires_grad) == bool(g[key + '.has_graph'])
+        if L.requires_grad:
+            L.backward()
+        assert abs(float(L.detach()) - float(g[key + '.loss'])) <= 2e-5 * abs(float(g[key + '.loss']))
+        assert np.array_equal(mask.cpu().numpy(), g[base + 'mask'])
+        ref_depth = g[key + '.depth'] if not bool(g[key + '.depth_same_as_flag_free']) else g[base + 'depth']
+        assert np.abs(depth.detach().cpu().numpy() - ref_depth)[mb.cpu().numpy()].max() <= 1e-4
+        for name, t in (('g_latent', lat), ('g_R', Rt), ('g_T', Tt)):
+            mine = np.zeros(t.shape, np.float32) if t.grad is None else t.grad.cpu().numpy()
+            ref, scale, fl = g['%s.%s' % (key, name)], float(g['%s.%s_scale' % (key, name)]), float(g['%s.%s_floor_rel' % (key, name)])
+            rel = float(np.abs(mine.reshape(-1) - ref.reshape(-1)).max() / scale)
+            worst[(flagset, name)] = (rel, fl)
+            assert rel <= max(2.0 * fl, 1e-3), (key, name, rel, fl)
+    print('G18 %s %s: worst residual / floor per flag set:' % (marcher, 'd2n' if d2n else 'agn'),
+          {k[0]: '%.1e / %.1e' % max(v for kk, v in worst.items() if kk[0] == k[0]) for k in worst})

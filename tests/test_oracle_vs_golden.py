@@ -276,3 +276,52 @@ def test_oracle_matches_reference_at_headline_size(cpu_oracle, name):
     b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g['T'], g['latent'], seed=int(g['loss_seed']), march_step=int(g['march_step']),
                               buffer_size=int(g['buffer_size']), ratio=float(g['ratio']), marcher=str(g['marcher']), use_depth2normal=True)
     print(name, helpers.compare_big_golden(b, g, name + ' oracle'))
+
+
+def _g18_cases():
+    path = os.path.join(GOLDEN, 'g18_no_grad_flags.npz')
+    if not os.path.exists(path):
+        return []
+    g = np.load(path)
+    return [(str(c).split('|')[0], bool(int(str(c).split('|')[1])), str(f)) for c in g['cases'] for f in g['flag_sets']]
+
+
+def g18_upstream(flags, d2n, wd, wq, wn, mask):
+    """Upstream image gradients of the golden loss under a set of no_grad_* flags -- the detaches SDFRenderer.render applies to its
+    OUTPUTS (renderer.py:876-877, 388-389): no_grad_depth detaches Zdepth (and with it depth and finite-difference normals),
+    min_abs_query is detached when mask AND camera gradients are both off. What the flags do INSIDE
+    the render (which decode_sdf calls run detached) is the cfg's grad_* switches."""
+    g_depth = None if 'depth' in flags else wd * mask
+    g_normal = wn          # no_grad_normal detaches the normals before `R @ normal` (renderer.py:908-909, 978): the R term survives, and
+    #                        it is the only term an autograd normal has here (A.6-1); finite-difference normals hang on depth
+    g_q = None if ('mask' in flags and 'camera' in flags) else wq
+    return g_depth, g_normal, g_q
+
+
+@pytest.mark.parametrize('marcher,d2n,flagset', _g18_cases())
+def test_oracle_no_grad_flags_match_reference_golden(cpu_oracle, marcher, d2n, flagset):
+    """G18: the reference's own gradients with every no_grad_* keyword of SDFRenderer.render switched on (alone and in the combinations
+    the code treats specially), oracle/gen_golden_flags.py. Pins WHICH terms each flag removes (e.g. no_grad_camera is honoured only by
+    the full-resolution recursive rows, no_grad_depth also skips the z - s*r + s*r round trip in the forward value)."""
+    import helpers
+    g = np.load(os.path.join(GOLDEN, 'g18_no_grad_flags.npz'))
+    flags = tuple(flagset.split('+'))
+    H, W = int(g['H']), int(g['W'])
+    key = '%s_%s_%s' % (marcher, 'd2n' if d2n else 'agn', flagset)
+    cfg = orc.make_cfg(H, W, g['K'], march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), ratio=float(g['ratio']), marcher=marcher,
+                       use_depth2normal=d2n, grad_depth='depth' not in flags, grad_mask='mask' not in flags, grad_camera='camera' not in flags)
+    out = cpu_oracle.render(cfg, g['latent'], g['R'], g['T'])
+    wd, wq, wn = helpers.loss_weights(H, W, int(g['loss_seed']))
+    m = out['mask'].reshape(H, W).astype(np.float32)
+    gd, gn, gq = g18_upstream(flags, d2n, wd, wq, wn, m)
+    gl, gR, gT, _ = out['state'].backward(g_min_sdf=None if gq is None else gq.reshape(-1), g_depth=None if gd is None else gd.reshape(-1),
+                                          g_normal=None if gn is None else gn.reshape(-1))
+    base = '%s_%s_flag_free.' % (marcher, 'd2n' if d2n else 'agn')
+    assert np.array_equal(out['mask'].reshape(H, W), g[base + 'mask'])
+    ref_depth = g[key + '.depth'] if not bool(g[key + '.depth_same_as_flag_free']) else g[base + 'depth']
+    mb = m.astype(bool)
+    assert np.abs(out['depth'].reshape(H, W) - ref_depth)[mb].max() <= 1e-4
+    for name, mine in (('g_latent', gl), ('g_R', gR), ('g_T', gT)):
+        ref, scale, fl = g['%s.%s' % (key, name)], float(g['%s.%s_scale' % (key, name)]), float(g['%s.%s_floor_rel' % (key, name)])
+        rel = float(np.abs(mine.reshape(-1) - ref.reshape(-1)).max() / scale)
+        assert rel <= max(2.0 * fl, 1e-3), (key, name, rel, fl)          # SURVEY 8c: gradients <= 1e-3 relative, or the reference's own floor
