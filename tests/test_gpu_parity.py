@@ -1637,3 +1637,125 @@ def test_no_grad_flags_match_reference_golden(fixture_decoder, marcher, d2n):
             assert rel <= max(2.0 * fl, 1e-3), (key, name, rel, fl)
     print('G18 %s %s: worst residual / floor per flag set:' % (marcher, 'd2n' if d2n else 'agn'),
           {k[0]: '%.1e / %.1e' % max(v for kk, v in worst.items() if kk[0] == k[0]) for k in worst})
+
+
+class _StepRecorder(object):
+    """Wraps optimizer.step like oracle/gen_golden_loops.py does around the reference's loop: the optimised tensor and its gradient as
+    the loop hands them to Adam, iteration by iteration."""
+
+    def __init__(self, opt, tensor):
+        self.values, self.grads, self.tensor = [], [], tensor
+        self._step = opt.step
+        opt.step = self.step
+
+    def step(self, *a, **k):
+        self.values.append(self.tensor.detach().cpu().numpy().copy())
+        self.grads.append(self.tensor.grad.detach().cpu().numpy().copy())
+        return self._step(*a, **k)
+
+
+def _plain_decoder(fixture_decoder):
+    import torch
+    from core.graph.deep_sdf_decoder import Decoder
+    Ws, bs, _ = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W_, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W_), ('bias', b))})
+    return dec.cuda()
+
+
+def _check_loop_against_golden(rec, final, g, label, lr, grad_at):
+    """rec: the drop-in loop's own five iterations; grad_at(value) -> the gradient ONE iteration of the drop-in loop computes when started
+    at `value`. Two checks: (1) parity proper -- at the reference's own tensor of every iteration the loop's gradient equals the
+    reference's (1e-3 relative, or 2 x the reference's noise floor); (2) the free-running trajectory stays on the reference's for
+    the first iterations and ends within a few Adam steps of it. (Later free-running gradients are NOT compared point-wise: measured on
+    G20, a 4.5e-7 difference in the shape code before iteration 4 -- Adam amplifying a 1e-6 gradient residual -- moves one pixel of the
+    16 x 16 renderer across the mask threshold and the gradient by 6e-3, while at the reference's own code of that iteration the two
+    gradients agree to 3e-4.)"""
+    vals, grads = np.array(rec.values), np.array(rec.grads)
+    ref_v, ref_g = g['values'], g['grads']
+    assert vals.shape == ref_v.shape and grads.shape == ref_g.shape
+    fg, ff = float(g['floor_grad_rel']), float(g['floor_final_abs'])
+    at_ref = []
+    for i in range(ref_v.shape[0]):
+        mine = grad_at(ref_v[i])
+        at_ref.append(float(np.abs(mine - ref_g[i]).max() / np.abs(ref_g[i]).max()))
+    free = [float(np.abs(grads[i] - ref_g[i]).max() / np.abs(ref_g[i]).max()) for i in range(grads.shape[0])]
+    dvals = [float(np.abs(vals[i] - ref_v[i]).max()) for i in range(vals.shape[0])]
+    dv = np.abs(final.reshape(-1) - g['final'].reshape(-1))
+    print('%s: gradient residual AT THE REFERENCE\'S tensor of each iteration %s (reference noise floor %.1e); free-running: gradient %s, '
+          '|tensor - reference| before each step %s, final max %.2e p99 %.2e (floor %.1e)'
+          % (label, ['%.1e' % r for r in at_ref], fg, ['%.1e' % r for r in free], ['%.1e' % v for v in dvals], dv.max(), np.percentile(dv, 99), ff))
+    assert max(at_ref) <= max(2.0 * fg, 1e-3), at_ref
+    assert dvals[0] == 0.0 and free[0] <= max(2.0 * fg, 2e-4), (dvals, free)
+    assert all(v <= 0.02 * lr for v in dvals[:3]), dvals                 # three iterations on the reference's trajectory
+    assert np.percentile(dv, 99) <= max(2.0 * ff, 0.1 * lr) and dv.max() <= 2.5 * lr * grads.shape[0], (dv.max(), np.percentile(dv, 99), ff)
+
+
+@pytest.mark.gpu
+def test_camera_optimisation_loop_matches_reference_golden(fixture_decoder):
+    """G19: the reference's optimize_single_view(optimizer_type='camera') (optimize_single.py:36-103 as run_single_camera.py:76-111 drives
+    it: quaternion + translation tensor, get_camera_from_tensor inside the loop, Adam lr 5e-3, weights 10 / 10 / 1 / 1 / 1) -- five
+    iterations through the drop-in loop and renderer against the camera tensors and gradients the reference itself produced."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.inv_optimizer import optimize_single_view
+    g = dict(np.load(os.path.join(GOLDEN, 'g19_camera_loop.npz')))
+    dec = _plain_decoder(fixture_decoder)
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer(dec, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']), threshold=5e-5,
+                    ray_marching_ratio=1.5, use_depth2normal=False)
+    lat = torch.from_numpy(g['latent']).cuda()
+    RT = torch.from_numpy(g['RT_true']).cuda()
+    d, n, m, q = r.render(lat, RT[:, :3], RT[:, 3], no_grad=True)        # the GT the reference rendered from the true camera: ours agrees
+    assert (m.cpu().numpy() != g['gt_mask']).sum() <= 2
+    both = (m.cpu().numpy() > 0) & (g['gt_mask'] > 0)
+    assert np.abs(d.detach().cpu().numpy() - g['gt_depth'])[both].max() <= 1e-4
+    gt_pack = {'depth': torch.from_numpy(g['gt_depth']).cuda(), 'normal': torch.from_numpy(g['gt_normal']).cuda(),
+               'silhouette': torch.from_numpy(g['gt_mask']).cuda()}
+    cam = torch.from_numpy(g['camera0']).cuda().requires_grad_(True)
+    opt = torch.optim.Adam([cam], lr=float(g['lr']))
+    rec = _StepRecorder(opt, cam)
+    wd = dict(w_depth=10.0, w_normal=10.0, w_mask_gt=1.0, w_mask_out=1.0, w_l2reg=1.0)
+    out, _ = optimize_single_view([r], None, opt, lat, cam, gt_pack, wd, optimizer_type='camera', num_iters=int(g['iters']), renderer_weights=[1.0], silent=True)
+    assert out is cam
+
+    def grad_at(value):
+        c = torch.from_numpy(value).cuda().requires_grad_(True)
+        o = torch.optim.SGD([c], lr=0.0)
+        rr = _StepRecorder(o, c)
+        optimize_single_view([r], None, o, lat, c, gt_pack, wd, optimizer_type='camera', num_iters=1, renderer_weights=[1.0], silent=True)
+        return rr.grads[0]
+    _check_loop_against_golden(rec, cam.detach().cpu().numpy(), g, 'G19 camera loop', float(g['lr']), grad_at)
+
+
+@pytest.mark.gpu
+def test_multiscale_shape_loop_matches_reference_golden(fixture_decoder):
+    """G20: the reference's optimize_single_view over the multi-scale renderer list of run_single_shape.py:110-113 (full resolution with
+    buffer_size 1, 1/2 with 3, 1/4 with 5 through downsize_camera_intrinsic; one loss summed over the three; GT downsized inside
+    compute_all_loss) -- five Adam iterations through the drop-in loop against the shape codes and gradients the reference produced."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.inv_optimizer import optimize_single_view
+    from core.utils.render_utils import downsize_camera_intrinsic
+    g = dict(np.load(os.path.join(GOLDEN, 'g20_multiscale_shape_loop.npz')))
+    dec = _plain_decoder(fixture_decoder)
+    H, W, S = int(g['H']), int(g['W']), int(g['march_step'])
+    mk = lambda Kx, bs, **kw: SDFRenderer(dec, Kx, march_step=S, buffer_size=bs, threshold=5e-5, use_depth2normal=True, **kw)
+    rs = [mk(g['K'], 1, img_hw=(H, W), ray_marching_ratio=1.5), mk(downsize_camera_intrinsic(g['K'], 2), 3), mk(downsize_camera_intrinsic(g['K'], 4), 5)]
+    assert [list(r.get_img_hw()) for r in rs] == g['img_hw'].tolist()
+    RT = torch.from_numpy(g['RT']).cuda()
+    gt_pack = {'depth': torch.from_numpy(g['gt_depth']).cuda(), 'normal': torch.from_numpy(g['gt_normal']).cuda(),
+               'silhouette': torch.from_numpy(g['gt_mask']).cuda()}
+    lat = torch.from_numpy(g['latent0']).cuda().requires_grad_(True)
+    opt = torch.optim.Adam([lat], lr=float(g['lr']))
+    rec = _StepRecorder(opt, lat)
+    wd = dict(w_depth=10.0, w_normal=5.0, w_mask_gt=1.0, w_mask_out=1.0, w_l2reg=1.0)
+    optimize_single_view(rs, None, opt, lat, RT, gt_pack, wd, optimizer_type='shape', num_iters=int(g['iters']), renderer_weights=[1.0, 1.0, 1.0], silent=True)
+
+    def grad_at(value):
+        l_ = torch.from_numpy(value).cuda().requires_grad_(True)
+        o = torch.optim.SGD([l_], lr=0.0)
+        rr = _StepRecorder(o, l_)
+        optimize_single_view(rs, None, o, l_, RT, gt_pack, wd, optimizer_type='shape', num_iters=1, renderer_weights=[1.0, 1.0, 1.0], silent=True)
+        return rr.grads[0]
+    _check_loop_against_golden(rec, lat.detach().cpu().numpy(), g, 'G20 multi-scale shape loop', float(g['lr']), grad_at)
