@@ -536,3 +536,65 @@ def test_split_study_pieces_reconstruct_their_operand():
     assert bool((err <= torch.maximum(x.abs() * 2.0 ** -21, torch.full_like(x, 2.0 ** -25 / 64))).all())
     for q in h2:
         assert torch.equal((q.detach() * 64).to(torch.float16).to(torch.float32) / 64, q.detach())
+
+
+def test_python_helpers_match_reference_golden():
+    """G21 (oracle/gen_golden_helpers.py): the reference's own render_utils / loss_utils / train_utils helpers evaluated on seeded
+    inputs, against the restatements the drop-in package ships next to the kernels -- values, in-place side effects and autograd
+    gradients. CPU tensors: these helpers are plain PyTorch on whatever device their inputs live on."""
+    import torch
+    from conftest import GOLDEN
+    from core.utils import render_utils as ru, loss_utils as lu, train_utils as tu
+    assert os.path.abspath(ru.__file__).startswith(PKG)
+    g = dict(np.load(os.path.join(GOLDEN, 'g21_python_helpers.npz')))
+    T = torch.from_numpy
+    # depth2normal: values, the in-place zeroing of its input (render_utils.py:24-25), gradient
+    d = T(g['d2n_depth_in'].copy()).requires_grad_(True)
+    dd = d * 1.0
+    n = ru.depth2normal(dd, float(g['d2n_fx']), float(g['d2n_fy']))
+    (n * T(g['d2n_wn'])).sum().backward()
+    assert np.abs(n.detach().numpy() - g['d2n_normal']).max() <= 1e-6
+    assert np.array_equal(dd.detach().numpy(), g['d2n_depth_after'])
+    assert np.abs(d.grad.numpy() - g['d2n_grad']).max() <= 1e-5 * np.abs(g['d2n_grad']).max()
+    assert np.abs(ru.depth2normal(T(g['d2n_depth_in'].copy()), 40.0).numpy() - g['d2n_normal_single_f']).max() <= 1e-6
+    # quaternion -> rotation, camera tensor -> [R | T] (single and batched) + gradient
+    assert np.abs(ru.quad2rotation(T(g['quat'])).numpy() - g['quat_rot']).max() <= 1e-6
+    assert np.abs(ru.get_camera_from_tensor(T(g['cam'])).numpy() - g['cam_RT_batch']).max() <= 1e-6
+    single = ru.get_camera_from_tensor(T(g['cam'][2]))
+    assert single.shape == (3, 4) and np.abs(single.numpy() - g['cam_RT_single']).max() <= 1e-6
+    c = T(g['cam'][1].copy()).requires_grad_(True)
+    (ru.get_camera_from_tensor(c) * T(g['cam_wRT'])).sum().backward()
+    assert np.abs(c.grad.numpy() - g['cam_grad']).max() <= 1e-5 * np.abs(g['cam_grad']).max()
+    # and back: the inverse the reference takes from Blender's mathutils
+    for i in range(g['cam'].shape[0]):
+        back = ru.get_tensor_from_camera(g['cam_RT_batch'][i]).numpy()
+        q = g['cam'][i, :4] * (1.0 if g['cam'][i, 0] >= 0 else -1.0)
+        assert np.abs(back[:4] - q).max() <= 2e-6 and np.abs(back[4:] - g['cam'][i, 4:]).max() <= 1e-6
+    # intrinsics of a downsized image
+    assert np.allclose(ru.downsize_camera_intrinsic(g['K'], 2), g['K_half'], atol=0) and np.allclose(ru.downsize_camera_intrinsic(g['K'], 4), g['K_quarter'], atol=0)
+    assert bool(g['K_fifth_raises'])
+    with pytest.raises(ValueError):
+        ru.downsize_camera_intrinsic(g['K'], 5)
+    # image / mask downsizing (loss_utils.py:27-57): masks survive only where the whole block is set
+    for f in (2, 4):
+        assert np.abs(lu.downsize_img_tensor(T(g['ds_img']), f).numpy() - g['ds_img_%d' % f]).max() <= 1e-6
+        assert np.abs(lu.downsize_img_tensor(T(g['ds_img3']), f).numpy() - g['ds_img3_%d' % f]).max() <= 1e-6
+        mk = lu.downsize_img_tensor(T(g['ds_mask']), f)
+        assert mk.dtype == torch.uint8 and np.array_equal(mk.numpy(), g['ds_mask_%d' % f])
+        assert np.array_equal(lu.downsize_img_tensor(T(g['ds_mask']).bool(), f).numpy() != 0, g['ds_mask_%d' % f] != 0)
+    # bilinear sampling at pixel coordinates, zero padding outside
+    assert np.abs(lu.grid_sample_on_img(T(g['gs_img']), T(g['gs_xy'])).numpy() - g['gs_out']).max() <= 1e-6
+    # colour loss + gradient
+    co = T(g['lc_out'].copy()).requires_grad_(True)
+    lc, _ = lu.compute_loss_color(co, T(g['lc_m1']), T(g['lc_gt']), T(g['lc_m2']))
+    lc.backward()
+    assert abs(float(lc) - float(g['lc_loss'])) <= 1e-6 and np.abs(co.grad.numpy() - g['lc_grad']).max() <= 1e-7
+    # sim(3): exp of a so(3) vector by the 19-term series, [exp(s) R | t], gradients
+    sim3 = {'rot': T(g['sim3_rot'].copy()).requires_grad_(True), 'scale': torch.tensor(float(g['sim3_scale']), requires_grad=True),
+            'trans': T(g['sim3_trans'].copy()).requires_grad_(True)}
+    M = tu.params_to_mtrx(sim3)
+    (M * T(g['sim3_w'])).sum().backward()
+    assert np.abs(M.detach().numpy() - g['sim3_mtrx']).max() <= 1e-6
+    assert np.abs(sim3['rot'].grad.numpy() - g['sim3_g_rot']).max() <= 1e-5 and abs(float(sim3['scale'].grad) - float(g['sim3_g_scale'])) <= 1e-5
+    assert np.abs(sim3['trans'].grad.numpy() - g['sim3_g_trans']).max() <= 1e-6
+    assert np.abs(tu.get_lie_rotation_matrix(torch.tensor([1.3, -0.8, 2.1])).numpy() - g['lie_big']).max() <= 2e-5      # (a large rotation: the truncated series itself)
