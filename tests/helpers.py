@@ -132,3 +132,26 @@ def compare_big_golden(a, g, label, grad_floor_mult=2.0):
         res[k + '_floor'] = fl
         assert rel <= grad_floor_mult * fl, (label, k, rel, fl)
     return res
+
+
+DEEPSDF_SPECS = {       # the layout of facebookresearch/DeepSDF's examples/*/specs.json (what load_decoder reads, decoder_utils.py:7-27)
+    'Description': ['synthetic experiment directory written by tests/helpers.py: fixture F1 in DeepSDF checkpoint format'],
+    'NetworkArch': 'deep_sdf_decoder', 'CodeLength': 256,
+    'NetworkSpecs': {'dims': [512] * 8, 'dropout': list(range(8)), 'dropout_prob': 0.2, 'norm_layers': list(range(8)), 'latent_in': [4],
+                     'xyz_in_all': False, 'use_tanh': False, 'latent_dropout': False, 'weight_norm': True},
+}
+
+
+def write_deepsdf_experiment(root, state_dict, checkpoint='2000', module_prefix=True, epoch=2000):
+    """A DeepSDF experiment directory as the reference's drivers expect it (run_single_shape.py:26-33, decoder_utils.py:7-51):
+    <root>/specs.json + <root>/ModelParameters/<checkpoint>.pth = {'epoch', 'model_state_dict'}; shape decoders are saved from a
+    DataParallel module ('module.' prefix), colour decoders without it (decoder_utils.py:35-42). `state_dict`: name -> numpy array."""
+    import json
+    import os
+    import torch
+    os.makedirs(os.path.join(root, 'ModelParameters'), exist_ok=True)
+    with open(os.path.join(root, 'specs.json'), 'w') as f:
+        json.dump(DEEPSDF_SPECS, f)
+    sd = {(('module.' + k) if module_prefix else k): torch.from_numpy(np.ascontiguousarray(v)) for k, v in state_dict.items()}
+    torch.save({'epoch': epoch, 'model_state_dict': sd}, os.path.join(root, 'ModelParameters', checkpoint + '.pth'))
+    return root

@@ -598,3 +598,44 @@ def test_python_helpers_match_reference_golden():
     assert np.abs(sim3['rot'].grad.numpy() - g['sim3_g_rot']).max() <= 1e-5 and abs(float(sim3['scale'].grad) - float(g['sim3_g_scale'])) <= 1e-5
     assert np.abs(sim3['trans'].grad.numpy() - g['sim3_g_trans']).max() <= 1e-6
     assert np.abs(tu.get_lie_rotation_matrix(torch.tensor([1.3, -0.8, 2.1])).numpy() - g['lie_big']).max() <= 2e-5      # (a large rotation: the truncated series itself)
+
+
+def test_load_decoder_matches_reference_golden(fixture_decoder, tmp_path):
+    """G22 (oracle/gen_golden_load.py): the reference's load_decoder (decoder_utils.py:7-51) on a DeepSDF experiment directory -- the
+    first call of every driver (run_single_shape.py:62-63: `load_decoder(dir, checkpoint)` then `.module.cuda()`). The drop-in one must
+    hand back the same wrapper, state-dict keys / shapes, constructor attributes and eval-mode outputs, for the shape decoder (saved from
+    DataParallel: 'module.' prefix) and for a colour decoder (specs of the shape experiment, weights of the colour experiment, no
+    prefix); the packer must accept the loaded module (weight-norm folded)."""
+    import torch
+    import helpers
+    from conftest import GOLDEN
+    from core.utils.decoder_utils import load_decoder
+    from distr import fixture, decoder_pack
+    g = dict(np.load(os.path.join(GOLDEN, 'g22_load_decoder.npz')))
+    Ws, bs, latent = fixture_decoder
+    cWs, cbs = fixture.make_color_decoder_weights(color_size=16)[:2]
+    d_shape = helpers.write_deepsdf_experiment(str(tmp_path / 'sofas'), decoder_pack.fixture_state_dict(Ws, bs, True), '2000', module_prefix=True)
+    d_color = helpers.write_deepsdf_experiment(str(tmp_path / 'sofas_color'), decoder_pack.fixture_state_dict(cWs, cbs, True), 'latest', module_prefix=False)
+
+    def check(dec, pre, x):
+        assert type(dec).__name__ == str(g[pre + 'cls']) and type(dec.module).__name__ == str(g[pre + 'inner'])
+        sd = dec.state_dict()
+        assert sorted(sd.keys()) == [str(k) for k in g[pre + 'keys']]
+        assert [list(sd[k].shape) + [0] * (2 - sd[k].dim()) for k in sorted(sd.keys())] == g[pre + 'shapes'].tolist()
+        for a, want in zip(g['attr_names'], g[pre + 'attrs']):
+            assert repr(getattr(dec.module, str(a))) == str(want), (a, getattr(dec.module, str(a)), want)
+        dec.module.eval()
+        with torch.no_grad():
+            y = dec.module.inference(torch.from_numpy(x)).numpy()
+        assert np.abs(y - g[pre + 'y']).max() <= 1e-6
+    dec = load_decoder(d_shape, '2000')
+    check(dec, 'shape_', g['x'])
+    check(load_decoder(d_shape, 'latest', color_size=16, experiment_directory_color=d_color), 'color_', g['xc'])
+    assert sorted(load_decoder(d_shape, None).state_dict().keys()) == [str(k) for k in g['nockpt_keys']]
+    with pytest.raises(Exception):
+        load_decoder(str(tmp_path / 'nowhere'), '2000')
+    # what the renderer does with it: fold the weight norm, hand effective weights to the packer -- they are the fixture's
+    Wse, bse = decoder_pack.effective_weights({k: v.numpy() for k, v in dec.module.state_dict().items()})
+    for W, We in zip(Ws, Wse):
+        assert np.abs(W - We).max() <= 2e-7 * max(1.0, np.abs(W).max())
+    assert decoder_pack.pack_module(dec.module).size == sum(W.size + b.size for W, b in zip(Ws, bs))
