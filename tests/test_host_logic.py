@@ -639,3 +639,26 @@ def test_load_decoder_matches_reference_golden(fixture_decoder, tmp_path):
     for W, We in zip(Ws, Wse):
         assert np.abs(W - We).max() <= 2e-7 * max(1.0, np.abs(W).max())
     assert decoder_pack.pack_module(dec.module).size == sum(W.size + b.size for W, b in zip(Ws, bs))
+
+
+def test_multi_view_pair_schedule_matches_reference_golden(monkeypatch):
+    """G23 (oracle/gen_golden_schedule.py): the view pairs the reference's optimize_multi_view renders, round by round
+    (optimize_multi.py:48-65: rot_freq, the sep_dist stride, the wrap-around rule), recorded from the reference's own loop -- against the
+    pairs the drop-in loop hands to its round (and shards over the ranks: pairs[rank::world])."""
+    import torch
+    from conftest import GOLDEN
+    import core.inv_optimizer.optimize_multi as om
+    assert os.path.abspath(om.__file__).startswith(PKG)
+    g = dict(np.load(os.path.join(GOLDEN, 'g23_multi_view_schedule.npz')))
+    for (n, v, sep) in g['combos'].tolist():
+        rounds = []
+
+        def fake_round(renderer, shape_code, images, cameras, pairs, weight_list, **kw):
+            rounds.append([list(p) for p in pairs])
+            return shape_code.sum() * 0.0 + 1.0, {'color': torch.tensor(0.0), 'l2reg': torch.tensor(0.0)}
+        monkeypatch.setattr(om, 'multi_view_round', fake_round)
+        monkeypatch.setattr(om, '_StreamPool', lambda n_, dev: None)
+        code = torch.zeros(1, 4, requires_grad=True)
+        om.optimize_multi_view(None, None, code, torch.optim.SGD([code], lr=0.0), [None] * n, [None] * n, {}, num_views_per_round=v, num_iters=2,
+                               sep_dist=sep, test_step=1000, distributed=False)
+        assert rounds == g['pairs_%d_%d_%d' % (n, v, sep)].tolist(), (n, v, sep)
