@@ -1559,7 +1559,7 @@ __global__ void __launch_bounds__(256) k_normal_finish(View V0, float* normal_hw
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[j] = g[j] / (len + 1e-12f);
   }
-  const float* M = V.cfg.M;
+  const float* M = V.cfg.M_normal;     // renderer.py:899: the normals take the constructor's matrix whatever use_transform says
   float t[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) t[i] = M[i * 3] * g[0] + M[i * 3 + 1] * g[1] + M[i * 3 + 2] * g[2];

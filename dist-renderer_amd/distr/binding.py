@@ -54,6 +54,7 @@ class RenderCfg(_Sized):
         ('K_inv', C.c_float * 9),
         ('fx', C.c_float), ('fy', C.c_float),
         ('M', C.c_float * 9),
+        ('M_normal', C.c_float * 9),
         ('march_step', C.c_int32), ('buffer_size', C.c_int32),
         ('ratio', C.c_float), ('threshold', C.c_float), ('radius', C.c_float), ('clamp_dist', C.c_float),
         ('marcher', C.c_int32),
@@ -196,6 +197,9 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
     if Mm.shape != (3, 3):
         raise NotImplementedError('only 3x3 transform matrices are supported (the reference\'s 3x4 sim3 inverse path '
                                   'hits an un-imported pdb.set_trace(), renderer.py:116)')
+    # use_transform=False removes the matrix from the sample points only; render_normal transforms the normals unconditionally
+    # (renderer.py:895 vs :899, golden G24)
+    cfg.M_normal = (C.c_float * 9)(*Mm.reshape(-1))
     if not use_transform:
         Mm = np.eye(3, dtype=np.float32)
     cfg.M = (C.c_float * 9)(*Mm.reshape(-1))

@@ -87,7 +87,11 @@ typedef struct distr_render_cfg {
   int32_t H, W;               /* img_hw                                                     renderer.py:31-35 */
   float K_inv[9];             /* float32(inv(K)), row-major                                 renderer.py:161-164 */
   float fx, fy;               /* K[0,0], K[1,1] (depth2normal)                              renderer.py:973-974 */
-  float M[9];                 /* transform_matrix (3x3), identity when use_transform=False  renderer.py:45, 84-120 */
+  float M[9];                 /* transform_matrix (3x3) applied (inverted) to the sample POINTS; identity when use_transform=False
+                                 renderer.py:45, 100-120, 202-223 */
+  float M_normal[9];          /* matrix applied to the surface NORMALS: always the constructor's transform_matrix -- render_normal calls
+                                 transform_points unconditionally (renderer.py:899), use_transform only switches the points' inverse
+                                 transform (:895); golden G24 */
   int32_t march_step;         /* renderer.py:18  */
   int32_t buffer_size;        /* renderer.py:19  (<= DISTR_MAX_BUFFER_SIZE) */
   float ratio;                /* ray_marching_ratio renderer.py:21 */

@@ -21,6 +21,7 @@ class OrcCfg(C.Structure):
         ('K_inv', C.c_float * 9),
         ('fx', C.c_float), ('fy', C.c_float),
         ('M', C.c_float * 9),
+        ('Mn', C.c_float * 9),
         ('march_step', C.c_int32), ('buffer_size', C.c_int32),
         ('ratio', C.c_float), ('threshold', C.c_float), ('radius', C.c_float), ('clamp_dist', C.c_float),
         ('marcher', C.c_int32),
@@ -98,8 +99,10 @@ def make_cfg(H, W, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold
     cfg.fx, cfg.fy = float(np.float32(K[0, 0])), float(np.float32(K[1, 1]))
     if transform_matrix is None:
         transform_matrix = np.array([[1., 0., 0.], [0., 0., -1.], [0., 1., 0.]])   # renderer.py:45
-    Mm = np.asarray(transform_matrix, dtype=np.float32) if use_transform else np.eye(3, dtype=np.float32)
+    Mfull = np.asarray(transform_matrix, dtype=np.float32)
+    Mm = Mfull if use_transform else np.eye(3, dtype=np.float32)      # the points' (inverse) transform: renderer.py:895, 202-223
     cfg.M = (C.c_float * 9)(*Mm.reshape(-1))
+    cfg.Mn = (C.c_float * 9)(*Mfull.reshape(-1))                      # the normals' transform is unconditional: renderer.py:899 (golden G24)
     cfg.march_step, cfg.buffer_size = march_step, buffer_size
     cfg.ratio, cfg.threshold, cfg.radius, cfg.clamp_dist = ratio, threshold, radius, clamp_dist
     cfg.marcher = MARCHERS[marcher]

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   /* struct layouts, field by field, for the ctypes mirror to be compared with (tests/test_host_logic.py) */
 #define OFF(T, f) printf("offset %s.%s %zu %zu\n", #T, #f, offsetof(T, f), sizeof(((T*)0)->f))
   OFF(distr_render_cfg, struct_size); OFF(distr_render_cfg, H); OFF(distr_render_cfg, W); OFF(distr_render_cfg, K_inv); OFF(distr_render_cfg, fx); OFF(distr_render_cfg, fy);
-  OFF(distr_render_cfg, M); OFF(distr_render_cfg, march_step); OFF(distr_render_cfg, buffer_size); OFF(distr_render_cfg, ratio);
+  OFF(distr_render_cfg, M); OFF(distr_render_cfg, M_normal); OFF(distr_render_cfg, march_step); OFF(distr_render_cfg, buffer_size); OFF(distr_render_cfg, ratio);
   OFF(distr_render_cfg, threshold); OFF(distr_render_cfg, radius); OFF(distr_render_cfg, clamp_dist); OFF(distr_render_cfg, marcher);
   OFF(distr_render_cfg, coarse_steps); OFF(distr_render_cfg, use_depth2normal); OFF(distr_render_cfg, normalize_normal);
   OFF(distr_render_cfg, want_normal); OFF(distr_render_cfg, grad_depth); OFF(distr_render_cfg, grad_mask); OFF(distr_render_cfg, grad_camera);

@@ -1759,3 +1759,75 @@ def test_multiscale_shape_loop_matches_reference_golden(fixture_decoder):
         optimize_single_view(rs, None, o, l_, RT, gt_pack, wd, optimizer_type='shape', num_iters=1, renderer_weights=[1.0, 1.0, 1.0], silent=True)
         return rr.grads[0]
     _check_loop_against_golden(rec, lat.detach().cpu().numpy(), g, 'G20 multi-scale shape loop', float(g['lr']), grad_at)
+
+
+@pytest.mark.gpu
+def test_renderer_options_match_reference_golden(fixture_decoder):
+    """G24 through the drop-in class: every constructor / call option of the golden (identity and permuting transform_matrix,
+    use_transform=False, normalize_normal=False, clamp_dist, threshold, radius, march_step_list, ray_marching_ratio, buffer_size 1 / 8,
+    img_hw=None) with the reference's own keyword names, against the reference's outputs and gradients; plus render_depth with its own
+    default marcher ('recursive', renderer.py:836) and the gradient entering through Zdepth."""
+    import torch
+    import test_oracle_vs_golden as tg
+    from core.sdfrenderer import SDFRenderer
+    g = np.load(os.path.join(GOLDEN, 'g24_renderer_options.npz'))
+    dec = _plain_decoder(fixture_decoder)
+    H, W = int(g['H']), int(g['W'])
+    PERM = g['perm']
+    cases = {
+        'identity_transform': (dict(transform_matrix=np.eye(3)), dict()),
+        'permuting_transform': (dict(transform_matrix=PERM), dict(ray_marching_type='recursive')),
+        'no_use_transform': (dict(), dict(use_transform=False)),
+        'unnormalized_normal': (dict(), dict(normalize_normal=False, ray_marching_type='recursive')),
+        'clamp_005': (dict(), dict(clamp_dist=0.05)),
+        'threshold_1e-3': (dict(threshold=1e-3), dict()),
+        'radius_09': (dict(radius=0.9), dict()),
+        'coarse_2_4': (dict(march_step_list=[2, 4, -1]), dict()),
+        'ratio_10': (dict(ray_marching_ratio=1.0), dict(ray_marching_type='recursive')),
+        'ratio_20': (dict(ray_marching_ratio=2.0), dict()),
+        'buffer_1': (dict(buffer_size=1), dict()),
+        'buffer_8': (dict(buffer_size=8), dict(ray_marching_type='trivial')),
+        'd2n_threshold_ratio': (dict(use_depth2normal=True, threshold=2e-4, ray_marching_ratio=1.2), dict()),
+        'img_hw_none': (dict(), dict()),
+    }
+    assert sorted(list(cases) + ['render_depth_default']) == sorted(str(n) for n in g['names'])
+    wd, wq, wn = (torch.from_numpy(a).cuda() for a in helpers.loss_weights(H, W, 5))
+
+    def run(ckw, rkw, img_hw):
+        kw = dict(march_step=int(g['march_step']), buffer_size=3, ray_marching_ratio=1.5, use_depth2normal=False)
+        kw.update(ckw)
+        r = SDFRenderer(dec, g['K'], img_hw=img_hw, **kw)
+        assert tuple(r.get_img_hw()) == (H, W)
+        lat = torch.from_numpy(g['latent']).cuda().requires_grad_(True)
+        Rt, Tt = torch.from_numpy(g['R']).cuda().requires_grad_(True), torch.from_numpy(g['T']).cuda().requires_grad_(True)
+        depth, normal, mask, mq = r.render(lat, Rt, Tt, **rkw)
+        L = (depth * wd)[mask.bool()].sum() + (mq * wq).sum() + (normal * wn).sum()
+        L.backward()
+        return dict(mask=mask.cpu().numpy(), depth=depth.detach().cpu().numpy(), normal=normal.detach().cpu().numpy(), min_sdf=mq.detach().cpu().numpy(),
+                    g_latent=lat.grad.cpu().numpy(), g_R=Rt.grad.cpu().numpy(), g_T=Tt.grad.cpu().numpy(), loss=float(L.detach()))
+    for name, (ckw, rkw) in sorted(cases.items()):
+        a = run(ckw, rkw, None if name == 'img_hw_none' else (H, W))
+        if name == 'img_hw_none':                                  # size from the intrinsic (renderer.py:31-33): the plain default render
+            assert abs(a['loss'] - float(g['img_hw_none.loss'])) <= 2e-5 * abs(float(g['img_hw_none.loss']))
+            assert np.abs(a['g_latent'] - g['img_hw_none.g_latent']).max() <= 1e-3 * np.abs(g['img_hw_none.g_latent']).max()
+            continue
+        res = tg.check_g24(a, g, name)
+        assert abs(a['loss'] - float(g[name + '.loss'])) <= 5e-5 * abs(float(g[name + '.loss'])), (name, a['loss'], float(g[name + '.loss']))
+        print('G24', name, {k: '%.1e' % v for k, v in res.items()})
+    # render_depth(): default marcher 'recursive', gradient through Zdepth and min_sdf
+    r = SDFRenderer(dec, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=2)
+    lat = torch.from_numpy(g['latent']).cuda().requires_grad_(True)
+    Rt, Tt = torch.from_numpy(g['R']).cuda().requires_grad_(True), torch.from_numpy(g['T']).cuda().requires_grad_(True)
+    z, m, q = r.render_depth(lat, Rt, Tt)
+    assert m.dtype == torch.bool and np.array_equal(m.cpu().numpy().astype(np.uint8), g['render_depth_default.mask'])
+    ((z * torch.from_numpy(g['render_depth_default.gz']).cuda())[m].sum() + 0.5 * q.sum()).backward()
+    mb = m.cpu().numpy()
+    assert np.abs(z.detach().cpu().numpy() - g['render_depth_default.zdepth'])[mb].max() <= 1e-4
+    # off the final mask Zdepth still holds where the march ended (every ray of this view crosses the unit sphere; 1e11 only for rays that
+    # miss it, renderer.py:866-869): same values up to stop-step events on rays that never converged
+    dz_off = np.abs(z.detach().cpu().numpy() - g['render_depth_default.zdepth'])[~mb]
+    assert np.percentile(dz_off, 99) <= 1e-4 and dz_off.max() <= 0.2, (np.percentile(dz_off, 99), dz_off.max())
+    assert np.abs(q.detach().cpu().numpy() - g['render_depth_default.q']).max() <= 1e-4
+    for k, t in (('g_latent', lat), ('g_R', Rt), ('g_T', Tt)):
+        ref = g['render_depth_default.' + k]
+        assert np.abs(t.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), k

@@ -330,3 +330,55 @@ def test_oracle_no_grad_flags_match_reference_golden(cpu_oracle, marcher, d2n, f
         ref, scale, fl = g['%s.%s' % (key, name)], float(g['%s.%s_scale' % (key, name)]), float(g['%s.%s_floor_rel' % (key, name)])
         rel = float(np.abs(mine.reshape(-1) - ref.reshape(-1)).max() / scale)
         assert rel <= max(2.0 * fl, 1e-3), (key, name, rel, fl)          # gradients <= 1e-3 relative, or the reference's own floor
+
+
+# G24 cases as cfg keyword arguments of the oracle / binding (oracle/gen_golden_options.py::CASES)
+G24_CFG = {
+    'identity_transform': dict(transform_matrix=np.eye(3)),
+    'permuting_transform': dict(transform_matrix=np.array([[0., 1., 0.], [1., 0., 0.], [0., 0., -1.]]), marcher='recursive'),
+    'no_use_transform': dict(use_transform=False),
+    'unnormalized_normal': dict(normalize_normal=False, marcher='recursive'),
+    'clamp_005': dict(clamp_dist=0.05),
+    'threshold_1e-3': dict(threshold=1e-3),
+    'radius_09': dict(radius=0.9),
+    'coarse_2_4': dict(coarse_steps=(2, 4)),
+    'ratio_10': dict(ratio=1.0, marcher='recursive'),
+    'ratio_20': dict(ratio=2.0),
+    'buffer_1': dict(buffer_size=1),
+    'buffer_8': dict(buffer_size=8, marcher='trivial'),
+    'd2n_threshold_ratio': dict(use_depth2normal=True, threshold=2e-4, ratio=1.2),
+}
+
+
+def check_g24(a, g, name):
+    """a: dict(mask, depth, normal, min_sdf, g_latent, g_R, g_T[, loss]) of one G24 case against the reference's outputs: <= 1 mask flip
+    (or the reference's own flips under weight noise), depth / min-sdf 1e-4, normals at the p99 bar, gradients 1e-3 or 2 x floor."""
+    H, W = (int(v) for v in g[name + '.hw'])
+    ma, mr = a['mask'].reshape(H, W).astype(bool), g[name + '.mask'].astype(bool)
+    assert int((ma != mr).sum()) <= max(1, 2 * int(g[name + '.flips_floor'])), name
+    both = ma & mr
+    assert np.abs(a['depth'].reshape(H, W) - g[name + '.depth'])[both].max() <= 1e-4, name
+    assert np.abs(a['min_sdf'].reshape(H, W) - g[name + '.q']).max() <= 1e-4, name
+    dn = np.abs(a['normal'].reshape(H, W, 3) - g[name + '.normal'])[both]
+    fx = float(g['K'][0, 0])
+    assert np.percentile(dn, 99) <= (max(1e-4, 1e-5 * fx) if 'd2n' in name else 1e-4) * (30.0 if name == 'unnormalized_normal' else 1.0), (name, np.percentile(dn, 99))
+    res = {}
+    for k in ('g_latent', 'g_R', 'g_T'):
+        rel = float(np.abs(a[k].reshape(-1) - g['%s.%s' % (name, k)].reshape(-1)).max() / np.abs(g['%s.%s' % (name, k)]).max())
+        res[k] = rel
+        assert rel <= max(2.0 * float(g['%s.%s_floor_rel' % (name, k)]), 1e-3), (name, k, rel)
+    return res
+
+
+@pytest.mark.parametrize('name', sorted(G24_CFG))
+def test_oracle_renderer_options_match_reference_golden(cpu_oracle, name):
+    """G24 (oracle/gen_golden_options.py): constructor / call options of SDFRenderer rendered by the reference itself. Until round 4 the
+    oracle's reading of them was the only check -- and it was wrong for use_transform=False: the reference removes the transform matrix
+    from the sample points only, render_normal keeps transforming the normals (renderer.py:895 vs :899)."""
+    import helpers
+    g = np.load(os.path.join(GOLDEN, 'g24_renderer_options.npz'))
+    H, W = int(g['H']), int(g['W'])
+    kw = dict(march_step=int(g['march_step']), buffer_size=3, ratio=1.5, marcher='pyramid_recursive', use_depth2normal=False)
+    kw.update(G24_CFG[name])
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g['T'], g['latent'], **kw)
+    print(name, check_g24(b, g, name))
