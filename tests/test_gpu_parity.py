@@ -159,7 +159,8 @@ def test_render_depth_and_warp_gradient_path(engine, cpu_oracle, orc, fixture_de
 
 def test_camera_inside_sphere_and_empty_view(engine, cpu_oracle, orc, fixture_decoder):
     """Edge cases of get_intersections_with_unit_spheres (renderer.py:266-268): camera inside the unit sphere
-    (init depth 0 everywhere) and a camera looking away (no ray hits the sphere: empty lists everywhere)."""
+    (init depth 0 everywhere) and a camera looking away (the reference intersects LINES with the sphere, so rays still "meet" it behind the
+    camera and march from a negative depth; none finds a surface: golden G25 pins that against the reference itself)."""
     from distr import fixture
     _, _, latent = fixture_decoder
     H = W = 32
@@ -1831,3 +1832,19 @@ def test_renderer_options_match_reference_golden(fixture_decoder):
     for k, t in (('g_latent', lat), ('g_R', Rt), ('g_T', Tt)):
         ref = g['render_depth_default.' + k]
         assert np.abs(t.grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), k
+
+
+@pytest.mark.gpu
+def test_edge_cases_match_reference_golden(engine):
+    """G25 on the HIP path (same checks as the oracle's, tests/test_oracle_vs_golden.py::check_g25): camera inside the unit sphere, far
+    away, looking away, and a shape code without a surface."""
+    import test_oracle_vs_golden as tg
+    g = np.load(os.path.join(GOLDEN, 'g25_edge_cases.npz'))
+    H, W = int(g['H']), int(g['W'])
+    for name, marcher, d2n in tg.G25_RUNS:
+        key = '%s.%s_%s' % (name, marcher, 'd2n' if d2n else 'agn')
+        a = helpers.hip_render(engine, H, W, g['K'], g['R'], g[name + '.T'], g[name + '.latent'], march_step=int(g['march_step']),
+                               buffer_size=int(g['buffer_size']), marcher=marcher, use_depth2normal=d2n)
+        res = tg.check_g25(a, g, key, H, W)
+        assert abs(a['loss'] - float(g[key + '.loss'])) <= 5e-5 * abs(float(g[key + '.loss'])), key
+        print('G25', key, 'valid', int(a['mask'].sum()), {k: '%.1e' % v for k, v in res.items()})

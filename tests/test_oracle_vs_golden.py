@@ -382,3 +382,50 @@ def test_oracle_renderer_options_match_reference_golden(cpu_oracle, name):
     kw.update(G24_CFG[name])
     b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g['T'], g['latent'], **kw)
     print(name, check_g24(b, g, name))
+
+
+G25_RUNS = [(n, m, d) for n in ('away', 'far', 'inside', 'nosurf') for (m, d) in (('recursive', False), ('pyramid_recursive', False), ('pyramid_recursive', True))]
+
+
+def check_g25(a, g, key, H, W):
+    """One edge case of G25 against the reference: mask (<= 1 flip), the in-sphere set (Zdepth < 1e10) exactly, depth / Zdepth / min-sdf at
+    1e-4 (min-sdf everywhere: off the sphere it is dist + threshold - radius, renderer.py:863), normals, loss, gradients relative to the
+    largest of the three gradient tensors' own scale (a gradient that is ~0 in the reference must be ~0 here)."""
+    ma, mr = a['mask'].reshape(H, W).astype(bool), g[key + '.mask'].astype(bool)
+    assert int((ma != mr).sum()) <= 1, key
+    za, zr = a['zdepth'].reshape(-1), g[key + '.zdepth'].reshape(-1)
+    assert np.array_equal(za < 1e10, zr < 1e10), key                       # same rays meet the unit sphere
+    ins = zr < 1e10
+    assert np.array_equal(za[~ins], zr[~ins])                              # 1e11 where they do not
+    both = (ma & mr).reshape(-1)
+    if both.any():
+        assert np.abs(za - zr)[both].max() <= 1e-4 and np.abs(a['depth'].reshape(-1) - g[key + '.depth'].reshape(-1))[both].max() <= 1e-4, key
+        dn = np.abs(a['normal'].reshape(-1, 3) - g[key + '.normal'].reshape(-1, 3))[both]
+        assert np.percentile(dn, 99) <= (3.2e-4 if key.endswith('d2n') else 1e-4), (key, np.percentile(dn, 99))
+    none = ~(ma | mr)
+    assert np.array_equal(a['depth'].reshape(H, W)[none], g[key + '.depth'][none]), key       # background convention, exactly
+    assert np.abs(a['min_sdf'].reshape(H, W) - g[key + '.q']).max() <= 1e-4, key
+    res = {}
+    for k in ('g_latent', 'g_R', 'g_T'):
+        ref = g['%s.%s' % (key, k)]
+        # (floor 1e-2: with no surface every tanh is saturated, 1 - y^2 ~ 1e-5 is all rounding and the gradients are ~1e-4 -- "zero" on the
+        # scale of this loss, whose gradients are O(1..1000) whenever there is a surface)
+        scale = max(float(np.abs(ref).max()), 1e-3 * max(float(np.abs(g['%s.%s' % (key, kk)]).max()) for kk in ('g_latent', 'g_R', 'g_T')), 1e-2)
+        res[k] = float(np.abs(a[k].reshape(-1) - ref.reshape(-1)).max() / scale)
+        assert res[k] <= 2e-3, (key, k, res[k])
+    return res
+
+
+@pytest.mark.parametrize('name,marcher,d2n', G25_RUNS)
+def test_oracle_edge_cases_match_reference_golden(cpu_oracle, name, marcher, d2n):
+    """G25 (oracle/gen_golden_edges.py): camera inside the unit sphere, camera far away (most rays miss the sphere), camera looking away
+    (the reference intersects LINES with the sphere: 405 rays still 'meet' it behind the camera, none finds a surface) and a shape code
+    without a surface -- rendered fwd + bwd by the reference itself."""
+    import helpers
+    g = np.load(os.path.join(GOLDEN, 'g25_edge_cases.npz'))
+    H, W = int(g['H']), int(g['W'])
+    key = '%s.%s_%s' % (name, marcher, 'd2n' if d2n else 'agn')
+    assert not bool(g[key + '.raised'])
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g[name + '.T'], g[name + '.latent'], march_step=int(g['march_step']),
+                              buffer_size=int(g['buffer_size']), marcher=marcher, use_depth2normal=d2n)
+    print(key, check_g25(b, g, key, H, W))
