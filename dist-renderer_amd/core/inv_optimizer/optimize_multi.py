@@ -49,8 +49,13 @@ class _StreamPool(object):
         main = torch.cuda.current_stream()
         side = self.streams[i % len(self.streams)]
         side.wait_stream(main)
+        from distr import binding
         with torch.cuda.stream(side):
-            out = fn()
+            if len(self.streams) > 1:
+                with binding.concurrent_section():      # several renders share the device: no sticky tail launches (distr_render_cfg.concurrent)
+                    out = fn()
+            else:
+                out = fn()
         return out
 
     def join(self, tensors=()):

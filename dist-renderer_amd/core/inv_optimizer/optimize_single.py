@@ -40,11 +40,15 @@ def _progress(n, silent):
 def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, camera_tensor, gt_pack, weight_dict,
                          optimizer_type='shape', num_iters=200, renderer_weights=None, grad_settings=None, points_gt=None,
                          test_step=50, profile=False, visualizer=None, silent=False, vis_folder=None,
-                         ray_marching_type='pyramid_recursive', on_iteration=None, distributed=None):
+                         ray_marching_type='pyramid_recursive', on_iteration=None, distributed=None, streams=None):
+    """streams (not in the reference): the renderers of a multi-scale list (run_single_shape.py:110-113) are independent until their losses
+    are summed; each is issued on its own HIP stream of a small pool so that their latency-bound march tails overlap (same values: the
+    sum is taken in list order). None = one stream per renderer when the list has several and no visualizer wants them one by one;
+    0 = the reference's sequential order."""
     if optimizer_type not in ('shape', 'camera'):
         raise NotImplementedError
     from distr import parallel
-    from .optimize_multi import _dist_state
+    from .optimize_multi import _dist_state, _StreamPool
     rank, world = _dist_state(distributed)
     silent = silent or rank != 0             # printing / plots / evaluation once, on rank 0
     weights = list(renderer_weights) if renderer_weights else [1.0] * len(sdfrenderer_list)
@@ -53,13 +57,36 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
     visualize = (visualizer is not None) and (not silent)
     if (visualize or (points_gt is not None and not silent)) and vis_folder is not None and not os.path.exists(vis_folder):
         os.mkdir(vis_folder)
+    nstreams = (len(sdfrenderer_list) if len(sdfrenderer_list) > 1 else 0) if streams is None else int(streams)
+    if visualizer is not None or not shape_code.is_cuda:
+        nstreams = 0
+    pool = _StreamPool(nstreams, shape_code.device) if nstreams > 0 else None
     for i in _progress(num_iters, silent):
         optimizer.zero_grad()
         extrinsics = camera_tensor if optimizer_type == 'shape' else get_camera_from_tensor(camera_tensor)
         loss = 0
         err = None
         try:
-            for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights)):
+            if pool is not None:
+                # the scales of a multi-scale list on a pool of streams: one latency-bound march per stream, overlapping
+                mine = [(idx, r_, w_) for idx, (r_, w_) in enumerate(zip(sdfrenderer_list, weights)) if idx % world == rank]
+
+                def one(renderer, rw):
+                    pack, _ = compute_all_loss(renderer, shape_code, extrinsics, gt_pack, threshold=renderer.get_threshold(), profile=profile,
+                                               visualizer=None, ray_marching_type=ray_marching_type, grad_settings=dict(grad_settings))
+                    return pack, rw * (weight_dict['w_depth'] * pack['depth'] + weight_dict['w_normal'] * pack['normal'] +
+                                       weight_dict['w_mask_gt'] * pack['mask_gt'] + weight_dict['w_mask_out'] * pack['mask_out'] +
+                                       weight_dict['w_l2reg'] * pack['l2reg'])
+                outs = [pool.run(k, lambda r_=r_, w_=w_: one(r_, w_)) for k, (idx, r_, w_) in enumerate(mine)]
+                pool.join([o[1] for o in outs])
+                for (idx, r_, w_), (pack, part) in zip(mine, outs):
+                    loss = loss + part
+                    if idx == 0:
+                        if not silent:
+                            print_loss_pack(pack, '{0}/s224'.format(i))
+                        if on_iteration is not None:
+                            on_iteration(i, pack, loss)
+            for idx, (renderer, rw) in enumerate(zip(sdfrenderer_list, weights) if pool is None else ()):
                 if idx % world != rank:          # renderer-parallel: another rank renders this scale
                     continue
                 # only the first (full-resolution) renderer of a multi-scale list feeds the visualiser (optimize_single.py:63-74)

@@ -806,7 +806,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       else hipLaunchKernelGGL((k_step<false, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
     } else {
       G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
-      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky);
+      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky && !cfg->concurrent);
       unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
       if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
       G.n16 = up8(n16);

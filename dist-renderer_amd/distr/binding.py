@@ -64,6 +64,7 @@ class RenderCfg(_Sized):
         ('save_for_backward', C.c_int32),
         ('row0', C.c_int32), ('rows', C.c_int32),
         ('arith', C.c_int32),
+        ('concurrent', C.c_int32),
     ]
 
     @property
@@ -180,6 +181,27 @@ def lib():
     return _lib
 
 
+_concurrent = threading.local()
+
+
+def concurrent_renders():
+    """True inside a `concurrent_section()` of this thread: the caller is issuing several renders on different streams at once."""
+    return getattr(_concurrent, 'depth', 0) > 0
+
+
+class concurrent_section(object):
+    """`with binding.concurrent_section():` around renders that are issued on a pool of streams -- every cfg built inside carries
+    `concurrent = 1` (distr_render_cfg.concurrent: the march tails of those renders do not go sticky, they share the chip)."""
+
+    def __enter__(self):
+        _concurrent.depth = getattr(_concurrent, 'depth', 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _concurrent.depth -= 1
+        return False
+
+
 def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
              marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
              use_depth2normal=False, normalize_normal=True, want_normal=True,
@@ -216,6 +238,7 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
         cfg.row0, cfg.rows = int(band[0]), int(band[1])
     if arith not in ARITH:
         raise ValueError("arith must be one of %s" % sorted(ARITH))
+    cfg.concurrent = 1 if concurrent_renders() else 0      # inside a stream pool (concurrent_section): no sticky tail launches
     cfg.arith = ARITH[arith]     # 'f32': exact (default); 'bf16x6' / 'f16x3': split-bf16 / split-f16 march tiles (DISTR_ARITH_*)
     return cfg
 

@@ -124,6 +124,11 @@ typedef struct distr_render_cfg {
                                  backward pass is the split-bf16 dX chain on the ReLU masks this forward saved. 2: three f16 products per f32
                                  product with the activations kept as two f16 planes in LDS (csrc/distr_mlp_h3.hpp): same accuracy class and
                                  tile set as 1 for decoders inside the f16 range (see DISTR_ARITH_F16X3), backward = that of mode 1. */
+  int32_t concurrent;         /* hint, 0 by default: 1 = the caller has OTHER renders in flight on other streams of this device (a pool of
+                                 streams over the scales of a multi-scale renderer list or the view pairs of a round). The tail of the march
+                                 then does not turn "sticky": a sticky launch keeps up to 248 compute units to itself for milliseconds, which
+                                 is the fastest way to finish ONE small render and the slowest way to share the chip. Values never depend on
+                                 it (tests/gpu_diag_multiscale.py: three scales on three streams 23.8 -> 20.6 ms per iteration). */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */

@@ -1760,6 +1760,12 @@ def test_multiscale_shape_loop_matches_reference_golden(fixture_decoder):
         optimize_single_view(rs, None, o, l_, RT, gt_pack, wd, optimizer_type='shape', num_iters=1, renderer_weights=[1.0, 1.0, 1.0], silent=True)
         return rr.grads[0]
     _check_loop_against_golden(rec, lat.detach().cpu().numpy(), g, 'G20 multi-scale shape loop', float(g['lr']), grad_at)
+    # the loop above ran the three scales on a pool of HIP streams (streams=None: one per renderer, distr_render_cfg.concurrent set);
+    # the reference's sequential order must give the same shape code bit for bit
+    lat2 = torch.from_numpy(g['latent0']).cuda().requires_grad_(True)
+    opt2 = torch.optim.Adam([lat2], lr=float(g['lr']))
+    optimize_single_view(rs, None, opt2, lat2, RT, gt_pack, wd, optimizer_type='shape', num_iters=int(g['iters']), renderer_weights=[1.0, 1.0, 1.0], silent=True, streams=0)
+    assert torch.equal(lat2.detach(), lat.detach())
 
 
 @pytest.mark.gpu
