@@ -26,8 +26,11 @@ class SDFRenderer_warp(SDFRenderer):
                     thres_depth=0.001):
         h, w = self.img_hw
         dev = self.calib_map.device
-        Z1, m1, q1 = self.render_depth(latent, R1, T1, clamp_dist=clamp_dist, profile=profile)
-        Z2, m2, q2 = self.render_depth(latent, R2, T2, clamp_dist=clamp_dist, profile=profile, no_grad_depth=True)
+        # the two depth renders of the pair (renderer_warp.py:108-109: view 2 with no_grad_depth) as ONE batched launch sequence: every
+        # march step covers the live rays of both views, their latency-bound tails overlap; each view is byte-identical to its own
+        # render_depth call (tests/test_gpu_batch.py)
+        Z, M, Q = self.render_depth_batch(latent, [R1, R2], [T1, T2], clamp_dist=clamp_dist, no_grad_depth=[False, True])
+        Z1, m1, q1, Z2, m2, q2 = Z[0], M[0], Q[0], Z[1], M[1], Q[1]
         # warp + consistency test + L1 colour, forward and backward, fused (row f2): distr_warp_loss_forward/_backward.
         # Gradients reach the latent through Zdepth of view 1 and the cameras directly.
         wcfg = binding.make_warp_cfg((h, w), self.intrinsic, thres_depth)
