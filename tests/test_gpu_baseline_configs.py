@@ -460,6 +460,12 @@ def test_bench_rccl_multi_gpu():
     for j in outs:
         assert j['config']['rccl']['backend'] == 'nccl' and j['config']['rccl']['world_size'] == 2, j['config']['rccl']
     assert abs(plain['value'] - 2 * 512 * 512 / (plain['ms_per_step'] * 1e-3)) <= 1e-6 * plain['value']
-    plan = bal['config']['balance_plan']
+    plan = bal['config']['balance_plan'] or bal['config'].get('balance_plan_tried')   # (used, or tried and found slower than whole views)
     assert plan is not None and plan[1][0][2] < 512, plan              # view 7 (rank 1) hands rows to rank 0
-    assert bal['ms_per_step'] <= 1.02 * plain['ms_per_step']           # and the step is not slower than with whole views
+    assert bal['ms_per_step'] <= 1.02 * plain['ms_per_step']           # `value` is the better of the two timed modes
+    for j in outs:                                                     # the self-validation of an N > 1 run, on real RCCL
+        c = j['config']
+        assert c['serial_check']['ok'] is True and c['scaling_measurement'] is True and c['rccl']['one_gpu_per_rank'] is True, c
+        assert len({r['device_index'] for r in c['rccl']['ranks']}) == 2
+    cb = bal['config']
+    assert cb['unbalanced_ms_per_step'] > 0 and cb['balanced_ms_per_step'] > 0 and cb['value_is'] in ('balanced', 'unbalanced')
