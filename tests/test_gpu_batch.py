@@ -322,3 +322,50 @@ def test_renderer_takes_its_default_arithmetic_from_the_environment(fixture_deco
     monkeypatch.setenv('DISTR_ARITH', 'fp8')
     with pytest.raises(ValueError, match='DISTR_ARITH'):
         SDFRenderer(dec, K, img_hw=(size, size))
+
+
+def test_render_depth_batch_mixed_no_grad_flags_equal_per_view_calls(fixture_decoder):
+    """SDFRenderer.render_depth_batch with DIFFERENT no_grad_* options per view -- including one view with no_grad_mask AND
+    no_grad_camera, whose min_sdf row render_depth detaches (renderer.py:388-389 + 863) -- must give, for a loss over all outputs of all
+    views, exactly the gradients of the per-view render_depth calls with the same options (the batch used to leak that view's min-sdf
+    gradient of the rays that miss the sphere into g_R / g_T)."""
+    import torch
+    from core.sdfrenderer import SDFRenderer
+    from core.graph.deep_sdf_decoder import Decoder
+    from distr import fixture
+    Ws, bs, latent = fixture_decoder
+    dec = Decoder(256, [512] * 8, norm_layers=(), latent_in=[4])
+    dec.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (W_, b) in enumerate(zip(Ws, bs)) for n, a in (('weight', W_), ('bias', b))})
+    dec = dec.cuda()
+    H = W = 40
+    K = fixture.make_intrinsic(H, W)
+    r = SDFRenderer(dec, K, img_hw=(H, W), march_step=24, buffer_size=2)
+    cams = [fixture.make_camera(20.0 * i, 10.0, 2.6 if i == 1 else 1.6, 0.0) for i in range(4)]      # view 1 is far: most of its rays miss the sphere
+    ngd, ngm, ngc = [False, False, True, False], [False, True, False, True], [False, True, False, False]
+    rs = np.random.RandomState(3)
+    wz, wq = (torch.from_numpy(rs.rand(4, H * W).astype(np.float32)).cuda() for _ in range(2))
+
+    def leaves():
+        lat = torch.from_numpy(latent).cuda().requires_grad_(True)
+        Rs = [torch.from_numpy(c[0]).cuda().requires_grad_(True) for c in cams]
+        Ts = [torch.from_numpy(c[1]).cuda().requires_grad_(True) for c in cams]
+        return lat, Rs, Ts
+    lat, Rs, Ts = leaves()
+    Z, M, Q = r.render_depth_batch(lat, Rs, Ts, no_grad_depth=ngd, no_grad_mask=ngm, no_grad_camera=ngc)
+    (torch.where(M, Z * wz, torch.zeros_like(Z)).sum() + (Q * wq).sum()).backward()
+    lat2, Rs2, Ts2 = leaves()
+    total = 0
+    for v in range(4):
+        z, m, q = r.render_depth(lat2, Rs2[v], Ts2[v], no_grad_depth=ngd[v], no_grad_mask=ngm[v], no_grad_camera=ngc[v])
+        assert torch.equal(z.detach(), Z[v].detach()) and torch.equal(m, M[v]) and torch.equal(q.detach(), Q[v].detach())
+        total = total + torch.where(m, z * wz[v], torch.zeros_like(z)).sum() + (q * wq[v]).sum()
+    total.backward()
+    assert int((~(Z[1] < 1e10)).sum()) > 100                                    # view 1 has rays that miss the sphere
+    for v in range(4):
+        for a, b, nm in ((Rs[v].grad, Rs2[v].grad, 'R'), (Ts[v].grad, Ts2[v].grad, 'T')):
+            if b is None:
+                assert a is None or float(a.abs().max()) == 0.0, (v, nm)
+            else:
+                assert torch.equal(a, b), (v, nm, (a - b).abs().max())
+    assert Rs2[1].grad is None or float(Rs2[1].grad.abs().max()) == 0.0           # both flags set: nothing reaches view 1's camera
+    assert (lat.grad - lat2.grad).abs().max() <= 2e-6 * lat2.grad.abs().max()      # (a shared code: the sum over views, order differs)
