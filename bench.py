@@ -14,6 +14,17 @@ Inputs are resident in HBM before the timed region. Views shard over ranks (view
 4 shapes (latent seeds 1234..1237) x one 1024x1024 view x 100 march steps, a FIXED total amount of work split over the
 ranks shape-major then into row bands (distr.parallel.shard_rows, distr.functions.render_band_call); "scaling": "strong".
 
+N > 1 (one rank per GPU over RCCL; nothing of this runs at N = 1, whose line is unchanged): the run validates itself.
+  * two timed regions with the same protocol (W warm-up + exactly K steps between barrier + synchronize): first UNBALANCED (one whole
+    view per GPU), then -- after five untimed calibration steps -- BALANCED (slow views hand row bands to fast ranks); `value` is the
+    better one, config.unbalanced_ms_per_step / balanced_ms_per_step / value_is report both;
+  * config.serial_check: rank 0 renders all N views itself and the all-reduced loss / latent gradients of both regions must equal
+    that serial sum (1e-5 / 1e-4 relative) -- `ok: false` and a non-zero exit otherwise;
+  * config.rccl: backend (anything but RCCL is refused unless DISTR_DIST_BACKEND overrides it for one-GPU test rigs, which the line
+    then flags with scaling_measurement: false), world size, RCCL version, and rank / device / PCI bus id / pid of every rank;
+  * config.per_rank: every rank's own GPU milliseconds per step and its all-reduce + wait, per timed mode;
+  * the opt-in arithmetic passes and the CPU baselines are skipped.
+
 Extra objects on the JSON line:
   roofline     the dominant kernel (fused march/MLP kernel k_march): algorithmic FLOP (3 146 752 per decoder
                evaluation, latent hoisted) / summed hipEvent kernel time on the launch stream, vs the 157.3 TFLOP/s
