@@ -34,8 +34,13 @@ class SDFRenderer_color(SDFRenderer):
         if idx.numel() == 0:
             return color.reshape(h, w, 3)
         points = self.generate_point_samples(cam_pos, cam_rays[:, idx], Zdepth.reshape(-1)[idx], has_zdepth_grad=False)
-        with torch.no_grad():
-            rgb = functions.color_eval(self._color_engine, latent_color, latent, points.t())
+        if no_grad or not torch.is_grad_enabled():
+            with torch.no_grad():
+                rgb = functions.color_eval(self._color_engine, latent_color, latent, points.t())
+        else:
+            # renderer_rgb.py:32-36: without no_grad the colours stay on the tape -- gradients to the colour code, the shape code and, through
+            # the surface points (Zdepth detached: has_zdepth_grad=False), to the camera (distr_color_backward; golden G26)
+            rgb = functions.color_eval_autograd(self._color_engine, latent_color, latent, points.t().contiguous())
         return color.index_copy(0, idx, rgb).reshape(h, w, 3)
 
     # reference: renderer_rgb.py:39
@@ -61,7 +66,9 @@ class SDFRenderer_color(SDFRenderer):
         cfg.use_depth2normal = 0
         zdepth, mask, min_sdf, depth, normal = functions.render_call(self._engine, cfg, latent, R, T)
         if no_grad:
-            depth, normal, min_sdf = depth.detach(), normal.detach(), min_sdf.detach()
+            # (the normals are detached inside render_normal, before `R @ normal` (renderer_rgb.py:93-94): their gradient w.r.t. R stays,
+            # exactly as in SDFRenderer.render -- golden G18)
+            depth, min_sdf = depth.detach(), min_sdf.detach()
         valid = mask.bool()
         color = self.render_color(latent_color, latent, self.get_camera_location(R, T), self.get_camera_rays(R), zdepth.detach(),
                                   valid, no_grad=no_grad)

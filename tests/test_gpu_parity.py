@@ -1854,3 +1854,55 @@ def test_edge_cases_match_reference_golden(engine):
         res = tg.check_g25(a, g, key, H, W)
         assert abs(a['loss'] - float(g[key + '.loss'])) <= 5e-5 * abs(float(g[key + '.loss'])), key
         print('G25', key, 'valid', int(a['mask'].sum()), {k: '%.1e' % v for k, v in res.items()})
+
+
+@pytest.mark.gpu
+def test_color_render_gradients_match_reference_golden(fixture_decoder):
+    """G26: SDFRenderer_color.render WITHOUT no_grad (its default, renderer_rgb.py:73-125): the colour image stays on the tape -- through
+    decode_color to the colour code and the shape code, through the surface points to the camera. Loss over depth, normal, colour and
+    min-sdf; gradients w.r.t. colour code, shape code, R, T against the reference's, plain and with a point light (bar: 1e-3 relative or
+    2 x the reference's own noise floor)."""
+    import torch
+    from core.sdfrenderer import SDFRenderer_color
+    from core.graph.deep_sdf_decoder import Decoder
+    from distr import fixture
+    g = dict(np.load(os.path.join(GOLDEN, 'g26_color_render_grad.npz')))
+    Ws, bs, _ = fixture_decoder
+    cs = int(g['color_size'])
+    Wc, bc, code = fixture.make_color_decoder_weights(color_size=cs)
+    assert np.array_equal(code, g['color_code'])
+
+    def module(W_, b_, latent, dims, last):
+        d = Decoder(latent, dims, last_dim=last, norm_layers=(), latent_in=[4])
+        d.load_state_dict({('lin%d.%s' % (l, n)): torch.from_numpy(a) for l, (Wl, bl) in enumerate(zip(W_, b_)) for n, a in (('weight', Wl), ('bias', bl))})
+        return d.cuda()
+    dims_c = [512] * 8
+    dims_c[3] += cs
+    dec, dec_c = module(Ws, bs, 256, [512] * 8, 1), module(Wc, bc, 256 + cs, dims_c, 3)
+    H, W = int(g['H']), int(g['W'])
+    r = SDFRenderer_color(dec, dec_c, g['K'], img_hw=(H, W), march_step=int(g['march_step']), buffer_size=int(g['buffer_size']))
+    c = lambda k: torch.from_numpy(g[k]).cuda()
+    for tag in ('plain', 'lit'):
+        lat, cc = c('latent').requires_grad_(True), c('color_code').requires_grad_(True)
+        Rt, Tt = c('R').requires_grad_(True), c('T').requires_grad_(True)
+        kw = {} if tag == 'plain' else dict(lighting_locations=c('lights'), lighting_energies=c('energies'))
+        d, n, col, m, q = r.render(cc, lat, Rt, Tt, **kw)
+        mb = m.bool()
+        assert int((m.cpu().numpy() != g[tag + '.mask']).sum()) <= 1
+        both = mb.cpu().numpy() & g[tag + '.mask'].astype(bool)
+        assert np.percentile(np.abs(col.detach().cpu().numpy() - g[tag + '.color'])[both], 99) <= 1e-4
+        L = (d * c('w_d'))[mb].sum() + (n * c('w_n')).sum() + (col * c('w_c')).sum() + (q * c('w_q')).sum()
+        L.backward()
+        assert abs(float(L.detach()) - float(g[tag + '.loss'])) <= 5e-5 * abs(float(g[tag + '.loss']))
+        res = {}
+        for k, t in (('g_color_code', cc), ('g_latent', lat), ('g_R', Rt), ('g_T', Tt)):
+            ref = g['%s.%s' % (tag, k)]
+            res[k] = float(np.abs(t.grad.cpu().numpy().reshape(-1) - ref.reshape(-1)).max() / np.abs(ref).max())
+            assert res[k] <= max(1e-3, 2.0 * float(g['%s.%s_floor_rel' % (tag, k)])), (tag, k, res[k])
+        print('G26', tag, {k: '%.1e' % v for k, v in res.items()})
+    # no_grad=True: nothing but the explicit `R @ normal` term is left (renderer_rgb.py:93-94: the normals are detached before it)
+    lat, cc, Rt = c('latent').requires_grad_(True), c('color_code').requires_grad_(True), c('R').requires_grad_(True)
+    d, n, col, m, q = r.render(cc, lat, Rt, c('T'), no_grad=True)
+    assert not col.requires_grad and not d.requires_grad and not q.requires_grad and n.requires_grad
+    n.sum().backward()
+    assert (lat.grad is None or float(lat.grad.abs().max()) == 0.0) and cc.grad is None and float(Rt.grad.abs().max()) > 0
