@@ -38,6 +38,7 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -54,6 +55,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FLOP_PER_EVAL = 3146752          # 1 573 376 MAC per point with the latent columns hoisted
+BALANCE_MARGIN = 0.02            # N > 1: the balanced timing becomes `value` only when it beats the unbalanced one by more than this
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 H = W = 512
@@ -96,11 +98,11 @@ def collective_info(world, local):
         info['backend_is_rccl'] = info['backend'] == 'nccl'       # torch's "nccl" backend IS RCCL on ROCm
         props = torch.cuda.get_device_properties(local)
         mine = {'rank': dist.get_rank(), 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device_index': int(local),
-                'device_name': props.name, 'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid()}
+                'device_name': props.name, 'pci_bus_id': getattr(props, 'pci_bus_id', None), 'pid': os.getpid(), 'host': platform.node()}
         ranks = [None] * info['world_size']
         dist.all_gather_object(ranks, mine)
         info['ranks'] = ranks
-        info['distinct_devices'] = len({(r['device_index'], r['pci_bus_id']) for r in ranks})
+        info['distinct_devices'] = len({(r.get('host'), r['device_index'], r['pci_bus_id']) for r in ranks})    # (host: one GPU per rank on several nodes)
         # a scaling measurement needs RCCL and one GPU per rank; test rigs that time-share one GPU (DISTR_DIST_BACKEND=gloo) say so here
         info['one_gpu_per_rank'] = bool(info['backend_is_rccl'] and info['distinct_devices'] == info['world_size'])
     try:
@@ -448,7 +450,9 @@ def main():
             timing['balanced'] = el_b
             snaps['balanced'] = snap_b
             diag['balanced'] = rank_diagnostics()
-            if el_b < elapsed or fake:                               # (forced times: the tests want to see the plan's run)
+            # `value` switches to the balanced region only when it wins by more than the run-to-run noise (2 %): a plain best-of-two
+            # would bias the headline upward by that noise
+            if el_b < (1.0 - BALANCE_MARGIN) * elapsed or fake:      # (forced times: the tests want to see the plan's run)
                 elapsed, snaps['chosen'] = el_b, snap_b
             else:
                 plan_tried, plan = plan, None                        # the balancer did not pay on this node: report it, run unbalanced
@@ -589,9 +593,16 @@ def main():
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))   # newest round's PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
     tpath = cands[-1] if cands else os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+    traffic_digest, traffic_stale = None, None
+    from distr import binding as _binding
+    built_from = _binding.source_digest()
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath))['bytes_per_launch']
+            tj = json.load(open(tpath))
+            traffic_digest = tj.get('csrc_sha256')
+            # the PMC pass describes the kernels it ran: if csrc/ has changed since, the number is not this library's
+            traffic_stale = traffic_digest != built_from
+            traffic = None if traffic_stale else tj['bytes_per_launch']
         except Exception:
             traffic = None
     rccl_info = collective_info(world, local)           # (collective: every rank takes part in the all-gather)
@@ -614,7 +625,8 @@ def main():
                                                          ('fixed total work split shape-major then in row bands' + (', whole images of a rank as one batched launch sequence' if not args.no_batch else '')) if c5 else
                                                          ('N views per step on N GPUs (C4 camera circle): one view per GPU, slow views hand row bands to fast '
                                                           'ranks' if plan else '1 view per GPU')),
-                       'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') + ' (RCCL all-reduce of packed latent grad)',
+                       'parallelism': ('shape/row-band-parallel x%d' if c5 else 'view-parallel x%d') % args.gpus + (' with row-band load balancing' if plan else '') +
+                                      ((' (%s all-reduce of packed latent grad)' % ('RCCL' if rccl_info.get('backend') == 'nccl' else str(rccl_info.get('backend')) + ' [NOT RCCL: test rig]')) if world > 1 else ' (single process, no collective)'),
                        'rccl': rccl_info,
                        'rank0_items': [list(it) for it in items], 'balance_plan': plan, 'calibration_steps_before_warmup': calibration_steps, 'loss_sum_all_ranks': float(loss_buf.item()),
                        'latent_grad_norm_all_ranks': grad_norm,
@@ -627,7 +639,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0, 'unit': 'TFLOP/s',
                          'frac': achieved / (PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0), 'traffic': traffic,
                          'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16 / f16 MFMA dense peak; algorithmic FLOP counted once (the six bf16 / three f16 products per f32 product are not counted several times)',
-                         'traffic_note': 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
+                         'traffic_csrc_sha256': traffic_digest, 'csrc_sha256': built_from,
+                         'traffic_note': ('null: the committed PMC pass (%s) was taken on other kernels (csrc digest differs); re-run profiles/promote.sh' % os.path.relpath(tpath, ROOT)) if traffic_stale else 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
                          'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
                                    % (ROOF_STEPS, launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
@@ -653,6 +666,10 @@ def main():
                 c['unbalanced_ms_per_step'] = 1e3 * timing['unbalanced'] / args.steps
                 c['balanced_ms_per_step'] = (1e3 * timing['balanced'] / args.steps) if timing['balanced'] is not None else None
                 c['value_is'] = 'balanced' if plan else 'unbalanced'
+                c['value_switch_margin'] = BALANCE_MARGIN
+            # which of the timed modes is the N = 1 protocol run on N GPUs (one whole view per GPU, nothing moved between ranks): efficiency
+            # against the N = 1 line compares like with like only through this mode's number
+            c['n1_protocol_equivalent'] = 'unbalanced' if not c5 else 'row_bands (strong scaling: no N = 1 analogue per rank; compare total ms_per_step)'
                 if timing.get('balance_plan_tried'):
                     c['balance_plan_tried'] = timing['balance_plan_tried']
         if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)

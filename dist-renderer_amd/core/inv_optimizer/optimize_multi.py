@@ -169,4 +169,6 @@ def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images
                     evaluator.latent_vec_to_points(shape_code, num_points=num_sample_points, fname=os.path.join(vis_dir, 'mesh_best.ply'), silent=True)
                 print('CHAMFER DISTANCE: {0:.3f} & {1:.3f} at epoch {2}'.format(dist1 * 1000, dist2 * 1000, epoch))
                 print('BEST SUM CHAMFER DISTANCE: {0:.3f} at epoch {1}'.format(best_chamfer, best_epoch))
+    if world > 1:
+        parallel.check_pending_errors()      # the last step's (deferred) error flag
     return shape_code, shape_optimizer

@@ -58,8 +58,8 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
     if (visualize or (points_gt is not None and not silent)) and vis_folder is not None and not os.path.exists(vis_folder):
         os.mkdir(vis_folder)
     nstreams = (len(sdfrenderer_list) if len(sdfrenderer_list) > 1 else 0) if streams is None else int(streams)
-    if visualizer is not None or not shape_code.is_cuda:
-        nstreams = 0
+    if visualizer is not None or not shape_code.is_cuda or profile:
+        nstreams = 0             # (profile: launch counters and timing events are per context, not per stream -- one scale at a time)
     pool = _StreamPool(nstreams, shape_code.device) if nstreams > 0 else None
     for i in _progress(num_iters, silent):
         optimizer.zero_grad()
@@ -131,4 +131,6 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
                 visualizer.add_chamfer(dist)
         if visualize:
             visualizer.dump_all_data(os.path.join(vis_folder, 'vis_all_data_{}.pkl'.format(i)))
+    if world > 1:
+        parallel.check_pending_errors()      # the last step's (deferred) error flag: a failure on another rank must not end silently
     return (shape_code if optimizer_type == 'shape' else camera_tensor), optimizer

@@ -191,8 +191,12 @@ class SDFRenderer(object):
         view: optimize_multi.py:62-81): Rs (B,3,3) / Ts (B,3) or sequences of per-view tensors, latent (1,L) shared by the views or
         (B,L); no_grad_* = None or one bool per view. Returns (Zdepth (B,P), valid_mask (B,P) bool, min_sdf_sample (B,P)); row v is
         bit-identical to render_depth(latent, Rs[v], Ts[v], no_grad_*=...[v]) and so are the gradients."""
-        Rs = torch.stack(list(Rs)) if not torch.is_tensor(Rs) else Rs
-        Ts = torch.stack(list(Ts)) if not torch.is_tensor(Ts) else Ts
+        # sequences of per-view tensors may live on different devices / in different float types (a host-resident f64 camera for one
+        # view): each is brought to the renderer's device in f32 before stacking, differentiably, like a stand-alone render_depth does
+        dev = self.calib_map.device
+        to_dev = lambda t: t.to(device=dev, dtype=torch.float32)
+        Rs = torch.stack([to_dev(r) for r in Rs]) if not torch.is_tensor(Rs) else Rs
+        Ts = torch.stack([to_dev(t) for t in Ts]) if not torch.is_tensor(Ts) else Ts
         B = Rs.shape[0]
         ngd = [bool(x) for x in (no_grad_depth if no_grad_depth is not None else [False] * B)]
         ngm = [bool(x) for x in (no_grad_mask if no_grad_mask is not None else [False] * B)]
@@ -217,8 +221,10 @@ class SDFRenderer(object):
 
     def render_normal_batch(self, latent, Rs, Ts, Zdepth, valid_mask, clamp_dist=0.1, normalize=True, use_transform=True):
         """render_normal (renderer.py:880) of B views in one launch sequence -> (B,3,P)."""
-        Rs = torch.stack(list(Rs)) if not torch.is_tensor(Rs) else Rs
-        Ts = torch.stack(list(Ts)) if not torch.is_tensor(Ts) else Ts
+        dev = self.calib_map.device
+        to_dev = lambda t: t.to(device=dev, dtype=torch.float32)      # (per view, like render_depth_batch)
+        Rs = torch.stack([to_dev(r) for r in Rs]) if not torch.is_tensor(Rs) else Rs
+        Ts = torch.stack([to_dev(t) for t in Ts]) if not torch.is_tensor(Ts) else Ts
         cfg = self._cfg(clamp_dist, 'recursive', use_transform, want_normal=True, normalize_normal=normalize)
         cfg.use_depth2normal = 0
         cfg.save_for_backward = 0          # gradient-free pass: no ReLU-mask store in the workspace (512 B x P x (buffer_size + 1) per view)
@@ -259,7 +265,9 @@ class SDFRenderer(object):
         # (:978) -- the explicit gradient of that product w.r.t. R survives the flag (golden G18: g_R is the same with and without it).
         # The autograd normal of this build carries exactly that term and nothing else (the terms through the decoder are identically
         # ~0 for a ReLU decoder after normalisation), so the flag has nothing left to remove here. (Round 3 detached the
-        # whole image, which also dropped the R term: found by G18.)
+        # whole image, which also dropped the R term: found by G18.) With normalize_normal=False the decoder-path terms are not
+        # identically zero in the reference, but this build omits them BY DESIGN for both settings (the autograd normal is a
+        # gradient-free pass, render_normal: save_for_backward = 0), so the flag is a no-op there too.
         if no_grad_mask and no_grad_camera:
             min_sdf = min_sdf.detach()
         if num_forward_sampling != 0:

@@ -4,7 +4,8 @@ core/sdfrenderer/renderer_rgb.py:12-125). Same constructor / `
 Depth, mask, min-sdf sample and normals come from one fused `distr_render_forward` (the 'recursive' marcher that
 `render_depth` defaults to, autograd-style normals); the colour decoder runs on the fused decoder tile too
 (`distr_color_eval`: latent = [shape code | colour code] folded into per-call constants, lin8 with three rows). The
-colour path is forward-only, as in the reference's only user (demo/demo_360.py)."""
+colour image is differentiable like the reference's (golden G26): `render_color` / `render` without `no_grad` keep the colour
+code, the shape code and -- through the surface points -- the camera on the tape (ColorDecodeFunction -> distr_color_backward)."""
 import torch
 
 from distr import functions

@@ -24,6 +24,9 @@ class SDFRenderer_warp(SDFRenderer):
     # reference: renderer_warp.py:103
     def render_warp(self, latent, R1, T1, R2, T2, img1, img2, clamp_dist=0.1, profile=False, no_grad_normal=False,
                     thres_depth=0.001):
+        # (`profile` is accepted for signature compatibility and ignored: the reference prints host-side timers around its two
+        # render_depth calls, renderer_warp.py:105-110; the batched launch sequence has no per-view boundary to time. self._last is
+        # not updated on this path either -- use render_depth(profile=True) to time one view.)
         h, w = self.img_hw
         dev = self.calib_map.device
         # the two depth renders of the pair (renderer_warp.py:108-109: view 2 with no_grad_depth) as ONE batched launch sequence: every

@@ -97,9 +97,24 @@ class RenderStats(_Sized):
                 ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64), ('f16_overflows', C.c_int64)]
 
 
+SOURCES = ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_mlp_h3.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')
+
+
+def source_digest():
+    """sha256 over the native sources libdistr.so is built from (csrc/ + include/distr.h, fixed order, name + bytes). Evidence files
+    that describe the kernels (profiles/rNN_traffic.json) record it; bench.py only quotes them for the same digest."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, f) for f in SOURCES] + [os.path.join(_HERE, '..', '..', 'include', 'distr.h')]:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=False):
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
-    srcs = [os.path.join(CSRC, f) for f in ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_mlp_h3.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')]
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH

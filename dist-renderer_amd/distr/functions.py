@@ -180,11 +180,14 @@ F16_CHECK_EVERY = 256          # renders between two range checks of the split-f
                                # every decoder upload is always checked)
 
 
-def _check_f16_range(engine, cfg, ws, nviews=1, view_bytes=0):
+def _check_f16_range(engine, cfg, ws, nviews=1, view_bytes=0, needs_grad=False):
     """arith = 'f16x3' only. A decoder activation that leaves the f16 range makes the march see a NaN sdf, which fails both `stay`
     comparisons and silently ends the ray -- a driver would optimise on corrupted renders. The march kernel counts such evaluations
-    (distr_render_stats.f16_overflows); reading the counter costs a device sync, so it is read on the first render after every
-    decoder upload and then every F16_CHECK_EVERY renders, and anything but zero RAISES (use arith='bf16x6' or 'f32' for this decoder)."""
+    (distr_render_stats.f16_overflows); reading the counter costs a device sync, so for gradient-free renders it is read on the
+    first render after every decoder upload and then every F16_CHECK_EVERY renders. A render that will be back-propagated
+    (`needs_grad`: an optimisation loop moving the shape code, where overflow depends on the current latent) is checked EVERY time:
+    a backward taken on NaN-terminated rays is the failure that must not pass silently. Anything but zero RAISES (use
+    arith='bf16x6' or 'f32' for this decoder). Residual window: up to F16_CHECK_EVERY - 1 consecutive gradient-free renders."""
     if cfg.arith != binding.ARITH['f16x3']:
         return
     import os
@@ -195,7 +198,7 @@ def _check_f16_range(engine, cfg, ws, nviews=1, view_bytes=0):
     if first:
         st['gen'], st['n'] = gen, 0
     st['n'] += 1
-    if not (first or (every > 0 and st['n'] % every == 0)):
+    if not (first or needs_grad or (every > 0 and st['n'] % every == 0)):
         return
     bad = 0
     for v in range(nviews):
@@ -232,7 +235,7 @@ class RenderFunction(torch.autograd.Function):
             engine.ctx.h, C.byref(cfg), p(lat), p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None,
             p(ws), ws.numel(), engine.ctx.stream()))
-        _check_f16_range(engine, cfg, ws)
+        _check_f16_range(engine, cfg, ws, needs_grad=any(ctx.needs_input_grad[:3]))
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes = engine, cfg, ws, bwd_bytes
         ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)
@@ -308,7 +311,7 @@ class RenderBatchFunction(torch.autograd.Function):
         engine.ctx.check(engine.ctx.L.distr_render_forward_batch(
             engine.ctx.h, C.byref(cfg), B, flags, p(lat), 0 if shared else 256, p(Rc), p(Tc), p(zdepth), p(mask), p(min_sdf),
             p(depth) if cfg.want_normal else None, p(normal) if cfg.want_normal else None, p(ws), ws.numel(), engine.ctx.stream()))
-        _check_f16_range(engine, cfg, ws, B, fwd_bytes)
+        _check_f16_range(engine, cfg, ws, B, fwd_bytes, needs_grad=any(ctx.needs_input_grad[:3]))
         ctx.engine, ctx.cfg, ctx.ws, ctx.bwd_bytes, ctx.B, ctx.shared = engine, cfg, ws, bwd_bytes, B, shared
         ctx.generation = getattr(engine, 'generation', 0)
         ctx.shapes = (latent.shape, R.shape, T.shape)

@@ -25,9 +25,14 @@ def init_from_env(backend=None):
             backend = os.environ.get('DISTR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        kw = {}
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == 'nccl':
+                # bind the communicator to THIS rank's GPU at creation: RCCL then initialises eagerly on that device and
+                # barrier() / the first collective do not have to guess it from "the device under the current context"
+                kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -77,7 +82,26 @@ def _reduction_device(group, params):
     return params[0].device if params else torch.device('cpu')
 
 
-def allreduce_grads(params, scalars=(), group=None, error=None):
+_pending_flags = {}          # group -> (host copy of a step's error flag, event after the copy): read before the NEXT collective
+
+
+def check_pending_errors(group=None):
+    """Reads the error flag of the previous allreduce_grads of `group`, if that call deferred it (device buffers: the flag is copied
+    to pinned host memory behind the all-reduce and read here, i.e. before the next collective or at the end of the loop, when the
+    copy has long completed -- the optimisation loop never stops to wait for its own all-reduce). Raises RemoteRankError if another
+    rank reported a failure in that step; every rank raises it at the same point, before entering another collective."""
+    item = _pending_flags.pop(group, None)
+    if item is None:
+        return
+    host, event = item
+    if event is not None:
+        event.synchronize()
+    n = float(host[0])
+    if n > 0.0:
+        raise RemoteRankError('%d rank(s) failed inside the previous step; leaving the loop on every rank' % int(round(n)))
+
+
+def allreduce_grads(params, scalars=(), group=None, error=None, lazy=None):
     """The one collective of an optimisation step: the gradients of `params` (shape code, sim(3) parameters, camera
     tensor ...) and the detached loss `scalars` are packed into ONE flat buffer [g_latent | g_sim3 / g_cam | loss ... | error flag]
     and summed over the ranks with a single all-reduce (RCCL on GPUs, gloo on CPU); every rank then holds identical gradients and
@@ -87,12 +111,16 @@ def allreduce_grads(params, scalars=(), group=None, error=None):
     collective and copied back in its own device / dtype (the buffer is f64 as soon as one piece is, so f64 gradients are not rounded
     through f32). `error`: an exception this rank caught while computing its share of the step (or None). The flag travels in the
     same buffer, so a failure on one rank does not leave the others waiting in a collective: the failing rank re-raises its own
-    exception after the all-reduce, every other rank raises RemoteRankError. Returns the reduced scalars as 0-d tensors."""
+    exception after the all-reduce, every other rank raises RemoteRankError. Returns the reduced scalars as 0-d tensors.
+    `lazy` (default: on for device buffers): the flag of THIS step is not read here (a device -> host sync in every optimiser
+    step) but by check_pending_errors() at the start of the next call / the end of the loop: the failing rank still raises at
+    once (it knows), the others one step later and before they enter another collective, so nobody is left waiting either."""
     params = [p for p in params if p is not None]
     if not is_distributed(group):
         if error is not None:
             raise error
         return [s.detach() if torch.is_tensor(s) else torch.tensor(float(s)) for s in scalars]
+    check_pending_errors(group)                     # a failure another rank reported in the previous step: leave before the collective
     dev = _reduction_device(group, params)
     grads = [p.grad if p.grad is not None else None for p in params]
     wide = any((g if g is not None else p).dtype == torch.float64 for g, p in zip(grads, params)) or \
@@ -110,10 +138,20 @@ def allreduce_grads(params, scalars=(), group=None, error=None):
     pieces.append(torch.tensor([0.0 if error is None else 1.0], dtype=dt, device=dev))
     flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    failed = float(flat[-1]) > 0.0
     if error is not None:
         raise error
-    if failed:
+    if lazy is None:
+        lazy = flat.is_cuda
+    if lazy:
+        if flat.is_cuda:
+            host = torch.empty(1, dtype=flat.dtype, pin_memory=True)
+            host.copy_(flat[-1:], non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            host, event = flat[-1:].clone(), None
+        _pending_flags[group] = (host, event)
+    elif float(flat[-1]) > 0.0:
         raise RemoteRankError('%d rank(s) failed inside this step; leaving the step on every rank' % int(round(float(flat[-1]))))
     off = 0
     for p in params:

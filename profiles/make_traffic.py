@@ -3,8 +3,12 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts 64 B per 128-B request for 16 B/lane streaming loads, hence the x2 on FETCH_SIZE
 (MI355X_MICROARCH.md, HBM section). A 'launch' = one march launch of bench.py's roofline (k_step or coarse k_march)."""
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'dist-renderer_amd'))
 
 
 def rows(path):
@@ -34,6 +38,9 @@ def main():
         'fetch_correction': 'x2: gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming loads (MI355X_MICROARCH.md, HBM '
                             'section); the weight fragments are buffer_load_dwordx4',
         'bytes_per_launch': int(round((2.0 * fetch + write) * 1024.0 / n)),
+        # the sources the profiled libdistr.so was built from (distr.binding.source_digest): bench.py quotes bytes_per_launch only while
+        # csrc/ still has this digest -- run this script in the same tree state as the PMC passes
+        'csrc_sha256': __import__('distr.binding', fromlist=['source_digest']).source_digest(),
         'mfma_busy': {'k_step': round(busy('k_step'), 3), 'k_march_coarse': round(busy('k_march'), 3),
                       'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), profiles/%s_pmc_mfma.md; k_step covers all 44 '
                              'full-resolution steps of a forward including the latency-bound tail' % name},

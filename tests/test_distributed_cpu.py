@@ -246,7 +246,33 @@ def _error_worker(rank, world, port, q):
     except parallel.RemoteRankError:
         kind = 'remote'
     parallel.barrier()                       # the group is still usable afterwards
-    q.put((rank, ok, kind))
+    # (3) the deferred flag (what device buffers use: no device -> host sync inside the step). Step A: rank 1 fails;
+    # it raises its own error at once, rank 0 leaves step A normally and must raise RemoteRankError at the START of step B, i.e. before
+    # it enters a collective rank 1 will never join.
+    lazy_kind, entered_b = 'none', False
+    try:
+        err = ValueError('rank 1 broke again') if rank == 1 else None
+        parallel.allreduce_grads([a], [torch.tensor(1.0)], error=err, lazy=True)
+        lazy_kind = 'returned'
+        real_all_reduce = dist.all_reduce
+        def spy(*args, **kw):
+            nonlocal entered_b
+            entered_b = True
+            return real_all_reduce(*args, **kw)
+        dist.all_reduce = spy
+        try:
+            parallel.allreduce_grads([a], [torch.tensor(1.0)], lazy=True)
+        finally:
+            dist.all_reduce = real_all_reduce
+    except ValueError:
+        lazy_kind = 'own'
+    except parallel.RemoteRankError:
+        lazy_kind = 'remote-next-step' if lazy_kind == 'returned' else 'remote'
+    # a clean step leaves nothing pending at the end of a loop
+    if rank == 0:
+        parallel.check_pending_errors()
+    parallel.barrier()
+    q.put((rank, ok, kind, lazy_kind, entered_b))
     dist.destroy_process_group()
 
 
@@ -259,8 +285,10 @@ def test_allreduce_grads_mixed_types_and_error_flag_gloo():
     procs = [ctx.Process(target=_error_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict((r, (ok, kind)) for r, ok, kind in [q.get(timeout=240) for _ in procs])
+    res = dict((r[0], r[1:]) for r in [q.get(timeout=240) for _ in procs])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0] == (True, 'remote') and res[1] == (True, 'own'), res
+    assert res[0][:2] == (True, 'remote') and res[1][:2] == (True, 'own'), res
+    # deferred flag: the healthy rank learns of the failure one step later and BEFORE its next collective
+    assert res[0][2:] == ('remote-next-step', False) and res[1][2:] == ('own', False), res

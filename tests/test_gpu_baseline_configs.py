@@ -469,3 +469,9 @@ def test_bench_rccl_multi_gpu():
         assert len({r['device_index'] for r in c['rccl']['ranks']}) == 2
     cb = bal['config']
     assert cb['unbalanced_ms_per_step'] > 0 and cb['balanced_ms_per_step'] > 0 and cb['value_is'] in ('balanced', 'unbalanced')
+    # the real backend is named, the N = 1-equivalent mode is stated, `value` switches only above the noise margin
+    for j in outs:
+        assert 'RCCL all-reduce' in j['config']['parallelism'] and j['config']['n1_protocol_equivalent'] == 'unbalanced'
+    assert cb['value_switch_margin'] == 0.02
+    if cb['value_is'] == 'balanced':
+        assert cb['balanced_ms_per_step'] < (1.0 - cb['value_switch_margin']) * cb['unbalanced_ms_per_step']
