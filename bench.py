@@ -667,11 +667,11 @@ def main():
                 c['balanced_ms_per_step'] = (1e3 * timing['balanced'] / args.steps) if timing['balanced'] is not None else None
                 c['value_is'] = 'balanced' if plan else 'unbalanced'
                 c['value_switch_margin'] = BALANCE_MARGIN
+                if timing.get('balance_plan_tried'):
+                    c['balance_plan_tried'] = timing['balance_plan_tried']
             # which of the timed modes is the N = 1 protocol run on N GPUs (one whole view per GPU, nothing moved between ranks): efficiency
             # against the N = 1 line compares like with like only through this mode's number
             c['n1_protocol_equivalent'] = 'unbalanced' if not c5 else 'row_bands (strong scaling: no N = 1 analogue per rank; compare total ms_per_step)'
-                if timing.get('balance_plan_tried'):
-                    c['balance_plan_tried'] = timing['balance_plan_tried']
         if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)
             out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np, H, MARCH_STEP, args.marcher)
             out['cpu_baseline_torch'] = cpu_baseline_torch(fixture, Ws, bs, latent_np, MARCH_STEP, args.marcher)

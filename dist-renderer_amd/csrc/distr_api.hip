@@ -39,9 +39,10 @@ struct distr_ctx {
   bool save_masks = true;       // save ReLU masks in the forward so that the backward skips the decoder recompute
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
-  // exchange regions of the cluster tiles (distr_mlp.hpp, "Cluster tile"): uncached device memory, one region per stream
-  // that renders through this context (concurrent renders on different streams must not share barrier words)
-  struct XRegion { float* buf = nullptr; uint32_t* flags = nullptr; uint32_t epoch = 0; hipStream_t stream = nullptr; bool used = false; uint64_t last_use = 0; };
+  // exchange regions of the cluster tiles (distr_mlp.hpp, "Cluster tile"): granule slots in ordinary (cached) device memory +
+  // assembly words in uncached memory, one region per stream that renders through this context (concurrent renders on different
+  // streams must not share them)
+  struct XRegion { char* buf = nullptr; uint32_t* flags = nullptr; uint32_t epoch = 0; hipStream_t stream = nullptr; bool used = false; uint64_t last_use = 0; };
   uint64_t xr_clock = 0;
   bool xchg_ts = false;         // DISTR_XCHG_TS=1: cluster 0 / member 0 writes phase stamps behind the flag words (distr_debug_xchg_ts)
   static constexpr int NXR = 8;
@@ -51,6 +52,7 @@ struct distr_ctx {
   int min_cl = 2;               // smallest cluster: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032 (DISTR_CLUSTER_MIN=4: off)
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
   bool sticky = true;           // DISTR_STICKY=0: cluster tiles never keep their rays across march steps (sticky_tile16)
+  int xchg_sc1 = 0;             // DISTR_XCHG_SC1=1 (tests): write-through slice stores even for clusters on one XCD (the mixed-XCD path)
 };
 
 namespace {
@@ -219,8 +221,8 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   return DISTR_OK;
 }
 
-// Exchange region of `stream` (allocated on the stream's first render: 16 MiB + 128 KiB of uncached device memory; steady
-// state never allocates). Null (-> single-workgroup tiles) when disabled, out of regions, or the allocation fails.
+// Exchange region of `stream` (allocated on the stream's first render: 32 MiB of granule slots + 128 KiB of uncached assembly
+// words; steady state never allocates). Null (-> single-workgroup tiles) when disabled, out of regions, or the allocation fails.
 distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
   if (!ctx->cluster) return nullptr;
   {  // a launch sequence that is being captured into a graph would replay with the epochs of the capture (the barrier words
@@ -248,13 +250,15 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
     lru->stream = stream; lru->last_use = ++ctx->xr_clock;
     return lru;
   }
-  constexpr size_t buf_bytes = (size_t)256 * 2 * 8192 * sizeof(float), flag_bytes = (size_t)256 * 128 * sizeof(uint32_t) + 64 * sizeof(long long);
+  constexpr size_t buf_bytes = (size_t)256 * XCLUSTER_BYTES, flag_bytes = (size_t)256 * 128 * sizeof(uint32_t) + 64 * sizeof(long long);
   int cur = -1;
   (void)hipGetDevice(&cur);
   if (cur != ctx->device) (void)hipSetDevice(ctx->device);       // the region must live on the context's device
   struct Restore { int cur, dev; ~Restore() { if (cur >= 0 && cur != dev) (void)hipSetDevice(cur); } } restore{cur, ctx->device};
-  if (hipExtMallocWithFlags((void**)&free_slot->buf, buf_bytes, hipDeviceMallocUncached) != hipSuccess ||
+  // (granule tags start at 8 = epoch 1 << 3: a zeroed slot never validates)
+  if (hipMalloc((void**)&free_slot->buf, buf_bytes) != hipSuccess ||
       hipExtMallocWithFlags((void**)&free_slot->flags, flag_bytes, hipDeviceMallocUncached) != hipSuccess ||
+      hipMemset(free_slot->buf, 0, buf_bytes) != hipSuccess ||
       hipMemset(free_slot->flags, 0, flag_bytes) != hipSuccess) {
     (void)hipGetLastError();
     if (free_slot->buf) { (void)hipFree(free_slot->buf); free_slot->buf = nullptr; }
@@ -267,14 +271,17 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
 }
 
 // Exchange parameters of the next launch on region `r`. `epochs` = barrier epochs the launch may use (1; a step launch whose
-// cluster tiles may go sticky uses one per remaining march step). The epoch counter wraps after ~4e9: before it does, the flag
-// words are cleared on the stream (no stale word may equal a future epoch) and counting restarts at 1.
-inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl, int test_abort, int min_cl, uint32_t epochs = 1, bool sticky = false) {
-  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1};
+// cluster tiles may go sticky uses one per remaining march step). Epochs stay below 2^28 (an arrival word is epoch << 4 | XCC id,
+// a granule tag epoch << 3 | layer): before the counter gets there, the assembly words AND the granule slots are cleared on the
+// stream (no stale word or tag may equal a future one) and counting restarts at 1.
+inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl, int test_abort, int min_cl, uint32_t epochs = 1, bool sticky = false,
+                      int force_sc1 = 0) {
+  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1, force_sc1};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
   if (r) {
-    if (r->epoch > 0xffffffffu - epochs - 1) {
+    if (r->epoch > 0x0fffffffu - epochs - 1) {
       (void)hipMemsetAsync(r->flags, 0, (size_t)256 * 128 * sizeof(uint32_t), s);
+      (void)hipMemsetAsync(r->buf, 0, (size_t)256 * XCLUSTER_BYTES, s);
       r->epoch = 0;
     }
     x.buf = r->buf; x.flags = r->flags; x.epoch = r->epoch + 1; x.epochs = epochs; x.sticky = sticky ? 1 : 0;
@@ -406,6 +413,7 @@ int distr_create_abi(distr_ctx** out, int hip_device, uint32_t abi_version) {
   if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e) != 0;
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   if (const char* e = getenv("DISTR_STICKY")) ctx->sticky = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_XCHG_SC1")) ctx->xchg_sc1 = atoi(e) != 0;
   {
     // invariants of the tile-size split (fine_split and the host-side grid sizes rely on them): multiples of 64,
     // 64 <= t16 <= t32, and t16 + t32 below one full round (16384 rays) so that "remainder" ranges never reach a round
@@ -728,7 +736,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       const int crb = (nviews * pad_to(ln, 32) <= t32) ? 1 : 2;
       const int ctile = c16 ? 16 : 32 * crb;
       unsigned tiles = NV * (unsigned)((ln + ctile - 1) / ctile);
-      A.xc = next_xchg(c16 ? xr : nullptr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl);
+      A.xc = next_xchg(c16 ? xr : nullptr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, 1, false, ctx->xchg_sc1);
       if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
       if (c16) {
@@ -806,7 +814,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       else hipLaunchKernelGGL((k_step<false, 1>), dim3(grid), dim3(NTHREADS), 0, s, A, D, ctx->D16, G);
     } else {
       G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
-      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky && !cfg->concurrent);
+      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky && !cfg->concurrent, ctx->xchg_sc1);
       unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
       if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
       G.n16 = up8(n16);

@@ -9,6 +9,8 @@
 //   depth2normal                        core/utils/render_utils.py:9-43
 //   autograd backward                   (PyTorch tape in the reference; SURVEY.md Appendix A.6 contract)
 #pragma once
+#include <type_traits>
+
 #include "distr_mlp.hpp"
 #include "distr_mlp_b6.hpp"
 #include "distr_mlp_h3.hpp"
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_march(
 // (compute units held by another stream) is evaluated by its lead member alone and hands its rays back to the next step's live
 // list; if a barrier times out later, the lead member finishes the tile alone on the single-workgroup path.
 template <bool KEEP>
-__device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, const View& V,
+__device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CLX& S, const View& V,
                                               int tile, int member, int64_t base, int64_t count) {
   constexpr int TILE = 16;
   const int tid = threadIdx.x;
@@ -824,14 +826,17 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         const float za = mn + init_now;
         const float a = fabsf(s);
         if (lead) {
-          V.m[id] = mn;
+          // (the ray's row addresses are recomputed from id + an opaque zero every step: hoisted out of the step loop they would be ~40
+          // 64-bit values alive across the decoder evaluation)
+          const int32_t id_ = id + zero;
+          V.m[id_] = mn;
           RayPre st;                   // this step's view of the selected rows (only the keys and slots are read)
           st.m = m; st.init_now = init_now; st.maxbound = maxbound; st.minabs = minabs;
 #pragma unroll
           for (int k = 0; k < MAX_BS; ++k) { st.ks[k] = S.sk[k][tid]; st.sl[k] = S.ssl[k][tid]; }
-          const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);
+          const int slot = topk_insert_pre(V, st, id_, s, zd, V.pyramid ? za : mn, id_);
           if (slot >= 0) {
-            mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+            mblock = (long long)id_ * (V.cfg.buffer_size + 1) + slot;
             // the same insertion on the LDS copy: rows behind the new one move down, the new row takes its place
             const int bs = V.cfg.buffer_size;
             int pos = bs;
@@ -849,8 +854,8 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
               if (k == pos) { S.sk[k][tid] = s; S.ssl[k][tid] = slot; }
             }
           }
-          if (a < minabs) V.minabs[id] = a;
-          if (step == 0) V.first_sdf[id] = s;
+          if (a < minabs) V.minabs[id_] = a;
+          if (step == 0) V.first_sdf[id_] = s;
         }
         if (a < minabs) minabs = a;
         m = mn;
@@ -893,8 +898,9 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
 
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
 // MODE_FINE (recursive marchers), MODE_COARSE (pyramid levels of small images) and MODE_EVAL.
-template <int MODE, bool KEEP>
-__device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CL& S, int bidx,
+// SM: Smem16CLX where cluster tiles can occur (MODE_FINE / MODE_COARSE), Smem16CL for MODE_EVAL (no landing zone: two workgroups per CU)
+template <int MODE, bool KEEP, class SM>
+__device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, SM& S, int bidx,
                                              int origin_tile) {
   constexpr int TILE = 16;
   const View& V0 = A.V;
@@ -969,9 +975,11 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
     }
   }
   const View V = view_at(V0, vb);
-  if (sticky_launch && !origin) {
-    sticky_tile16<KEEP>(A, D, D16, S, V, tile, member, base, count);
-    return;
+  if constexpr (MODE == MODE_FINE) {
+    if (sticky_launch && !origin) {
+      sticky_tile16<KEEP>(A, D, D16, S, V, tile, member, base, count);
+      return;
+    }
   }
   if (origin && V.C->origin_done) return;   // f(origin) was evaluated by an earlier launch (the one that turned sticky)
   const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, A.step) : nullptr;
@@ -1010,9 +1018,11 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   float pre;
   bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
   if (MODE != MODE_EVAL && cl > 1) {
-    if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-    else if (cl == 4) pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-    else pre = mlp_forward16_cl<2, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+    if constexpr (MODE != MODE_EVAL) {
+      if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+      else if (cl == 4) pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+      else pre = mlp_forward16_cl<2, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+    } else pre = 0.f;
     if (member != 0) return;            // only the lead member runs the epilogue
     clustered = S.fail == 0;
     if (!clustered) {
@@ -1079,9 +1089,11 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   }
 }
 
+// (MODE_EVAL: point lists of any length on single-workgroup tiles, two per CU; MODE_COARSE: at most 256 tiles, cluster tiles among
+// them -- one workgroup per CU and the whole register file for the weight ring + the granule requests in flight)
 template <int MODE, bool KEEP>
-__global__ void __launch_bounds__(256, 2) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
-  __shared__ Smem16CL S;
+__global__ void __launch_bounds__(256, (MODE == MODE_EVAL) ? 2 : 1) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
+  __shared__ typename std::conditional<MODE == MODE_EVAL, Smem16CL, Smem16CLX>::type S;
   march_tile16<MODE, KEEP>(A, D, D16, S, (int)blockIdx.x, A.origin_tile);
 }
 
@@ -1097,7 +1109,7 @@ struct StepGrid { int32_t n64, n32, n16; };
 template <bool KEEP, int ARITH = 0>
 __global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, DecoderDev16 D16, StepGrid G) {
   __shared__ __attribute__((aligned(16))) unsigned char raw[(sizeof(Smem<2>) > sizeof(SmemB6<2>)) ? sizeof(Smem<2>) : sizeof(SmemB6<2>)];
-  static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CL) && sizeof(SmemB6<2>) >= sizeof(SmemB6<1>), "role shared memory");
+  static_assert(sizeof(Smem<2>) >= sizeof(Smem<1>) && sizeof(Smem<2>) >= sizeof(Smem16CLX) && sizeof(SmemB6<2>) >= sizeof(SmemB6<1>), "role shared memory");
   // role order in the grid: 32-ray tiles, 16-ray / cluster tiles, 64-ray tiles. On a tail step the cluster tiles start
   // after one wave of idle 32-ray workgroups and the idle 64-ray workgroups retire on the free CUs while the clusters
   // run; on a dense step the remainder tiles start first and the persistent 64-ray workgroups follow as CUs free up.
@@ -1106,7 +1118,7 @@ __global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, Deco
   if (b < G.n32) {
     (void)march_tile<MODE_FINE, 1, KEEP, ARITH>(A, D, *reinterpret_cast<typename TileSmem<1, ARITH>::type*>(raw), b, G.n32, 32, ARITH ? A.origin_tile : 0);
   } else if (b < G.n32 + G.n16) {
-    if constexpr (ARITH == 0) march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CL*>(raw), b - G.n32, A.origin_tile);
+    if constexpr (ARITH == 0) march_tile16<MODE_FINE, KEEP>(A, D, D16, *reinterpret_cast<Smem16CLX*>(raw), b - G.n32, A.origin_tile);
   } else {
     for (int t = b - G.n32 - G.n16;; t += G.n64) {
       if (!march_tile<MODE_FINE, 2, KEEP, ARITH>(A, D, *reinterpret_cast<typename TileSmem<2, ARITH>::type*>(raw), t, 0x7fffffff, 64, 0)) break;

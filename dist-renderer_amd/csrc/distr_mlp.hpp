@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "distr_dense_asm.hpp"
 
 namespace distr {
@@ -755,11 +758,20 @@ struct Smem16 {
 
 struct Smem16CL : Smem16 {
   uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
-  int32_t fail;           // != 0: this member gave up on the cluster (assembly or barrier timed out / aborted)
+  int32_t fail;           // != 0: this member gave up on the cluster (assembly or a staging unit timed out / aborted)
+  int32_t sc1;            // the cluster's members sit on more than one XCD: slices are stored write-through (cl_assemble)
   int32_t cont;           // sticky tiles: any ray of the tile still live after this step
   float sk[8][16];        // sticky tiles: the rays' selected-row keys (sdf, |.| ascending) and mask slots between steps
   int32_t ssl[8][16];     // (DISTR_MAX_BUFFER_SIZE rows; kept here, not in registers, across the decoder evaluation)
 };
+
+// cluster tiles: + the landing zone of the granule requests (LDS-DMA; 4 units x 4 requests x 4 waves x 1 KiB, thread-private: a
+// thread reads back exactly the 16 bytes per request its own lane received)
+// The landing zone comes FIRST in the workgroup's LDS (offsets 0 .. 64 KiB - 1): the LDS-DMA destination travels in M0.
+struct SmemStage {
+  alignas(16) unsigned char stage[4 * 4 * 4 * 1024];
+};
+struct Smem16CLX : SmemStage, Smem16CL { };
 
 struct DecoderDev16 {
   const float* Wf[8];   // 16x16x4 A-fragments: float4 ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + i][16g + 4s + kq] : s=0..3 }
@@ -958,18 +970,29 @@ __device__ __forceinline__ void store_masks16(uint4* mstore, const long long* mb
 // Cluster tile: ONE 16-ray tile split over CL workgroups on CL compute units (the deep tail of the march, where a step
 // has at most a few hundred live rays: most of the chip idles and a step costs exactly one tile latency, which on one CU
 // cannot drop below ~100 us of MFMA issue). Member m computes rows [m*O/CL, (m+1)*O/CL) of every layer for all 16 rays
-// and the members exchange their slices after each layer through an UNCACHED device buffer owned by the context
-// (MTYPE UC: stores go to memory, loads bypass L1/L2, so no cache maintenance; measured 2.0 us per exchange for up to 64
-// clusters, profiles/ubench/cluster_exchange.hip; the same exchange through cached memory with agent-scope
-// release/acquire costs 3 us for 8 clusters and 16 us for 64). The members of a cluster are workgroups with equal
-// blockIdx mod 8, i.e. on the same XCD. Every output row is still one k-ordered fmaf chain computed by one wave, so the
-// values are bit-identical to every other tile size. Barrier = per-member epoch words (no atomics, no reset): a member
-// stores the launch's epoch into its word of barrier j and polls the CL words until all carry the epoch; polling is
-// bounded (a timeout sets *err and the launch finishes with garbage rather than hanging).
+// and the members exchange their slices after each layer. Every output row is still one k-ordered fmaf chain computed by
+// one wave, so the values are bit-identical to every other tile size.
+//
+// Exchange (round 5; rounds 2-4 used per-layer epoch-word barriers over uncached memory followed by a bulk read: store 0.6 +
+// barrier 0.9 + read 1.5 us of every 5.5 us layer): the data IS the flag. A slice travels as 8-byte GRANULES { value, tag },
+// tag = (launch epoch << 3) | layer -- unique per launch, march step and layer, so a granule validates itself and no word of
+// the protocol needs resetting, ordering or a barrier (MI355X_MICROARCH.md, "inter-workgroup visibility", form R2; 8-byte
+// halves of a 16-byte access, each self-validating). The consumer side is PIPELINED in k order: a layer's k-loop walks the
+// previous layer's rows in natural order, i.e. member 0's slice first, so a member starts on the first 128 rows (one staging
+// UNIT = 8 k-groups) as soon as THEY have arrived and stages unit u+1 into LDS while the MFMAs of unit u run; only the first
+// unit's hand-off latency is exposed per layer (about 1 us) instead of a barrier plus a bulk read of all slices.
+// All requests of a layer's input are issued at the end of the previous layer (their addresses do not depend on data); a
+// granule whose tag is not the expected one yet is simply requested again (bounded: a timeout makes the lead member evaluate
+// the tile alone, see below). The members of a cluster are workgroups with equal blockIdx mod 8, which the dispatcher places
+// on one XCD: their stores then stay in that XCD's L2 and the polling loads (sc1: L1-bypassing) are served from it. The
+// placement is CHECKED, not assumed: every member posts its XCC id with its arrival word and the lead member switches the
+// cluster to write-through (sc1) stores when the ids differ -- plain stores are never seen by another XCD's L2.
 struct Xchg {
-  float* buf;          // [256 clusters][2][8192]  activation slices, fragment layout (float4 index rb*64 + lane)
-  uint32_t* flags;     // [256 clusters][16 barriers][8 members]
-  uint32_t epoch;      // unique per launch (per region)
+  char* buf;           // [256 clusters][2 slots][32 row blocks][2 halves][64 lanes][16 B]  granule slots (cached device memory): row block rb,
+                       // half h, lane l = rows 16rb + 4(l>>4) + 2h + {0, 1} of ray l&15 as { v, tag, v', tag } -- 1 KiB per (rb, h): one
+                       // coalesced wave store on the producer, one LDS-DMA request on the consumer
+  uint32_t* flags;     // [256 clusters][16][8] uncached words: slot 0 = arrival words (epoch << 4 | XCC id), slot 8 = { go, abort, go-mixed-XCD }
+  uint32_t epoch;      // unique per launch (per region), < 2^28
   int32_t max_cl;      // largest cluster size to use (8 or 4)
   int32_t min_cl;      // smallest cluster size to use (2 = pair tiles up to 2032 rays; DISTR_CLUSTER_MIN=4 turns them off)
   int32_t test_abort;  // tests (DISTR_CLUSTER_TEST_ABORT=1): every lead member behaves as if its cluster had not assembled
@@ -977,16 +1000,19 @@ struct Xchg {
   int32_t par;         // parity of the exchange slots (sticky tiles alternate it per march step, see sticky_tile16)
   int32_t sticky;      // 1: a launch whose clusters (8 CUs per tile) all fit may march its tiles to the end (DISTR_STICKY=0: off)
   uint32_t epochs;     // epochs this launch may use: epoch .. epoch + epochs - 1 (one per march step of a sticky tile)
+  int32_t force_sc1;   // tests (DISTR_XCHG_SC1=1): write-through stores even when all members share an XCD (the mixed-XCD path)
 };
+constexpr int XSLOT_BYTES = 2048 * 32;            // one granule slot: 512 rows x 16 rays x 8 B
+constexpr int XCLUSTER_BYTES = 2 * XSLOT_BYTES;
 // Wall-clock budgets (100 MHz ticks) of the cluster protocol. Co-residency of a cluster's workgroups is NOT guaranteed by the
 // hardware (other streams / ranks may hold the compute units), so a cluster first ASSEMBLES: every member posts an arrival
 // word, the lead member waits at most CL_T_ARRIVE (after its own lin0) for all of them and then publishes `go` or `abort`. After `go` all members
-// are resident and the per-layer barriers can only be delayed by compute skew; they are still bounded (CL_T_BARRIER). Whenever
-// the lead member gives up -- at assembly or at any barrier -- it evaluates the tile on its own (mlp_forward16: same values,
+// are resident and the per-unit waits can only be delayed by compute skew; they are still bounded (CL_T_BARRIER). Whenever
+// the lead member gives up -- at assembly or at any unit -- it evaluates the tile on its own (mlp_forward16: same values,
 // bit for bit), so a scheduling surprise costs time, never correctness. Members that give up just leave.
 constexpr long long CL_T_ARRIVE = 30 * 100;      // 30 us (members of a cluster are dispatched within ~1 us of each other when CUs are free)
 constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for the lead's verdict
-constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per layer barrier
+constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per staging unit
 #define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); __builtin_amdgcn_s_waitcnt(0); } } while (0)
 
 
@@ -994,8 +1020,7 @@ constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per layer barrier
 // The A-fragments a wave needs are streamed in chunks of 8 float4 (G = 8/NBL feature groups of 16) through a RING of four
 // register buffers, three chunks ahead of their use: a chunk is 32 MFMAs of work (about 0.45 us at the issue rate), a request
 // needs about 1 us from L2, so one chunk of look-ahead (the first version) stalled every chunk. The ring runs across layers:
-// the first chunks of the next layer(s) are requested during the last chunks of this one, i.e. BEFORE its exchange barrier
-// (weights do not depend on activations), so their latency hides behind the exchange.
+// the first chunks of the next layer(s) are requested during the last chunks of this one (weights do not depend on activations).
 template <int K, int O, int CL>
 struct ClGeom {
   static constexpr int RBT = O / 16, PER = RBT / CL, NBL = (PER >= 4) ? PER / 4 : 1, ACT = (PER >= 4) ? 4 : PER;
@@ -1003,90 +1028,192 @@ struct ClGeom {
 };
 constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
 
-// The weight stream is issued with inline-asm loads and waited for with explicit vmcnt counts: the compiler's own wait-count
-// insertion drains the whole queue (vmcnt(0)) in front of every chunk here, which serialises each request with its use. Loads
-// of one wave return in order, so "the chunk requested 3 chunks ago has landed" = "at most 8 x (younger requests) loads are
-// outstanding". EVERY wave issues every request (waves without rows in a layer fetch another wave's fragments and drop them),
-// so the count is the same in all waves. Other memory operations in flight only make a wait stricter.
-__device__ __forceinline__ void cl_ld(f32x4& dst, const f32x4* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+// The weight stream AND the granule stream are issued by inline asm and waited for with explicit vmcnt counts: the compiler's own
+// wait-count insertion drains the whole queue (vmcnt(0)) in front of every use here, which serialises each request with its use.
+// Memory operations of one wave complete in order, so "request R has landed" = "at most (number of requests issued after R) are
+// outstanding". The counts are compile-time constants of the issue pattern, which is therefore the same in EVERY wave: every wave
+// issues every weight chunk (waves without rows in a layer fetch another wave's fragments and drop them) and every granule request.
+// Operations only some waves issue (slice stores, bias loads, debug stamps) are NOT counted: an uncounted operation in flight only
+// makes a wait stricter, never weaker. A re-request of granules (tag not there yet) is followed by vmcnt(0), after which every
+// statically counted wait is satisfied trivially.
+//
+// NO register the compiler allocates is ever the destination of such a request. A register the compiler sees defined by an asm load
+// counts as written when the statement ends: under register pressure it is copied, parked in an accumulation register or reused
+// BEFORE the data lands (garbage, or a memory fault when the reused register held an address) -- round 5's first version of the
+// pipelined exchange did exactly that (profiles/tools/vm_hazard_scan.py finds such accesses in the generated code). So:
+//   * the weight ring (4 chunks x 8 float4), the layers' accumulators and their start values live in FIXED accumulation registers
+//     a[96:255] that only the asm statements below name: the loads target them directly, the MFMAs read their A operand from them and
+//     accumulate in them (gfx950: loads may write AGPRs, an MFMA takes A / B from either file), v_accvgpr_read moves the finished
+//     rows out. Every statement lists a96..a255 as clobbered, so the compiler keeps nothing of its own there across them; outside
+//     the cluster tile the registers are ordinary (the other roles of k_step use them freely);
+//   * the granule requests are LDS-DMA requests (global_load_lds_dwordx4) into a thread-private landing zone (Smem16CLX::stage),
+//     read back with ordinary LDS loads after the counted wait.
+#define CL_CLOB "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+constexpr int CL_RING0 = 96;     // chunk slot r, float4 i, element s: a[96 + 32 r + 4 i + s]
+constexpr int CL_ACC0 = 224;     // accumulator set p (= layer & 1), row block ob, register r: a[224 + 16 p + 4 ob + r]
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+// Addresses: every request of the cluster tile is "wave-uniform base + 16 x lane" (or + 16 x (lane >> 4)): the base travels in an
+// SGPR pair, the lane part in ONE 32-bit VGPR shared by all requests -- no per-request 64-bit address VGPRs (hoisted out of the
+// step loop of a sticky tile they were dozens of live values next to the fixed registers).
+// (an "s" operand must be PROVABLY wave-uniform, else the compiler substitutes a VGPR and the assembler rejects the statement: bases
+// go through readfirstlane -- free when the value already sits in SGPRs. The compiler pads nothing INSIDE an asm string: a vector
+// memory instruction that reads an SGPR a scalar instruction wrote fewer than 5 wait states ago gets the OLD value -- an address
+// with a stale half, "memory access fault at (nil)" -- so every such statement opens with s_nop 4.)
+template <class T>
+__device__ __forceinline__ T* cl_uni(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+template <int LO>
+__device__ __forceinline__ void cl_ld_a(uint32_t voff, const void* sbase) {      // a[LO:LO+3] <- 16 bytes at sbase + voff
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%2:%2+3], %0, %1" ::"v"(voff), "s"(cl_uni(sbase)), "n"(LO) : "memory", CL_CLOB);
+}
+// eight of them in one statement (a weight chunk): a[LO + 4 i : LO + 4 i + 3] <- p_i + voff
+template <int LO>
+__device__ __forceinline__ void cl_ld_a8(uint32_t voff, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5,
+                                         const void* p6, const void* p7) {
+  asm volatile("s_nop 4\n\t"
+               "global_load_dwordx4 a[%9+0:%9+3], %0, %1\n\t"
+               "global_load_dwordx4 a[%9+4:%9+7], %0, %2\n\t"
+               "global_load_dwordx4 a[%9+8:%9+11], %0, %3\n\t"
+               "global_load_dwordx4 a[%9+12:%9+15], %0, %4\n\t"
+               "global_load_dwordx4 a[%9+16:%9+19], %0, %5\n\t"
+               "global_load_dwordx4 a[%9+20:%9+23], %0, %6\n\t"
+               "global_load_dwordx4 a[%9+24:%9+27], %0, %7\n\t"
+               "global_load_dwordx4 a[%9+28:%9+31], %0, %8"
+               ::"v"(voff), "s"(cl_uni(p0)), "s"(cl_uni(p1)), "s"(cl_uni(p2)), "s"(cl_uni(p3)), "s"(cl_uni(p4)), "s"(cl_uni(p5)), "s"(cl_uni(p6)),
+                 "s"(cl_uni(p7)), "n"(LO) : "memory", CL_CLOB);
+}
+// One k-group (16 features = 4 MFMA k-steps) of a wave's NBL row blocks: accumulator block ob = a[AB + 4 ob : AB + 4 ob + 3], its
+// A-fragment for k-step s = a[RB + 4 ob + s], B-fragment of k-step s = b_s. The NBL chains are interleaved, each stays k-ordered.
+template <int NBL, int AB, int RB>
+__device__ __forceinline__ void cl_mfma_group(float b0, float b1, float b2, float b3) {
+  if constexpr (NBL == 1) {
+    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+1], %1, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+2], %2, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+3], %3, a[%4+0:%4+3]"
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+  } else if constexpr (NBL == 2) {
+    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+4], %0, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+1], %1, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+5], %1, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+2], %2, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+6], %2, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+3], %3, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+7], %3, a[%4+4:%4+7]"
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+  } else {
+    static_assert(NBL == 4, "1, 2 or 4 row blocks per wave");
+    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+4], %0, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+8], %0, a[%4+8:%4+11]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+12], %0, a[%4+12:%4+15]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+1], %1, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+5], %1, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+9], %1, a[%4+8:%4+11]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+13], %1, a[%4+12:%4+15]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+2], %2, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+6], %2, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+10], %2, a[%4+8:%4+11]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+14], %2, a[%4+12:%4+15]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+3], %3, a[%4+0:%4+3]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+7], %3, a[%4+4:%4+7]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+11], %3, a[%4+8:%4+11]\n\t"
+                 "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+15], %3, a[%4+12:%4+15]"
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+  }
+}
+// the four finished rows of accumulator block a[LO:LO+3] (after the MFMA's 8 passes: s_nop)
+template <int LO>
+__device__ __forceinline__ f32x4 cl_acc_read4() {
+  float v0, v1, v2, v3;
+  asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %0, a[%4+0]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\tv_accvgpr_read_b32 %2, a[%4+2]\n\t"
+               "v_accvgpr_read_b32 %3, a[%4+3]" : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "n"(LO) : CL_CLOB);
+  f32x4 v;
+  v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+  return v;
+}
+// one LDS-DMA request: lane l's 16 bytes at gsrc (L1-bypassing: polled data) -> LDS bytes lds_dst + 16 l (lds_dst wave-uniform). M0 is
+// the compiler's: saved and restored inside the statement.
+__device__ __forceinline__ void cl_dma16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(cl_uni(sbase)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+__device__ __forceinline__ void cl_st(uint32_t voff, void* sbase, const f32x4& v, int sc1) {     // (s_nop 1: the store reads its data registers after issue)
+  sbase = cl_uni(sbase);
+  if (sc1) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");   // write-through: visible to every XCD
+  else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");           // stays in this XCD's L2
 }
 template <int N>
-__device__ __forceinline__ void cl_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+__device__ __forceinline__ void cl_wait_vm() {   // (vmcnt has 6 bits: a smaller count only waits for more)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory", CL_CLOB);
 }
-// "the value of these registers is final from here on": an empty asm that redefines them, so that nothing the compiler derives
-// from a loaded value (a copy into an accumulator register, a move) can be placed before the wait that precedes this statement
-__device__ __forceinline__ void cl_landed(f32x4 (&w)[8]) {
-  asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]));
-}
-__device__ __forceinline__ void cl_landed(f32x4& a) { asm volatile("" : "+v"(a)); }
 
-template <int K, int O, int CL>
-__device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, f32x4 (&w)[8], int c, int member, int wave, int lane) {
+// chunk C of a K x O layer -> ring slot SLOT: this wave's 8 float4 A-fragments (G = 8 / NBL k-groups of its NBL row blocks)
+template <int K, int O, int CL, int SLOT, int C>
+__device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, int member, int wave, int lane) {
   using Ge = ClGeom<K, O, CL>;
   static_assert(Ge::NG % Ge::G == 0, "whole chunks only");
   const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1)) * Ge::NBL;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(Wf) + (size_t)rb0 * 64 + lane;   // float4 index (g*RBT + rb)*64 + lane
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int g = c * Ge::G + i / Ge::NBL, ob = i % Ge::NBL;
-    cl_ld(w[i], wp + ((size_t)g * Ge::RBT + ob) * 64);
-  }
+  const char* wp = reinterpret_cast<const char*>(Wf) + (size_t)rb0 * 1024;          // float4 index (g*RBT + rb)*64 + lane
+  auto at = [&](int i) { return wp + ((size_t)(C * Ge::G + i / Ge::NBL) * Ge::RBT + (i % Ge::NBL)) * 1024; };
+  cl_ld_a8<CL_RING0 + 32 * SLOT>((uint32_t)lane * 16u, at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7));
 }
 
-// start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector), as counted loads
-template <int K, int O, int CL>
-__device__ __forceinline__ void cl_load_start(const float* __restrict__ init, f32x4 (&start)[4], int member, int wave, int kq) {
+// start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector) straight into accumulator set P
+// (uncounted requests: only the waves with rows issue them)
+template <int K, int O, int CL, int P>
+__device__ __forceinline__ void cl_load_start(const float* __restrict__ init, int member, int wave, int kq) {
   using Ge = ClGeom<K, O, CL>;
-  static_assert(Ge::NBL <= 4, "start[] holds at most 4 row blocks");
+  static_assert(Ge::NBL <= 4, "an accumulator set holds at most 4 row blocks");
   if (wave >= Ge::ACT) return;
   const int rb0 = member * Ge::PER + wave * Ge::NBL;
-#pragma unroll
-  for (int ob = 0; ob < Ge::NBL; ++ob) cl_ld(start[ob], reinterpret_cast<const f32x4*>(init + 16 * (rb0 + ob) + 4 * kq));
-}
-
-// slot layout of a cluster's flag words ([16][8] uint32): slot 0 = arrival words, slots 1..7 = the layers' barriers,
-// slot 8 = { go, abort } published by the lead member
-template <int CL>
-__device__ __forceinline__ void cl_barrier(uint32_t* flags /*this cluster: [16][8]*/, int j, int member, uint32_t epoch, int tid, int32_t* fail /*LDS*/) {
-  // precondition: every wave has drained its global stores (s_waitcnt 0) and passed a __syncthreads()
-  if (tid == 0) __hip_atomic_store(flags + j * 8 + member, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid < 64) {
-    const long long t0 = (long long)wall_clock64();
-    for (;;) {
-      const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + j * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-      if (__ballot(v != epoch) == 0ull) break;
-      if ((long long)wall_clock64() - t0 > CL_T_BARRIER) { if (tid == 0) *fail = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  __syncthreads();
+  static_for<Ge::NBL>([&](auto ob_) {
+    constexpr int ob = decltype(ob_)::value;
+    cl_ld_a<CL_ACC0 + 16 * P + 4 * ob>((uint32_t)kq * 16u, init + 16 * (rb0 + ob));
+  });
 }
 
 // Assembly of a cluster (see CL_T_*). Returns with *fail set (all threads see it after the barrier) when this member must not
-// take part: the lead then evaluates the tile alone, the others leave.
+// take part: the lead then evaluates the tile alone, the others leave. *sc1 (LDS, valid when the cluster assembled) = 1: the
+// members sit on more than one XCD, slices must be stored write-through.
 template <int CL>
-__device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int test_abort) {
+__device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int32_t* sc1, int test_abort, int force_sc1) {
   if (tid < 64) {
     const long long t0 = (long long)wall_clock64();
     if (member == 0) {
-      bool ok = false;
+      bool ok = false, mixed = false;
       for (;;) {
-        const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-        if (__ballot(v != epoch) == 0ull) { ok = !test_abort; break; }
+        const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (epoch << 4);
+        if (__ballot((v >> 4) != epoch) == 0ull) {
+          ok = !test_abort;
+          const uint32_t x0 = __shfl(v & 15u, 0);
+          mixed = __ballot(tid < CL && (v & 15u) != x0) != 0ull;
+          break;
+        }
         if ((long long)wall_clock64() - t0 > CL_T_ARRIVE) break;
         __builtin_amdgcn_s_sleep(1);
       }
       if (tid == 0) {
-        __hip_atomic_store(flags + 8 * 8 + (ok ? 0 : 1), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool wt = mixed || force_sc1;
+        __hip_atomic_store(flags + 8 * 8 + (ok ? (wt ? 2 : 0) : 1), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sc1 = wt ? 1 : 0;
         if (!ok) *fail = 1;
       }
     } else {
       for (;;) {
-        const uint32_t v = (tid < 2) ? __hip_atomic_load(flags + 8 * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t v = (tid < 3) ? __hip_atomic_load(flags + 8 * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const unsigned long long hit = __ballot(v == epoch);
-        if (hit & 1ull) break;                                  // go
+        if (hit & 5ull) { if (tid == 0) *sc1 = (hit & 4ull) ? 1 : 0; break; }     // go (same XCD / mixed)
         if ((hit & 2ull) || (long long)wall_clock64() - t0 > CL_T_GO) {   // abort, or no verdict: withdraw the arrival word and leave
           if (tid == 0) { *fail = 1; __hip_atomic_store(flags + member, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           break;
@@ -1112,161 +1239,242 @@ __device__ __forceinline__ void mask_nibble_or(Smem16CL& S, int layer, int row0,
   atomicOr(reinterpret_cast<uint32_t*>(&S.mk[jj][0]) + (idx >> 1), nib << (4 * n + 16 * (idx & 1)));
 }
 
-// One dense layer of the cluster tile: this member's row slice, ReLU, slice -> own LDS + exchange buffer, barrier, the
-// other members' slices -> LDS. On return X holds the full post-ReLU output of the layer (O rows) in every member.
-// `start` = this layer's accumulator start values (requested by the previous layer); it is dead once the accumulators are
-// initialised, so the next layer's values (initNext) are requested into the same registers after the chunk loop.
+// Requests the NU staging units of a slot (a layer's whole output, all members' slices incl. the own one: the request pattern must
+// not depend on the member). Unit u = row blocks 8u .. 8u+7; wave w takes row blocks 8u + w and 8u + w + 4 of it, both halves:
+// request q = 2e + h -> row block 8u + w + 4e, half h, landing at stage[u][q][w] (1 KiB each).
+// [U0, U1): unit 0 is requested right behind the own slice store (and re-requested until its granules are there: the exposed
+// hand-off); the others only once unit 0 has been seen -- requested together with it they would all come back stale (every member
+// publishes at about the same time) and each would cost its own re-request round trip in the middle of the k-loop.
+template <int U0, int U1>
+__device__ __forceinline__ void cl_request_units(Smem16CLX& S, const char* slot, int wave, int lane) {
+#pragma unroll
+  for (int u = U0; u < U1; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      cl_dma16((uint32_t)lane * 16u, slot + ((size_t)(8 * u + wave + 4 * (q >> 1)) * 2048 + (q & 1) * 1024), lds_off(S.stage) + (uint32_t)(((u * 4 + q) * 4 + wave) * 1024));
+}
+
+// Stages unit U of the slot into X: waits (statically counted, NWAIT younger requests) for its four requests, reads them back from
+// the landing zone, validates the granule tags, re-requests until they are all there (bounded), writes the values of the OTHER
+// members' rows to X (the own rows were written at write-back) and ORs their ReLU bits into the mask blocks (lead member, KEEP).
+// The caller adds the barrier. own rows of the producing layer: row blocks [own_lo, own_lo + own_n).
+template <int U, int NWAIT>
+__device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CLX& S, int tid, bool keep, int layer_of_data,
+                                              int wr_log, long long* dbg = nullptr) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lw = tid & 63, kq = lw >> 4, j = lw & 15;
+  cl_wait_vm<NWAIT>();
+  const f32x4* land = reinterpret_cast<const f32x4*>(S.stage + (U * 16 + wave) * 1024) + lw;     // + q * 256 float4
+  bool own[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { const int rb = U * 8 + wave + 4 * e; own[e] = (unsigned)(rb - own_lo) < (unsigned)own_n; }
+  // pass 1: only the tags (few registers live next to the weight ring)
+  auto bad = [&]() {
+    uint32_t x = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 g = land[q * 256];
+      x |= own[q >> 1] ? 0u : ((__float_as_uint(g[1]) ^ tag) | (__float_as_uint(g[3]) ^ tag));
+    }
+    return x != 0u;
+  };
+  int nre = 0;                                  // (debug: re-requests of this unit)
+  if (__ballot(bad()) != 0ull) {
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        cl_dma16((uint32_t)lw * 16u, slot + ((size_t)(8 * U + wave + 4 * (q >> 1)) * 2048 + (q & 1) * 1024), lds_off(S.stage) + (uint32_t)(((U * 4 + q) * 4 + wave) * 1024));
+      cl_wait_vm<0>();
+      ++nre;
+      if (__ballot(bad()) == 0ull) break;
+      if (*reinterpret_cast<volatile int32_t*>(&S.fail) != 0) break;
+      if ((long long)wall_clock64() - t0 > CL_T_BARRIER) { S.fail = 1; break; }
+    }
+  }
+  if (dbg && tid == 0) dbg[U] = nre;
+  // pass 2: the values, one entry (four rows of one ray) at a time
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (!own[e]) {
+      const int row = 16 * (U * 8 + wave + 4 * e) + 4 * kq;
+      const f32x4 g0 = land[(2 * e) * 256], g1 = land[(2 * e + 1) * 256];
+      f32x4 v;
+      v[0] = g0[0]; v[1] = g0[2]; v[2] = g1[0]; v[3] = g1[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.X[(row + r) * 16 + j] = v[r];
+      if (keep) mask_nibble_or(S, layer_of_data, row, wr_log, j, v);
+    }
+  }
+}
+
+// number of weight-chunk requests issued in iterations 0..upto of a layer whose chunk 0 sits at position GB of the TOT-chunk sequence
+constexpr int cl_issued(int GB, int TOT, int upto) {
+  int n = 0;
+  for (int i = 0; i <= upto; ++i) n += (GB + i + CL_AHEAD < TOT) ? 1 : 0;
+  return n;
+}
+
+// One dense layer of the cluster tile: this member's row slice over the (staged) input, ReLU, slice -> own LDS + granule slot,
+// requests for the whole layer output (the next layer's input). FIRST: the input (lin0's output) was computed whole by every member
+// (nothing staged, the start values and first weight chunks were requested before lin0). Otherwise the input is the previous layer's
+// slot: unit 0 is staged before the k-loop, unit u+1 two k-groups before the end of unit u (the B fragments run two groups ahead).
+// The accumulators are set LAYER & 1 of the fixed registers; their start values were requested into them by the previous layer
+// before its slice stores, the next layer's (initNext) are requested into the other set after the chunk loop.
 // GB = index of this layer's chunk 0 in the network-wide chunk sequence (ring slot = index & 3). On entry the first
 // min(CL_AHEAD, NCH) chunks of this layer are in flight / in their slots; while chunk c is used, chunk c + CL_AHEAD of the
 // sequence is requested: of this layer, of the next one (KN x ON, WfNext) or of the one after it (KN2 x ON2, WfNext2).
-template <int K, int O, int CL, int GB, int TOT, int KN, int ON, int KN2, int ON2>
-__device__ __forceinline__ void layer_cl(const float* __restrict__ Wf, const float* __restrict__ WfNext,
-                                         const float* __restrict__ WfNext2, f32x4 (&w)[4][8], f32x4 (&start)[4], const float* __restrict__ initNext,
-                                         Smem16CL& S, const Xchg& xc, float* xbase, uint32_t* flags, int layer, int member, bool keep,
-                                         int wr_log = 7) {
+// REQ_OUT: request the output slot afterwards (false for a member that leaves after its last slice store).
+// Returns false when this member gave up (S.fail set; nothing of its requests is in flight any more).
+template <int LAYER, int K, int O, int CL, int GB, int TOT, int KN, int ON, int KN2, int ON2, bool FIRST, bool REQ_OUT>
+__device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const float* __restrict__ WfNext, const float* __restrict__ WfNext2,
+                                         const float* __restrict__ initNext, Smem16CLX& S, const Xchg& xc, char* xbase, int member, bool keep) {
   using Ge = ClGeom<K, O, CL>;
   using GeN = ClGeom<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>;
   using GeN2 = ClGeom<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL>;
   constexpr int RBT = Ge::RBT, PER = Ge::PER, NBL = Ge::NBL, ACT = Ge::ACT, G = Ge::G, NCH = Ge::NCH, NG = Ge::NG;
   constexpr int NCHN = (KN > 0) ? GeN::NCH : 0, NCHN2 = (KN2 > 0) ? GeN2::NCH : 0;
+  constexpr int NUIN = FIRST ? 0 : K / 128, PERIN = (K / 16) / CL, NUOUT = O / 128;
+  constexpr int ACC = CL_ACC0 + 16 * (LAYER & 1);
+  constexpr int layer = LAYER;
+  static_assert(FIRST || (NG % 8 == 0 && PERIN >= 1), "staging units of 8 k-groups");
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, kq = lane >> 4, j = lane & 15;
   float* X = S.X;
-  float* slot = xbase + ((layer + xc.par) & 1) * 8192;
-  f32x4 acc[NBL];
+  const char* slot_in = xbase + ((layer - 1 + xc.par) & 1) * XSLOT_BYTES;
+  char* slot_out = xbase + ((layer + xc.par) & 1) * XSLOT_BYTES;
+  const uint32_t tag_in = (xc.epoch << 3) | (uint32_t)(layer - 1), tag_out = (xc.epoch << 3) | (uint32_t)layer;
+  constexpr int wr_in = (LAYER - 1 == 3) ? 6 : 7;
   const int rb0 = member * PER + wave * NBL;
-  if (wave < ACT) {   // start values (bias / latent constants): requested by the previous layer before its exchange (cl_load_start)
-#pragma unroll
-    for (int ob = 0; ob < NBL; ++ob) { cl_landed(start[ob]); acc[ob] = start[ob]; }
+  bool failed = false;
+  if constexpr (NUIN > 0) {   // the first 128 input rows (the only exposed hand-off of the layer); everything requested earlier has landed with them
+    cl_stage_unit<0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+    cl_request_units<1, NUIN>(S, slot_in, wave, lane);       // (before this layer's first weight request: the counts below rely on it)
+    __syncthreads();
+    if (S.fail) { cl_wait_vm<0>(); return false; }
+    DISTR_XTS(4 * (layer - 1) + 3);
   }
   const float* xb = X + lane;
   float b[3][4];                      // B fragments (LDS) run two feature groups ahead
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) { b[0][s4] = xb[(4 * s4) * 16]; b[1][s4] = xb[(16 * (NG > 1 ? 1 : 0) + 4 * s4) * 16]; }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int t = c + CL_AHEAD;       // (compile-time after unrolling)
-    if (t < NCH) cl_load_chunk<K, O, CL>(Wf, w[(GB + t) & 3], t, member, wave, lane);
-    else if (t - NCH < NCHN) cl_load_chunk<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>(WfNext, w[(GB + t) & 3], t - NCH, member, wave, lane);
-    else if (t - NCH - NCHN < NCHN2) cl_load_chunk<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL>(WfNext2, w[(GB + t) & 3], t - NCH - NCHN, member, wave, lane);
+  static_for<NCH>([&](auto c_) {
+    constexpr int c = decltype(c_)::value;
+    if (failed) return;
+    constexpr int t = c + CL_AHEAD;
+    if constexpr (t < NCH) cl_load_chunk<K, O, CL, (GB + t) & 3, t>(Wf, member, wave, lane);
+    else if constexpr (t - NCH < NCHN) cl_load_chunk<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL, (GB + t) & 3, t - NCH>(WfNext, member, wave, lane);
+    else if constexpr (t - NCH - NCHN < NCHN2) cl_load_chunk<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL, (GB + t) & 3, t - NCH - NCHN>(WfNext2, member, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     if (wave < ACT) {
-      // requests issued in iterations i of this layer: issued(i) = (GB + i + CL_AHEAD < TOT). Chunk c was requested in iteration
-      // c - CL_AHEAD (c >= CL_AHEAD; earlier chunks were requested in a previous layer and drained at its exchange); at c = 0 the
-      // start values must have landed (older than this iteration's request)
-      if (c == 0) {   // (layer 1 only: the start values and first chunks requested before lin0; later layers drained them at the exchange)
-        if (GB + CL_AHEAD < TOT) cl_wait_vm<8>(); else cl_wait_vm<0>();
-      } else if (c >= CL_AHEAD) {
-        const int younger = ((GB + c + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 2 + CL_AHEAD < TOT) ? 1 : 0);
-        if (younger == 3) cl_wait_vm<24>(); else if (younger == 2) cl_wait_vm<16>(); else if (younger == 1) cl_wait_vm<8>(); else cl_wait_vm<0>();
+      if constexpr (FIRST && c == 0) {
+        // first layer: chunks 0..2 and the start values were requested before lin0 (in that order); the only younger request is this
+        // iteration's chunk
+        if constexpr (GB + CL_AHEAD < TOT) cl_wait_vm<8>(); else cl_wait_vm<0>();
+      } else if constexpr (c >= CL_AHEAD) {
+        // chunk c was requested in iteration c - CL_AHEAD of this layer: younger = the weight requests of iterations c-2 .. c (the
+        // layer's input units were requested before, the output units are requested after the loop). Chunks c < CL_AHEAD were requested
+        // during the previous layer(s), before this layer's input units: they (and the start values) landed with unit 0.
+        constexpr int younger = ((GB + c + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 2 + CL_AHEAD < TOT) ? 1 : 0);
+        cl_wait_vm<8 * younger>();
       }
-      if (c == 0) {
-#pragma unroll
-        for (int ob = 0; ob < NBL; ++ob) cl_landed(acc[ob]);
-      }
-      cl_landed(w[(GB + c) & 3]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        const int g = c * G + gi;
-        if (g < NG) {
-          const int gn = (g + 2 < NG) ? g + 2 : NG - 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<G>([&](auto gi_) {
+      constexpr int gi = decltype(gi_)::value;
+      constexpr int g = c * G + gi;
+      if (failed) return;
+      if constexpr (g < NG) {
+        if constexpr (NUIN > 1 && (g % 8) == 6 && g + 2 < NG) {   // next unit: in LDS before the B fragments of its first group are read (two groups ahead)
+          constexpr int u = (g + 2) / 8;
+          // younger than unit u's requests: the later units' (4 each) and the weight chunks requested in iterations 0..c of this layer
+          long long* dbg = (LAYER == 2 && xc.ts && member == 0 && xbase == xc.buf) ? xc.ts + 48 : nullptr;
+          if (dbg && tid == 0) { dbg[-8 + 2 * u] = (long long)wall_clock64(); }
+          cl_stage_unit<u, 4 * (NUIN - 1 - u) + 8 * cl_issued(GB, TOT, c)>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in, dbg);
+          if (dbg && tid == 0) { dbg[-8 + 2 * u + 1] = (long long)wall_clock64(); }
+          if (K == 256 && u == NUIN - 1 && tid < 48) X[253 * 16 + tid] = S.xyz[tid];   // lin4's input: rows 253..255 carry xyz (over the staged / own zeros)
+          __syncthreads();
+          if (dbg && tid == 0) { dbg[8 + u] = (long long)wall_clock64(); }
+          if (S.fail) { failed = true; return; }
+        }
+        if (wave < ACT) {
+          constexpr int gn = (g + 2 < NG) ? g + 2 : NG - 1;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) b[(g + 2) % 3][s4] = xb[(16 * gn + 4 * s4) * 16];
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int ob = 0; ob < NBL; ++ob)
-              acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[(GB + c) & 3][gi * NBL + ob][s4], b[g % 3][s4], acc[ob], 0, 0, 0);
+          cl_mfma_group<NBL, ACC, CL_RING0 + 32 * ((GB + c) & 3) + 4 * gi * NBL>(b[g % 3][0], b[g % 3][1], b[g % 3][2], b[g % 3][3]);
         }
       }
-    }
+    });
     __builtin_amdgcn_sched_barrier(0);
-  }
-  if (KN > 0) cl_load_start<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>(initNext, start, member, wave, kq);   // lands during the exchange
+  });
+  if (failed) { cl_wait_vm<0>(); return false; }
+  if constexpr (KN > 0) cl_load_start<KN, ON, CL, (LAYER + 1) & 1>(initNext, member, wave, kq);   // lands with the next layer's first unit
   DISTR_XTS(4 * layer);
   __syncthreads();                         // everybody is done reading the layer input
   if (wave < ACT) {
-#pragma unroll
-    for (int ob = 0; ob < NBL; ++ob) {
-      f32x4 v;
+    f32x4 tg;
+    tg[1] = __uint_as_float(tag_out); tg[3] = tg[1];
+    const int sc1 = S.sc1;
+    static_for<NBL>([&](auto ob_) {
+      constexpr int ob = decltype(ob_)::value;
+      f32x4 v = cl_acc_read4<ACC + 4 * ob>();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = __int_as_float(max(__float_as_int(acc[ob][r]), 0));
+        v[r] = __int_as_float(max(__float_as_int(v[r]), 0));
         X[(16 * (rb0 + ob) + 4 * kq + r) * 16 + j] = v[r];
       }
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(slot) + (rb0 + ob) * 64 + lane);
-      if (keep) mask_nibble_or(S, layer, 16 * (rb0 + ob) + 4 * kq, wr_log, j, v);
-    }
+      char* p = slot_out + (size_t)(rb0 + ob) * 2048;
+      f32x4 g0 = tg, g1 = tg;
+      g0[0] = v[0]; g0[2] = v[1]; g1[0] = v[2]; g1[2] = v[3];
+      cl_st((uint32_t)lane * 16u, p, g0, sc1);
+      cl_st((uint32_t)lane * 16u, p + 1024, g1, sc1);
+      if (keep) mask_nibble_or(S, layer, 16 * (rb0 + ob) + 4 * kq, (LAYER == 3) ? 6 : 7, j, v);
+    });
   }
-  // Wait for this wave's slice stores (memory operations of one wave complete in order, so this also waits for the weight
-  // chunks requested above -- they were issued during the layer's last chunks and have normally landed by now).
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
+  if (REQ_OUT) cl_request_units<0, 1>(S, slot_out, wave, lane);
   DISTR_XTS(4 * layer + 1);
-  cl_barrier<CL>(flags, layer, member, xc.epoch, tid, &S.fail);
-  if (S.fail) return;                      // (uniform: written before the barrier's __syncthreads)
-  DISTR_XTS(4 * layer + 2);
-  // other members' slices: float4 index i over the row blocks not owned by this member; all loads first (ONE round trip to the
-  // uncached buffer), then the LDS writes
-  constexpr int OTHER = (RBT - PER) * 64, NLD = (OTHER + NTHREADS - 1) / NTHREADS;
-  f32x4 v[NLD];
-#pragma unroll
-  for (int q = 0; q < NLD; ++q) {
-    const int i = tid + q * NTHREADS;
-    int rb = i >> 6;
-    rb += (rb >= member * PER) ? PER : 0;
-    if (i < OTHER) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slot) + rb * 64 + (i & 63));
-  }
-#pragma unroll
-  for (int q = 0; q < NLD; ++q) {
-    const int i = tid + q * NTHREADS;
-    int rb = i >> 6;
-    const int l = i & 63;
-    rb += (rb >= member * PER) ? PER : 0;
-    const int row = 16 * rb + 4 * (l >> 4), jj = l & 15;
-    if (i < OTHER) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[(row + r) * 16 + jj] = v[q][r];
-      if (keep) mask_nibble_or(S, layer, row, wr_log, jj, v[q]);
-    }
-  }
-  __syncthreads();
-  DISTR_XTS(4 * layer + 3);
+  return true;
 }
 
 // Cluster forward. Every member returns after its last contribution; member 0 returns the pre-tanh value (ray = tid & 15)
 // and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0. On return S.fail != 0 (uniform over the
-// workgroup) means this member gave up (cluster not assembled in time / a barrier timed out): the lead member's caller then
+// workgroup) means this member gave up (cluster not assembled in time / a unit timed out): the lead member's caller then
 // evaluates the tile with mlp_forward16 (S.xyz is untouched), the other members simply leave.
 // ALL_LIN8 (sticky tiles): every member computes lin8 from its own copy of h7 and returns the pre-tanh value (all members then
 // mirror the march update in registers, no broadcast needed). assemble = false: the members are known to be resident (a later
-// march step of the same launch), no arrival / go handshake.
+// march step of the same launch), no arrival / go handshake (S.sc1 keeps the first step's verdict).
 template <int CL, bool KEEP, bool ALL_LIN8 = false>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
-                                                  const float* __restrict__ c4, Smem16CL& S, const Xchg& xc, int cluster, int member,
+                                                  const float* __restrict__ c4, Smem16CLX& S, const Xchg& xc, int cluster, int member,
                                                   bool assemble = true) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int kq = lane >> 4;
   const int ray = tid & 15;
+  cluster = __builtin_amdgcn_readfirstlane(cluster);      // (uniform by construction; the request bases are SGPR operands)
+  member = __builtin_amdgcn_readfirstlane(member);
   float* X = S.X;
-  float* xbase = xc.buf + (size_t)cluster * 2 * 8192;
+  char* xbase = xc.buf + (size_t)cluster * XCLUSTER_BYTES;
   uint32_t* flags = xc.flags + (size_t)cluster * 128;
   const bool lead = (member == 0);
-  f32x4 w[4][8];
   DISTR_XTS(0);
   if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
     S.fail = 0;
-    if (assemble) __hip_atomic_store(flags + member, xc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (assemble) {
+      uint32_t xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      S.sc1 = 1;    // (until the verdict)
+      __hip_atomic_store(flags + member, (xc.epoch << 4) | (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-#pragma unroll
-  for (int c = 0; c < CL_AHEAD; ++c) cl_load_chunk<512, 512, CL>(D16.Wf[1], w[c], c, member, wave, lane);   // lin1's first weights travel while lin0 runs
-  f32x4 sa[4];                                                                                              // start values of the next layer
-  cl_load_start<512, 512, CL>(D.bias[1], sa, member, wave, kq);
+  // lin1's first weights (ring slots 0..2) and start values (accumulator set 1) travel while lin0 runs
+  cl_load_chunk<512, 512, CL, 0, 0>(D16.Wf[1], member, wave, lane);
+  cl_load_chunk<512, 512, CL, 1, 1>(D16.Wf[1], member, wave, lane);
+  cl_load_chunk<512, 512, CL, 2, 2>(D16.Wf[1], member, wave, lane);
+  cl_load_start<512, 512, CL, 1>(D.bias[1], member, wave, kq);
   X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;
   if (KEEP && lead) {   // the rays' mask blocks are OR-ed together nibble by nibble (mask_nibble_or)
     uint4* z = reinterpret_cast<uint4*>(&S.mk[0][0]);
@@ -1277,7 +1485,9 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   {  // lin0 (K = 16 padded): cheaper to compute whole in every member than to exchange
     f32x4 acc[8];
     acc_init16<8>(acc, c0, wave * 128, kq);
+    asm volatile("" ::: CL_CLOB);        // (lin0's accumulators live across this point: not in the fixed registers the ring is landing in)
     dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
+    asm volatile("" ::: CL_CLOB);
     __syncthreads();
     (void)writeback16<8, false>(X, acc, wave * 128, lane);
     if (KEEP && lead) {
@@ -1288,31 +1498,37 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   }
   DISTR_XTS(1);
   if (assemble) {
-    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, xc.test_abort);
-    if (S.fail) return 0.f;
+    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, &S.sc1, xc.test_abort, xc.force_sc1);
+    if (S.fail) { cl_wait_vm<0>(); return 0.f; }
   }
   // position of every layer's chunk 0 in the network-wide chunk sequence (see layer_cl)
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
   static_assert(N1 >= CL_AHEAD, "the initial requests cover lin1's first chunks");
   constexpr int G1 = 0, G2 = G1 + N1, G3 = G2 + N1, G4 = G3 + N3, G5 = G4 + N4, G6 = G5 + N1, G7 = G6 + N1, GT = G7 + N1;
-  layer_cl<512, 512, CL, G1, GT, 512, 512, 512, 256>(D16.Wf[1], D16.Wf[2], D16.Wf[3], w, sa, D.bias[2], S, xc, xbase, flags, 1, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  layer_cl<512, 512, CL, G2, GT, 512, 256, 256, 512>(D16.Wf[2], D16.Wf[3], D16.Wf[4], w, sa, D.bias[3], S, xc, xbase, flags, 2, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  layer_cl<512, 256, CL, G3, GT, 256, 512, 512, 512>(D16.Wf[3], D16.Wf[4], D16.Wf[5], w, sa, c4, S, xc, xbase, flags, 3, member, KEEP && lead, 6);
-  if (S.fail) return 0.f;
-  __syncthreads();
-  if (tid < 48) X[253 * 16 + tid] = S.xyz[tid];
-  __syncthreads();
-  layer_cl<256, 512, CL, G4, GT, 512, 512, 512, 512>(D16.Wf[4], D16.Wf[5], D16.Wf[6], w, sa, D.bias[5], S, xc, xbase, flags, 4, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  layer_cl<512, 512, CL, G5, GT, 512, 512, 512, 512>(D16.Wf[5], D16.Wf[6], D16.Wf[7], w, sa, D.bias[6], S, xc, xbase, flags, 5, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  layer_cl<512, 512, CL, G6, GT, 512, 512, 0, 0>(D16.Wf[6], D16.Wf[7], nullptr, w, sa, D.bias[7], S, xc, xbase, flags, 6, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  layer_cl<512, 512, CL, G7, GT, 0, 0, 0, 0>(D16.Wf[7], nullptr, nullptr, w, sa, nullptr, S, xc, xbase, flags, 7, member, KEEP && lead);
-  if (S.fail) return 0.f;
-  if (!lead && !ALL_LIN8) return 0.f;
+  const bool kp = KEEP && lead;
+  if (!layer_cl<1, 512, 512, CL, G1, GT, 512, 512, 512, 256, true, true>(D16.Wf[1], D16.Wf[2], D16.Wf[3], D.bias[2], S, xc, xbase, member, kp)) return 0.f;
+  if (!layer_cl<2, 512, 512, CL, G2, GT, 512, 256, 256, 512, false, true>(D16.Wf[2], D16.Wf[3], D16.Wf[4], D.bias[3], S, xc, xbase, member, kp)) return 0.f;
+  if (!layer_cl<3, 512, 256, CL, G3, GT, 256, 512, 512, 512, false, true>(D16.Wf[3], D16.Wf[4], D16.Wf[5], c4, S, xc, xbase, member, kp)) return 0.f;
+  if (!layer_cl<4, 256, 512, CL, G4, GT, 512, 512, 512, 512, false, true>(D16.Wf[4], D16.Wf[5], D16.Wf[6], D.bias[5], S, xc, xbase, member, kp)) return 0.f;
+  if (!layer_cl<5, 512, 512, CL, G5, GT, 512, 512, 512, 512, false, true>(D16.Wf[5], D16.Wf[6], D16.Wf[7], D.bias[6], S, xc, xbase, member, kp)) return 0.f;
+  if (!layer_cl<6, 512, 512, CL, G6, GT, 512, 512, 0, 0, false, true>(D16.Wf[6], D16.Wf[7], nullptr, D.bias[7], S, xc, xbase, member, kp)) return 0.f;
+  if (!lead && !ALL_LIN8) {
+    (void)layer_cl<7, 512, 512, CL, G7, GT, 0, 0, 0, 0, false, false>(D16.Wf[7], nullptr, nullptr, nullptr, S, xc, xbase, member, false);
+    return 0.f;                          // (the slice stores complete before the wave ends)
+  }
+  if (!layer_cl<7, 512, 512, CL, G7, GT, 0, 0, 0, 0, false, true>(D16.Wf[7], nullptr, nullptr, nullptr, S, xc, xbase, member, kp)) return 0.f;
+  {  // h7: all four units (nothing is requested after them)
+    const char* slot7 = xbase + ((7 + xc.par) & 1) * XSLOT_BYTES;
+    const uint32_t tag7 = (xc.epoch << 3) | 7u;
+    constexpr int PER7 = 32 / CL;
+    cl_stage_unit<0, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_request_units<1, 4>(S, slot7, wave, lane);
+    cl_stage_unit<1, 8>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<2, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<3, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    __syncthreads();
+    if (S.fail) { cl_wait_vm<0>(); return 0.f; }
+  }
   DISTR_XTS(32);
   {
     float p = 0.f;

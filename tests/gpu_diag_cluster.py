@@ -23,9 +23,20 @@ out = (C.c_int64 * 64)()
 eng.ctx.check(eng.ctx.L.distr_debug_xchg_ts(eng.ctx.h, eng.ctx.stream(), out))
 ts = np.array(list(out), np.int64)
 t0 = ts[0]
-print('lin0 done: %.2f us' % ((ts[1] - t0) / 100.0))
+print('lin0 + assembly done: %.2f us' % ((ts[1] - t0) / 100.0))
+# stamps of cluster 0 / member 0 (distr_mlp.hpp, DISTR_XTS): 4l = end of layer l's k-loop, 4l+1 = own slice stored + next layer's input
+# requested, 4l+3 = first 128 rows of layer l's output staged and visible in LDS (start of layer l+1's k-loop)
+prev = ts[1]
 for l in range(1, 8):
-    a, b, c, d = ts[4 * l: 4 * l + 4]
-    prev = ts[4 * (l - 1) + 3] if l > 1 else ts[1]
-    print('layer %d: compute %.2f | relu+store+drain %.2f | barrier %.2f | read others %.2f   (us)' % (l, (a - prev) / 100.0, (b - a) / 100.0, (c - b) / 100.0, (d - c) / 100.0))
+    a, b = ts[4 * l], ts[4 * l + 1]
+    d = ts[4 * l + 3] if l < 7 else ts[32]
+    print('layer %d: k-loop %.2f | relu+store+request %.2f | hand-off (until %s) %.2f   (us)' % (l, (a - prev) / 100.0, (b - a) / 100.0,
+          'unit 0 staged' if l < 7 else 'all of h7 staged', (d - b) / 100.0))
+    prev = d
 print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))
+# layer 2 (k-loop of lin2, input = lin1's slices): the mid-loop staging of units 1..3 -- begin / end of cl_stage_unit, after its barrier,
+# and how often the unit had to be re-requested (stamps 40..58)
+t2 = ts[4 * 1 + 3]
+for u in (1, 2, 3):
+    print('layer 2 unit %d: stage begins %.2f us into the k-loop, takes %.2f, barrier +%.2f; re-requests %d' %
+          (u, (ts[40 + 2 * u] - t2) / 100.0, (ts[41 + 2 * u] - ts[40 + 2 * u]) / 100.0, (ts[56 + u] - ts[41 + 2 * u]) / 100.0, ts[48 + u]))
