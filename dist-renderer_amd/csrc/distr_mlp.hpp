@@ -765,13 +765,7 @@ struct Smem16CL : Smem16 {
   int32_t ssl[8][16];     // (DISTR_MAX_BUFFER_SIZE rows; kept here, not in registers, across the decoder evaluation)
 };
 
-// cluster tiles: + the landing zone of the granule requests (LDS-DMA; 4 units x 4 requests x 4 waves x 1 KiB, thread-private: a
-// thread reads back exactly the 16 bytes per request its own lane received)
-// The landing zone comes FIRST in the workgroup's LDS (offsets 0 .. 64 KiB - 1): the LDS-DMA destination travels in M0.
-struct SmemStage {
-  alignas(16) unsigned char stage[4 * 4 * 4 * 1024];
-};
-struct Smem16CLX : SmemStage, Smem16CL { };
+using Smem16CLX = Smem16CL;      // (cluster tiles need no landing zone in LDS: the granule requests land in fixed registers)
 
 struct DecoderDev16 {
   const float* Wf[8];   // 16x16x4 A-fragments: float4 ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + i][16g + 4s + kq] : s=0..3 }
@@ -1042,15 +1036,30 @@ constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
 // BEFORE the data lands (garbage, or a memory fault when the reused register held an address) -- round 5's first version of the
 // pipelined exchange did exactly that (profiles/tools/vm_hazard_scan.py finds such accesses in the generated code). So:
 //   * the weight ring (4 chunks x 8 float4), the layers' accumulators and their start values live in FIXED accumulation registers
-//     a[96:255] that only the asm statements below name: the loads target them directly, the MFMAs read their A operand from them and
+//     (ClRegs: a[120:255] for 8 members) that only the asm statements below name: the loads target them directly, the MFMAs read their A operand from them and
 //     accumulate in them (gfx950: loads may write AGPRs, an MFMA takes A / B from either file), v_accvgpr_read moves the finished
-//     rows out. Every statement lists a96..a255 as clobbered, so the compiler keeps nothing of its own there across them; outside
+//     rows out. Every statement lists the fixed range as clobbered, so the compiler keeps nothing of its own there across them; outside
 //     the cluster tile the registers are ordinary (the other roles of k_step use them freely);
-//   * the granule requests are LDS-DMA requests (global_load_lds_dwordx4) into a thread-private landing zone (Smem16CLX::stage),
-//     read back with ordinary LDS loads after the counted wait.
-#define CL_CLOB "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
-constexpr int CL_RING0 = 96;     // chunk slot r, float4 i, element s: a[96 + 32 r + 4 i + s]
-constexpr int CL_ACC0 = 224;     // accumulator set p (= layer & 1), row block ob, register r: a[224 + 16 p + 4 ob + r]
+//   * the granule requests land in fixed registers too (v[224:255]: two slots of 16 per thread); after the counted wait their tags
+//     are compared and their values stored to LDS by asm statements that name those registers. (LDS-DMA into a landing zone in LDS is register-safe as well and was tried first: it delivers 16 KiB per
+//     0.6 us and compute unit -- the 64 KiB of granules of a layer then take longer than the layer's k-loop.)
+#define CL_CLOB8 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define CL_CLOB4 "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define CL_CLOB2 "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+// one statement, clobber list by cluster size (the fixed range is smaller for larger clusters: fewer row blocks per wave)
+#define CL_ASM(CL, ...) do { if constexpr ((CL) == 8) asm volatile(__VA_ARGS__, CL_CLOB8); else if constexpr ((CL) == 4) asm volatile(__VA_ARGS__, CL_CLOB4); \
+                             else asm volatile(__VA_ARGS__, CL_CLOB2); } while (0)
+// Fixed registers of a cluster of CL members (NBLM = row blocks per wave of a 512-row layer = 8 / CL):
+//   accumulator set p (= layer & 1), row block ob, register r:   a[ACC0 + 4 NBLM p + 4 ob + r]        2 x 4 NBLM registers, top of the file
+//   weight ring: chunk slot r, float4 i, element s:              a[RING0 + 32 r + 4 i + s]            128 registers below them
+//   granule landing zone: slot u & 1, request q, dword d:        v[LAND0 + 16 (u & 1) + 4 q + d]      the top 32 ARCHITECTURAL registers
+// CL = 8: a[120:255], CL = 4: a[112:255], CL = 2: a[96:255], and v[224:255] for all. The landing zone is NOT in accumulation registers:
+// a v_accvgpr_read next to running MFMAs costs 30..95 cycles (profiles/ubench/mfma_fillers.log; the first version paid 16 of them per
+// unit), an LDS store straight from a VGPR costs nothing and a tag compare ~12.
+template <int CL>
+struct ClRegs {
+  static constexpr int NBLM = 8 / CL, ACC0 = 256 - 8 * NBLM, RING0 = ACC0 - 128, LAND0 = 224;
+};
 
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -1070,15 +1079,15 @@ __device__ __forceinline__ T* cl_uni(T* p) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
-template <int LO>
+template <int CL, int LO>
 __device__ __forceinline__ void cl_ld_a(uint32_t voff, const void* sbase) {      // a[LO:LO+3] <- 16 bytes at sbase + voff
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%2:%2+3], %0, %1" ::"v"(voff), "s"(cl_uni(sbase)), "n"(LO) : "memory", CL_CLOB);
+  CL_ASM(CL, "s_nop 4\n\tglobal_load_dwordx4 a[%2:%2+3], %0, %1" ::"v"(voff), "s"(cl_uni(sbase)), "n"(LO) : "memory");
 }
 // eight of them in one statement (a weight chunk): a[LO + 4 i : LO + 4 i + 3] <- p_i + voff
-template <int LO>
+template <int CL, int LO>
 __device__ __forceinline__ void cl_ld_a8(uint32_t voff, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5,
                                          const void* p6, const void* p7) {
-  asm volatile("s_nop 4\n\t"
+  CL_ASM(CL, "s_nop 4\n\t"
                "global_load_dwordx4 a[%9+0:%9+3], %0, %1\n\t"
                "global_load_dwordx4 a[%9+4:%9+7], %0, %2\n\t"
                "global_load_dwordx4 a[%9+8:%9+11], %0, %3\n\t"
@@ -1088,20 +1097,20 @@ __device__ __forceinline__ void cl_ld_a8(uint32_t voff, const void* p0, const vo
                "global_load_dwordx4 a[%9+24:%9+27], %0, %7\n\t"
                "global_load_dwordx4 a[%9+28:%9+31], %0, %8"
                ::"v"(voff), "s"(cl_uni(p0)), "s"(cl_uni(p1)), "s"(cl_uni(p2)), "s"(cl_uni(p3)), "s"(cl_uni(p4)), "s"(cl_uni(p5)), "s"(cl_uni(p6)),
-                 "s"(cl_uni(p7)), "n"(LO) : "memory", CL_CLOB);
+                 "s"(cl_uni(p7)), "n"(LO) : "memory");
 }
 // One k-group (16 features = 4 MFMA k-steps) of a wave's NBL row blocks: accumulator block ob = a[AB + 4 ob : AB + 4 ob + 3], its
 // A-fragment for k-step s = a[RB + 4 ob + s], B-fragment of k-step s = b_s. The NBL chains are interleaved, each stays k-ordered.
-template <int NBL, int AB, int RB>
+template <int CL, int NBL, int AB, int RB>
 __device__ __forceinline__ void cl_mfma_group(float b0, float b1, float b2, float b3) {
   if constexpr (NBL == 1) {
-    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+    CL_ASM(CL, "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+1], %1, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+2], %2, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+3], %3, a[%4+0:%4+3]"
-                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : "memory");
   } else if constexpr (NBL == 2) {
-    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+    CL_ASM(CL, "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+4], %0, a[%4+4:%4+7]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+1], %1, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+5], %1, a[%4+4:%4+7]\n\t"
@@ -1109,10 +1118,10 @@ __device__ __forceinline__ void cl_mfma_group(float b0, float b1, float b2, floa
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+6], %2, a[%4+4:%4+7]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+3], %3, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+7], %3, a[%4+4:%4+7]"
-                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : "memory");
   } else {
     static_assert(NBL == 4, "1, 2 or 4 row blocks per wave");
-    asm volatile("v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
+    CL_ASM(CL, "v_mfma_f32_16x16x4_f32 a[%4+0:%4+3], a[%5+0], %0, a[%4+0:%4+3]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+4], %0, a[%4+4:%4+7]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+8], %0, a[%4+8:%4+11]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+12], %0, a[%4+12:%4+15]\n\t"
@@ -1128,25 +1137,55 @@ __device__ __forceinline__ void cl_mfma_group(float b0, float b1, float b2, floa
                  "v_mfma_f32_16x16x4_f32 a[%4+4:%4+7], a[%5+7], %3, a[%4+4:%4+7]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+8:%4+11], a[%5+11], %3, a[%4+8:%4+11]\n\t"
                  "v_mfma_f32_16x16x4_f32 a[%4+12:%4+15], a[%5+15], %3, a[%4+12:%4+15]"
-                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : CL_CLOB);
+                 ::"v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(AB), "n"(RB) : "memory");
   }
 }
 // the four finished rows of accumulator block a[LO:LO+3] (after the MFMA's 8 passes: s_nop)
-template <int LO>
+template <int CL, int LO>
 __device__ __forceinline__ f32x4 cl_acc_read4() {
   float v0, v1, v2, v3;
-  asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %0, a[%4+0]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\tv_accvgpr_read_b32 %2, a[%4+2]\n\t"
-               "v_accvgpr_read_b32 %3, a[%4+3]" : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "n"(LO) : CL_CLOB);
+  CL_ASM(CL, "s_nop 15\n\ts_nop 3\n\tv_accvgpr_read_b32 %0, a[%4+0]\n\tv_accvgpr_read_b32 %1, a[%4+1]\n\tv_accvgpr_read_b32 %2, a[%4+2]\n\t"
+               "v_accvgpr_read_b32 %3, a[%4+3]" : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "n"(LO) : "memory");
   f32x4 v;
   v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
   return v;
 }
-// one LDS-DMA request: lane l's 16 bytes at gsrc (L1-bypassing: polled data) -> LDS bytes lds_dst + 16 l (lds_dst wave-uniform). M0 is
-// the compiler's: saved and restored inside the statement.
-__device__ __forceinline__ void cl_dma16(uint32_t voff, const void* sbase, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(cl_uni(sbase)), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+// the four requests of staging unit U (L1-bypassing: polled data) -> landing registers a[LAND:LAND+15]
+template <int CL, int LAND>
+__device__ __forceinline__ void cl_req4(uint32_t voff, const void* p0, const void* p1, const void* p2, const void* p3) {
+  CL_ASM(CL, "s_nop 4\n\t"
+               "global_load_dwordx4 v[%5+0:%5+3], %0, %1 sc1\n\t"
+               "global_load_dwordx4 v[%5+4:%5+7], %0, %2 sc1\n\t"
+               "global_load_dwordx4 v[%5+8:%5+11], %0, %3 sc1\n\t"
+               "global_load_dwordx4 v[%5+12:%5+15], %0, %4 sc1"
+               ::"v"(voff), "s"(cl_uni(p0)), "s"(cl_uni(p1)), "s"(cl_uni(p2)), "s"(cl_uni(p3)), "n"(LAND) : "memory");
+}
+// ... the granules of entry E (requests 2E, 2E+1 = four rows of one ray) after the counted wait:
+// lanes whose four tags are not all `tag` (as a wave mask: SALU work apart from the four compares)
+template <int CL, int LAND, int E>
+__device__ __forceinline__ unsigned long long cl_land_bad(uint32_t tag) {
+  unsigned long long m;
+  CL_ASM(CL, "v_cmp_ne_u32 vcc, %1, v[%2+1]\n\ts_mov_b64 %0, vcc\n\t"
+             "v_cmp_ne_u32 vcc, %1, v[%2+3]\n\ts_or_b64 %0, %0, vcc\n\t"
+             "v_cmp_ne_u32 vcc, %1, v[%2+5]\n\ts_or_b64 %0, %0, vcc\n\t"
+             "v_cmp_ne_u32 vcc, %1, v[%2+7]\n\ts_or_b64 %0, %0, vcc"
+             : "=&s"(m) : "v"(tag), "n"(LAND + 8 * E) : "memory", "vcc");
+  return m;
+}
+// its four values -> X[row .. row+3][ray] (lds = byte address of X[row][ray]; rows are 64 bytes apart)
+template <int CL, int LAND, int E>
+__device__ __forceinline__ void cl_land_store(uint32_t lds) {
+  CL_ASM(CL, "ds_write2_b32 %0, v[%1+0], v[%1+2] offset1:16\n\tds_write2_b32 %0, v[%1+4], v[%1+6] offset0:32 offset1:48" ::"v"(lds), "n"(LAND + 8 * E) : "memory");
+}
+// ... and their ReLU bits as a nibble (lead member, KEEP): bit r = value r > 0 (on the bit pattern)
+template <int CL, int LAND, int E>
+__device__ __forceinline__ uint32_t cl_land_nibble() {
+  uint32_t nib, t;
+  CL_ASM(CL, "v_med3_i32 %0, v[%2+6], 0, 1\n\tv_med3_i32 %1, v[%2+4], 0, 1\n\tv_lshl_or_b32 %0, %0, 1, %1\n\t"
+             "v_med3_i32 %1, v[%2+2], 0, 1\n\tv_lshl_or_b32 %0, %0, 1, %1\n\t"
+             "v_med3_i32 %1, v[%2+0], 0, 1\n\tv_lshl_or_b32 %0, %0, 1, %1"
+             : "=&v"(nib), "=&v"(t) : "n"(LAND + 8 * E) : "memory");
+  return nib;
 }
 __device__ __forceinline__ void cl_st(uint32_t voff, void* sbase, const f32x4& v, int sc1) {     // (s_nop 1: the store reads its data registers after issue)
   sbase = cl_uni(sbase);
@@ -1155,7 +1194,7 @@ __device__ __forceinline__ void cl_st(uint32_t voff, void* sbase, const f32x4& v
 }
 template <int N>
 __device__ __forceinline__ void cl_wait_vm() {   // (vmcnt has 6 bits: a smaller count only waits for more)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory", CL_CLOB);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
 }
 
 // chunk C of a K x O layer -> ring slot SLOT: this wave's 8 float4 A-fragments (G = 8 / NBL k-groups of its NBL row blocks)
@@ -1166,7 +1205,7 @@ __device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, int 
   const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1)) * Ge::NBL;
   const char* wp = reinterpret_cast<const char*>(Wf) + (size_t)rb0 * 1024;          // float4 index (g*RBT + rb)*64 + lane
   auto at = [&](int i) { return wp + ((size_t)(C * Ge::G + i / Ge::NBL) * Ge::RBT + (i % Ge::NBL)) * 1024; };
-  cl_ld_a8<CL_RING0 + 32 * SLOT>((uint32_t)lane * 16u, at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7));
+  cl_ld_a8<CL, ClRegs<CL>::RING0 + 32 * SLOT>((uint32_t)lane * 16u, at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7));
 }
 
 // start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector) straight into accumulator set P
@@ -1174,12 +1213,12 @@ __device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, int 
 template <int K, int O, int CL, int P>
 __device__ __forceinline__ void cl_load_start(const float* __restrict__ init, int member, int wave, int kq) {
   using Ge = ClGeom<K, O, CL>;
-  static_assert(Ge::NBL <= 4, "an accumulator set holds at most 4 row blocks");
+  static_assert(Ge::NBL <= ClRegs<CL>::NBLM, "an accumulator set holds NBLM row blocks");
   if (wave >= Ge::ACT) return;
   const int rb0 = member * Ge::PER + wave * Ge::NBL;
   static_for<Ge::NBL>([&](auto ob_) {
     constexpr int ob = decltype(ob_)::value;
-    cl_ld_a<CL_ACC0 + 16 * P + 4 * ob>((uint32_t)kq * 16u, init + 16 * (rb0 + ob));
+    cl_ld_a<CL, ClRegs<CL>::ACC0 + 4 * ClRegs<CL>::NBLM * P + 4 * ob>((uint32_t)kq * 16u, init + 16 * (rb0 + ob));
   });
 }
 
@@ -1230,13 +1269,24 @@ __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_
 // nibble with an LDS atomic-or (S.mk is zeroed at the start of the tile). Format of store_mask_chunk: chunk (w, h), word
 // layer*4 + ob, bit r <-> row w*WR + 32*ob + (r&3) + 8*(r>>2) + 4*h, WR = 1 << wr_log = rows per wave of the 32x32 tiles (128; 64
 // for lin3, whose words ob = 2, 3 stay zero). (Re-reading the finished layer from LDS cost 2 us per layer on the lead member.)
+// rb = row0 / 16 is wave-uniform (a wave's entry is a whole 16-row block, lane (kq, jj) holds its rows 4kq .. 4kq+3): with R = 16 rb,
+//   w = R >> wr_log, ob = (R & (WR - 1)) >> 5, h = kq & 1, n = 2 (rb & 1) + (kq >> 1),  idx = [64 w + 4 layer + ob] + 32 h
+// so everything but 64 bytes x (kq & 1) of the address and 4 x (kq >> 1) of the shift is scalar arithmetic; the nibble itself is four
+// clamps to [0, 1] (v_med3_i32 on the bit pattern) and three shift-ors -- about 10 vector instructions per entry instead of 35 (they
+// run beside the MFMAs of the lead member's k-loop, where every vector instruction costs ~13 cycles of matrix time).
+__device__ __forceinline__ void mask_nibble_put(Smem16CL& S, int layer, int rb, int wr_log, int kq, int jj, uint32_t nib) {
+  const int R = 16 * rb, w = R >> wr_log, ob = (R & ((1 << wr_log) - 1)) >> 5;
+  const int idxu = 64 * w + 4 * layer + ob;
+  uint32_t* p = reinterpret_cast<uint32_t*>(&S.mk[jj][0]) + (idxu >> 1) + 16 * (kq & 1);
+  atomicOr(p, nib << (8 * (rb & 1) + 16 * (idxu & 1) + 4 * (kq >> 1)));
+}
+__device__ __forceinline__ uint32_t mask_nibble_of(const f32x4& v) {     // bit r = "the float's integer pattern is positive"
+  const int b0 = min(max(__float_as_int(v[0]), 0), 1), b1 = min(max(__float_as_int(v[1]), 0), 1), b2 = min(max(__float_as_int(v[2]), 0), 1),
+            b3 = min(max(__float_as_int(v[3]), 0), 1);
+  return (uint32_t)(((((b3 << 1) | b2) << 1 | b1) << 1) | b0);
+}
 __device__ __forceinline__ void mask_nibble_or(Smem16CL& S, int layer, int row0, int wr_log, int jj, const f32x4& v) {
-  // (bit = "the float's integer pattern is positive", exactly the test of the other tile sizes' write-back)
-  const uint32_t nib = (__float_as_int(v[0]) > 0 ? 1u : 0u) | (__float_as_int(v[1]) > 0 ? 2u : 0u) | (__float_as_int(v[2]) > 0 ? 4u : 0u) |
-                       (__float_as_int(v[3]) > 0 ? 8u : 0u);
-  const int w = row0 >> wr_log, rem = row0 & ((1 << wr_log) - 1), ob = rem >> 5, rr = rem & 31, h = (rr >> 2) & 1, n = rr >> 3;
-  const int idx = (w * 2 + h) * 32 + layer * 4 + ob;
-  atomicOr(reinterpret_cast<uint32_t*>(&S.mk[jj][0]) + (idx >> 1), nib << (4 * n + 16 * (idx & 1)));
+  mask_nibble_put(S, layer, row0 >> 4, wr_log, (row0 >> 2) & 3, jj, mask_nibble_of(v));
 }
 
 // Requests the NU staging units of a slot (a layer's whole output, all members' slices incl. the own one: the request pattern must
@@ -1245,66 +1295,57 @@ __device__ __forceinline__ void mask_nibble_or(Smem16CL& S, int layer, int row0,
 // [U0, U1): unit 0 is requested right behind the own slice store (and re-requested until its granules are there: the exposed
 // hand-off); the others only once unit 0 has been seen -- requested together with it they would all come back stale (every member
 // publishes at about the same time) and each would cost its own re-request round trip in the middle of the k-loop.
-template <int U0, int U1>
-__device__ __forceinline__ void cl_request_units(Smem16CLX& S, const char* slot, int wave, int lane) {
-#pragma unroll
-  for (int u = U0; u < U1; ++u)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      cl_dma16((uint32_t)lane * 16u, slot + ((size_t)(8 * u + wave + 4 * (q >> 1)) * 2048 + (q & 1) * 1024), lds_off(S.stage) + (uint32_t)(((u * 4 + q) * 4 + wave) * 1024));
+// Unit u = row blocks 8u .. 8u+7; wave w takes row blocks 8u + w and 8u + w + 4 of it, both halves: request q = 2e + h -> row block
+// 8u + w + 4e, half h (the whole layer output incl. the own slice: the request pattern must not depend on the member).
+template <int CL, int U>
+__device__ __forceinline__ void cl_request_unit(const char* slot, int wave, int lane) {      // -> landing slot U & 1
+  const char* b = slot + (size_t)(8 * U + wave) * 2048;
+  cl_req4<CL, ClRegs<CL>::LAND0 + 16 * (U & 1)>((uint32_t)lane * 16u, b, b + 1024, b + 4 * 2048, b + 4 * 2048 + 1024);
 }
 
-// Stages unit U of the slot into X: waits (statically counted, NWAIT younger requests) for its four requests, reads them back from
-// the landing zone, validates the granule tags, re-requests until they are all there (bounded), writes the values of the OTHER
+// Request schedule of a layer input of NU units over the two landing slots: unit 0 behind the producer's own slice store; units 1 and
+// 2 when unit 0 has been staged (slot 0 is free again); unit 3 when unit 1 has been staged.
+// Stages unit U of the slot into X: waits (statically counted, NWAIT younger requests) for its four requests, moves them out of
+// the landing registers, validates the granule tags, re-requests until they are all there (bounded), writes the values of the OTHER
 // members' rows to X (the own rows were written at write-back) and ORs their ReLU bits into the mask blocks (lead member, KEEP).
 // The caller adds the barrier. own rows of the producing layer: row blocks [own_lo, own_lo + own_n).
-template <int U, int NWAIT>
-__device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CLX& S, int tid, bool keep, int layer_of_data,
+template <int CL, int U, int NWAIT>
+__device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CL& S, int tid, bool keep, int layer_of_data,
                                               int wr_log, long long* dbg = nullptr) {
+  constexpr int LAND = ClRegs<CL>::LAND0 + 16 * (U & 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lw = tid & 63, kq = lw >> 4, j = lw & 15;
   cl_wait_vm<NWAIT>();
-  const f32x4* land = reinterpret_cast<const f32x4*>(S.stage + (U * 16 + wave) * 1024) + lw;     // + q * 256 float4
-  bool own[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) { const int rb = U * 8 + wave + 4 * e; own[e] = (unsigned)(rb - own_lo) < (unsigned)own_n; }
-  // pass 1: only the tags (few registers live next to the weight ring)
+  if (dbg && tid == 0) dbg[4 + U] = (long long)wall_clock64();     // (debug: the unit's requests have landed)
+  // own rows of the producing layer (wave-uniform: a wave's two entries are whole row blocks): neither checked nor copied
+  const bool own0 = (unsigned)(U * 8 + wave - own_lo) < (unsigned)own_n, own1 = (unsigned)(U * 8 + wave + 4 - own_lo) < (unsigned)own_n;
   auto bad = [&]() {
-    uint32_t x = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 g = land[q * 256];
-      x |= own[q >> 1] ? 0u : ((__float_as_uint(g[1]) ^ tag) | (__float_as_uint(g[3]) ^ tag));
-    }
-    return x != 0u;
+    unsigned long long m = 0ull;
+    if (!own0) m |= cl_land_bad<CL, LAND, 0>(tag);
+    if (!own1) m |= cl_land_bad<CL, LAND, 1>(tag);
+    return m != 0ull;
   };
   int nre = 0;                                  // (debug: re-requests of this unit)
-  if (__ballot(bad()) != 0ull) {
+  if (bad()) {
     const long long t0 = (long long)wall_clock64();
     for (;;) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        cl_dma16((uint32_t)lw * 16u, slot + ((size_t)(8 * U + wave + 4 * (q >> 1)) * 2048 + (q & 1) * 1024), lds_off(S.stage) + (uint32_t)(((U * 4 + q) * 4 + wave) * 1024));
+      cl_request_unit<CL, U>(slot, wave, lw);
       cl_wait_vm<0>();
       ++nre;
-      if (__ballot(bad()) == 0ull) break;
+      if (!bad()) break;
       if (*reinterpret_cast<volatile int32_t*>(&S.fail) != 0) break;
       if ((long long)wall_clock64() - t0 > CL_T_BARRIER) { S.fail = 1; break; }
     }
   }
   if (dbg && tid == 0) dbg[U] = nre;
-  // pass 2: the values, one entry (four rows of one ray) at a time
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    if (!own[e]) {
-      const int row = 16 * (U * 8 + wave + 4 * e) + 4 * kq;
-      const f32x4 g0 = land[(2 * e) * 256], g1 = land[(2 * e + 1) * 256];
-      f32x4 v;
-      v[0] = g0[0]; v[1] = g0[2]; v[2] = g1[0]; v[3] = g1[2];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S.X[(row + r) * 16 + j] = v[r];
-      if (keep) mask_nibble_or(S, layer_of_data, row, wr_log, j, v);
-    }
+  const uint32_t x0 = lds_off(S.X) + (uint32_t)(((16 * (U * 8 + wave) + 4 * kq) * 16 + j) * 4);
+  if (!own0) {
+    cl_land_store<CL, LAND, 0>(x0);
+    if (keep) mask_nibble_put(S, layer_of_data, U * 8 + wave, wr_log, kq, j, cl_land_nibble<CL, LAND, 0>());
+  }
+  if (!own1) {
+    cl_land_store<CL, LAND, 1>(x0 + 4 * 16 * 16 * 4);
+    if (keep) mask_nibble_put(S, layer_of_data, U * 8 + wave + 4, wr_log, kq, j, cl_land_nibble<CL, LAND, 1>());
   }
 }
 
@@ -1335,7 +1376,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   constexpr int RBT = Ge::RBT, PER = Ge::PER, NBL = Ge::NBL, ACT = Ge::ACT, G = Ge::G, NCH = Ge::NCH, NG = Ge::NG;
   constexpr int NCHN = (KN > 0) ? GeN::NCH : 0, NCHN2 = (KN2 > 0) ? GeN2::NCH : 0;
   constexpr int NUIN = FIRST ? 0 : K / 128, PERIN = (K / 16) / CL, NUOUT = O / 128;
-  constexpr int ACC = CL_ACC0 + 16 * (LAYER & 1);
+  constexpr int ACC = ClRegs<CL>::ACC0 + 4 * ClRegs<CL>::NBLM * (LAYER & 1);
   constexpr int layer = LAYER;
   static_assert(FIRST || (NG % 8 == 0 && PERIN >= 1), "staging units of 8 k-groups");
   const int tid = threadIdx.x;
@@ -1349,8 +1390,10 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   const int rb0 = member * PER + wave * NBL;
   bool failed = false;
   if constexpr (NUIN > 0) {   // the first 128 input rows (the only exposed hand-off of the layer); everything requested earlier has landed with them
-    cl_stage_unit<0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
-    cl_request_units<1, NUIN>(S, slot_in, wave, lane);       // (before this layer's first weight request: the counts below rely on it)
+    cl_stage_unit<CL, 0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+    // (units 1 and 2 before this layer's first weight request: the counts below rely on it)
+    if constexpr (NUIN > 1) cl_request_unit<CL, 1>(slot_in, wave, lane);
+    if constexpr (NUIN > 2) cl_request_unit<CL, 2>(slot_in, wave, lane);
     __syncthreads();
     if (S.fail) { cl_wait_vm<0>(); return false; }
     DISTR_XTS(4 * (layer - 1) + 3);
@@ -1373,11 +1416,12 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
         // iteration's chunk
         if constexpr (GB + CL_AHEAD < TOT) cl_wait_vm<8>(); else cl_wait_vm<0>();
       } else if constexpr (c >= CL_AHEAD) {
-        // chunk c was requested in iteration c - CL_AHEAD of this layer: younger = the weight requests of iterations c-2 .. c (the
-        // layer's input units were requested before, the output units are requested after the loop). Chunks c < CL_AHEAD were requested
-        // during the previous layer(s), before this layer's input units: they (and the start values) landed with unit 0.
+        // chunk c was requested in iteration c - CL_AHEAD of this layer: younger = the weight requests of iterations c-2 .. c, and unit 3
+        // of the input if it was requested (behind the staging of unit 1, iteration CS1) in iterations c-3 .. c-1. Chunks c < CL_AHEAD were
+        // requested during the previous layer(s), before this layer's input units: they (and the start values) landed with unit 0.
         constexpr int younger = ((GB + c + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + c - 2 + CL_AHEAD < TOT) ? 1 : 0);
-        cl_wait_vm<8 * younger>();
+        constexpr int CS1 = 6 / G;
+        cl_wait_vm<8 * younger + ((NUIN == 4 && c - 3 <= CS1 && CS1 <= c - 1) ? 4 : 0)>();
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1388,10 +1432,15 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
       if constexpr (g < NG) {
         if constexpr (NUIN > 1 && (g % 8) == 6 && g + 2 < NG) {   // next unit: in LDS before the B fragments of its first group are read (two groups ahead)
           constexpr int u = (g + 2) / 8;
-          // younger than unit u's requests: the later units' (4 each) and the weight chunks requested in iterations 0..c of this layer
+          // younger than unit u's requests: unit 1: unit 2's + the weight chunks of iterations 0..c; unit 2: unit 3's (requested behind the
+          // staging of unit 1) + the chunks of iterations 0..c; unit 3: the chunks of the iterations after unit 1's staging .. c
+          constexpr int CS1 = 6 / G;
+          constexpr int NW = (u == 1) ? ((NUIN > 2 ? 4 : 0) + 8 * cl_issued(GB, TOT, c)) : (u == 2) ? ((NUIN > 3 ? 4 : 0) + 8 * cl_issued(GB, TOT, c))
+                                      : 8 * (cl_issued(GB, TOT, c) - cl_issued(GB, TOT, CS1));
           long long* dbg = (LAYER == 2 && xc.ts && member == 0 && xbase == xc.buf) ? xc.ts + 48 : nullptr;
           if (dbg && tid == 0) { dbg[-8 + 2 * u] = (long long)wall_clock64(); }
-          cl_stage_unit<u, 4 * (NUIN - 1 - u) + 8 * cl_issued(GB, TOT, c)>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in, dbg);
+          cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in, dbg);
+          if constexpr (u == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
           if (dbg && tid == 0) { dbg[-8 + 2 * u + 1] = (long long)wall_clock64(); }
           if (K == 256 && u == NUIN - 1 && tid < 48) X[253 * 16 + tid] = S.xyz[tid];   // lin4's input: rows 253..255 carry xyz (over the staged / own zeros)
           __syncthreads();
@@ -1403,7 +1452,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) b[(g + 2) % 3][s4] = xb[(16 * gn + 4 * s4) * 16];
           __builtin_amdgcn_sched_barrier(0);
-          cl_mfma_group<NBL, ACC, CL_RING0 + 32 * ((GB + c) & 3) + 4 * gi * NBL>(b[g % 3][0], b[g % 3][1], b[g % 3][2], b[g % 3][3]);
+          cl_mfma_group<CL, NBL, ACC, ClRegs<CL>::RING0 + 32 * ((GB + c) & 3) + 4 * gi * NBL>(b[g % 3][0], b[g % 3][1], b[g % 3][2], b[g % 3][3]);
         }
       }
     });
@@ -1419,7 +1468,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     const int sc1 = S.sc1;
     static_for<NBL>([&](auto ob_) {
       constexpr int ob = decltype(ob_)::value;
-      f32x4 v = cl_acc_read4<ACC + 4 * ob>();
+      f32x4 v = cl_acc_read4<CL, ACC + 4 * ob>();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = __int_as_float(max(__float_as_int(v[r]), 0));
@@ -1430,10 +1479,10 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
       g0[0] = v[0]; g0[2] = v[1]; g1[0] = v[2]; g1[2] = v[3];
       cl_st((uint32_t)lane * 16u, p, g0, sc1);
       cl_st((uint32_t)lane * 16u, p + 1024, g1, sc1);
-      if (keep) mask_nibble_or(S, layer, 16 * (rb0 + ob) + 4 * kq, (LAYER == 3) ? 6 : 7, j, v);
+      if (keep) mask_nibble_put(S, layer, rb0 + ob, (LAYER == 3) ? 6 : 7, kq, j, mask_nibble_of(v));
     });
   }
-  if (REQ_OUT) cl_request_units<0, 1>(S, slot_out, wave, lane);
+  if (REQ_OUT) cl_request_unit<CL, 0>(slot_out, wave, lane);
   DISTR_XTS(4 * layer + 1);
   return true;
 }
@@ -1485,14 +1534,14 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   {  // lin0 (K = 16 padded): cheaper to compute whole in every member than to exchange
     f32x4 acc[8];
     acc_init16<8>(acc, c0, wave * 128, kq);
-    asm volatile("" ::: CL_CLOB);        // (lin0's accumulators live across this point: not in the fixed registers the ring is landing in)
+    CL_ASM(CL, "" ::: "memory");        // (lin0's accumulators live across this point: not in the fixed registers the ring is landing in)
     dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
-    asm volatile("" ::: CL_CLOB);
+    CL_ASM(CL, "" ::: "memory");
     __syncthreads();
     (void)writeback16<8, false>(X, acc, wave * 128, lane);
     if (KEEP && lead) {
 #pragma unroll
-      for (int ob = 0; ob < 8; ++ob) mask_nibble_or(S, 0, wave * 128 + 16 * ob + 4 * kq, 7, ray, acc[ob]);
+      for (int ob = 0; ob < 8; ++ob) mask_nibble_put(S, 0, wave * 8 + ob, 7, kq, ray, mask_nibble_of(acc[ob]));
     }
     __syncthreads();
   }
@@ -1521,11 +1570,13 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     const char* slot7 = xbase + ((7 + xc.par) & 1) * XSLOT_BYTES;
     const uint32_t tag7 = (xc.epoch << 3) | 7u;
     constexpr int PER7 = 32 / CL;
-    cl_stage_unit<0, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
-    cl_request_units<1, 4>(S, slot7, wave, lane);
-    cl_stage_unit<1, 8>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
-    cl_stage_unit<2, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
-    cl_stage_unit<3, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<CL, 0, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_request_unit<CL, 1>(slot7, wave, lane);
+    cl_request_unit<CL, 2>(slot7, wave, lane);
+    cl_stage_unit<CL, 1, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_request_unit<CL, 3>(slot7, wave, lane);
+    cl_stage_unit<CL, 2, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<CL, 3, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
     __syncthreads();
     if (S.fail) { cl_wait_vm<0>(); return 0.f; }
   }

@@ -38,5 +38,5 @@ print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))
 # and how often the unit had to be re-requested (stamps 40..58)
 t2 = ts[4 * 1 + 3]
 for u in (1, 2, 3):
-    print('layer 2 unit %d: stage begins %.2f us into the k-loop, takes %.2f, barrier +%.2f; re-requests %d' %
-          (u, (ts[40 + 2 * u] - t2) / 100.0, (ts[41 + 2 * u] - ts[40 + 2 * u]) / 100.0, (ts[56 + u] - ts[41 + 2 * u]) / 100.0, ts[48 + u]))
+    print('layer 2 unit %d: stage begins %.2f us into the k-loop, waits %.2f for its requests, then takes %.2f, barrier +%.2f; re-requests %d' %
+          (u, (ts[40 + 2 * u] - t2) / 100.0, (ts[52 + u] - ts[40 + 2 * u]) / 100.0, (ts[41 + 2 * u] - ts[52 + u]) / 100.0, (ts[56 + u] - ts[41 + 2 * u]) / 100.0, ts[48 + u]))
