@@ -1311,12 +1311,11 @@ __device__ __forceinline__ void cl_request_unit(const char* slot, int wave, int 
 // The caller adds the barrier. own rows of the producing layer: row blocks [own_lo, own_lo + own_n).
 template <int CL, int U, int NWAIT>
 __device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CL& S, int tid, bool keep, int layer_of_data,
-                                              int wr_log, long long* dbg = nullptr) {
+                                              int wr_log) {
   constexpr int LAND = ClRegs<CL>::LAND0 + 16 * (U & 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lw = tid & 63, kq = lw >> 4, j = lw & 15;
   cl_wait_vm<NWAIT>();
-  if (dbg && tid == 0) dbg[4 + U] = (long long)wall_clock64();     // (debug: the unit's requests have landed)
   // own rows of the producing layer (wave-uniform: a wave's two entries are whole row blocks): neither checked nor copied
   const bool own0 = (unsigned)(U * 8 + wave - own_lo) < (unsigned)own_n, own1 = (unsigned)(U * 8 + wave + 4 - own_lo) < (unsigned)own_n;
   auto bad = [&]() {
@@ -1325,19 +1324,16 @@ __device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, in
     if (!own1) m |= cl_land_bad<CL, LAND, 1>(tag);
     return m != 0ull;
   };
-  int nre = 0;                                  // (debug: re-requests of this unit)
   if (bad()) {
     const long long t0 = (long long)wall_clock64();
     for (;;) {
       cl_request_unit<CL, U>(slot, wave, lw);
       cl_wait_vm<0>();
-      ++nre;
       if (!bad()) break;
       if (*reinterpret_cast<volatile int32_t*>(&S.fail) != 0) break;
       if ((long long)wall_clock64() - t0 > CL_T_BARRIER) { S.fail = 1; break; }
     }
   }
-  if (dbg && tid == 0) dbg[U] = nre;
   const uint32_t x0 = lds_off(S.X) + (uint32_t)(((16 * (U * 8 + wave) + 4 * kq) * 16 + j) * 4);
   if (!own0) {
     cl_land_store<CL, LAND, 0>(x0);
@@ -1437,14 +1433,10 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
           constexpr int CS1 = 6 / G;
           constexpr int NW = (u == 1) ? ((NUIN > 2 ? 4 : 0) + 8 * cl_issued(GB, TOT, c)) : (u == 2) ? ((NUIN > 3 ? 4 : 0) + 8 * cl_issued(GB, TOT, c))
                                       : 8 * (cl_issued(GB, TOT, c) - cl_issued(GB, TOT, CS1));
-          long long* dbg = (LAYER == 2 && xc.ts && member == 0 && xbase == xc.buf) ? xc.ts + 48 : nullptr;
-          if (dbg && tid == 0) { dbg[-8 + 2 * u] = (long long)wall_clock64(); }
-          cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in, dbg);
+          cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
           if constexpr (u == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
-          if (dbg && tid == 0) { dbg[-8 + 2 * u + 1] = (long long)wall_clock64(); }
           if (K == 256 && u == NUIN - 1 && tid < 48) X[253 * 16 + tid] = S.xyz[tid];   // lin4's input: rows 253..255 carry xyz (over the staged / own zeros)
           __syncthreads();
-          if (dbg && tid == 0) { dbg[8 + u] = (long long)wall_clock64(); }
           if (S.fail) { failed = true; return; }
         }
         if (wave < ACT) {

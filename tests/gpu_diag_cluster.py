@@ -34,9 +34,3 @@ for l in range(1, 8):
           'unit 0 staged' if l < 7 else 'all of h7 staged', (d - b) / 100.0))
     prev = d
 print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))
-# layer 2 (k-loop of lin2, input = lin1's slices): the mid-loop staging of units 1..3 -- begin / end of cl_stage_unit, after its barrier,
-# and how often the unit had to be re-requested (stamps 40..58)
-t2 = ts[4 * 1 + 3]
-for u in (1, 2, 3):
-    print('layer 2 unit %d: stage begins %.2f us into the k-loop, waits %.2f for its requests, then takes %.2f, barrier +%.2f; re-requests %d' %
-          (u, (ts[40 + 2 * u] - t2) / 100.0, (ts[52 + u] - ts[40 + 2 * u]) / 100.0, (ts[41 + 2 * u] - ts[52 + u]) / 100.0, (ts[56 + u] - ts[41 + 2 * u]) / 100.0, ts[48 + u]))
