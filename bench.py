@@ -197,8 +197,13 @@ def main():
                     help='several whole images on one GPU (c5 at N <= 2: a batch of shapes): render them one by one on the stream pool instead '
                          'of as ONE batched launch sequence (distr_render_forward_batch)')
     ap.add_argument('--items', default=None,
-                    help='diagnostics (N = 1, c3): the work items of the step as view:r0:r1[,view:r0:r1...] instead of one whole view, e.g. '
-                         '"5:0:512,7:480:512" = what rank 5 renders under the N = 8 balance plan (profiles/r02_view_balance.md)')
+                    help='diagnostics (N = 1): the work items of the step as view:r0:r1[,view:r0:r1...] instead of one whole view, e.g. '
+                         '"5:0:512,7:480:512" = what rank 5 renders under the N = 8 balance plan (profiles/r02_view_balance.md); with '
+                         '--workload c5 as shape:r0:r1[,...] = the pieces one rank of a row-band partition renders (profiles/plan_check_c5.py)')
+    ap.add_argument('--no-weighted-rows', action='store_true',
+                    help='c5 at N > 1: keep the cost-blind row partition (default: after timing it, the ranks exchange the surface-pixel '
+                         'counts of their bands and their step times, every rank computes the same cost-weighted cut '
+                         '(distr.parallel.shard_rows_plan) and the step is timed again under it)')
     ap.add_argument('--no-balance', action='store_true',
                     help='c3 at N > 1: keep exactly one whole view per GPU (default: five untimed calibration steps before the warm-up, in which the '
                          'ranks exchange step times and row cost profiles and the slowest views hand row bands to the fastest ranks, '
@@ -252,6 +257,11 @@ def main():
     if c5:
         n_shapes = 4
         items = [(img, 0, r0, r1) for (img, r0, r1) in parallel.shard_rows(n_shapes, H, rank, world)]
+        if args.items:
+            # single-GPU diagnostic (profiles/plan_check_c5.py): the pieces ONE rank of an N-rank partition renders, as shape:r0:r1[,...]
+            if world != 1:
+                raise SystemExit('--items is a single-GPU diagnostic')
+            items = [(int(a), 0, int(b), int(c)) for (a, b, c) in (it.split(':') for it in args.items.split(','))]
         lats_np = [latent_np] + [fixture.make_latent(1234 + i) for i in range(1, n_shapes)]
     else:
         n_shapes = 1
@@ -310,10 +320,12 @@ def main():
             outs = functions.render_band_call(eng, cur['cfg'], lats[shape], Rt, Tt, r0, r1)
         if (r0, r1) == (0, H):
             last_mask[v] = outs[1]
+        band_mask[(shape, r0, r1)] = outs[1]
         return image_loss(outs, r0, r1, (shape, v))
 
     last = {}              # gradients of the most recent step (reported as a norm: lets two runs be compared)
     last_mask = {}         # rendered mask of every whole view of the most recent step (row cost profile of the balancer)
+    band_mask = {}         # rendered mask of every piece of the most recent step (c5: row weights of the cost-weighted cut)
     local_ms = []          # (calibration only) GPU milliseconds of this rank's own work of a step, without the wait in the all-reduce
 
     def step(measure=False):
@@ -334,6 +346,7 @@ def main():
             losses = []
             for b, it in enumerate(whole):
                 last_mask[it[1]] = outs[1][b]
+                band_mask[(it[0], 0, H)] = outs[1][b]
                 losses.append(image_loss(tuple(o[b] for o in outs), 0, H, (it[0], it[1])))
             rest = [it for it in items if (it[2], it[3]) != (0, H)]
             more = [pool.run(i, lambda it=it: render_item(*it)) for i, it in enumerate(rest)]
@@ -458,6 +471,67 @@ def main():
                 plan_tried, plan = plan, None                        # the balancer did not pay on this node: report it, run unbalanced
                 apply_plan(plan0)
                 timing['balance_plan_tried'] = plan_tried
+
+    # ---- c5 at N > 1: the cost-weighted cut. The region above timed the cost-blind partition (equal row-unit
+    # runs). Now: every rank counts the surface pixels of its pieces per 4-row unit, one packed all-reduce makes the profile of all
+    # four images known everywhere, the ranks all-gather what their pieces cost them, and every rank computes the same weighted cut
+    # (distr.parallel.shard_rows_plan: cuts stay multiples of 4 rows, bands keep their 4-row halo) -- refined once from the times
+    # measured under it. Same total work, timed with the same protocol; BOTH timings are reported, `value` switches to the weighted
+    # one only when it wins by more than BALANCE_MARGIN.
+    row_plan = None
+    if c5 and world > 1 and not args.no_weighted_rows and not args.items:
+        timing['uniform'] = elapsed
+        snaps['uniform'] = snap
+        upi = (H + 3) // 4
+        plan_u = [parallel.shard_rows(n_shapes, H, r, world) for r in range(world)]
+
+        def apply_rows(pl):
+            items[:] = [(img, 0, r0, r1) for (img, r0, r1) in pl[rank]]
+            pool.streams = _StreamPool(min(len(items), args.streams) if len(items) > 1 else 0, dev).streams
+
+        def gathered_weights():
+            cnt = torch.zeros(n_shapes * upi, device=dev)
+            for (shape, _, r0, r1) in items:
+                m = band_mask.get((shape, r0, r1))
+                if m is None:
+                    continue
+                rows = m.reshape(r1 - r0, W).float().sum(1)
+                pad = (-(r1 - r0)) % 4
+                if pad:
+                    rows = torch.cat([rows, torch.zeros(pad, device=dev)])
+                cnt[shape * upi + r0 // 4: shape * upi + r0 // 4 + rows.numel() // 4] += rows.reshape(-1, 4).sum(1)
+            parallel.allreduce_packed([cnt])
+            c = cnt.cpu().numpy()
+            return [parallel.row_weights_from_counts(c[i * upi:(i + 1) * upi].tolist(), W, 4, H) for i in range(n_shapes)]
+
+        step(measure=True)
+        step(measure=True)
+        loads_u = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(local_ms[-1], device=dev)
+        weights = parallel.refine_row_weights(gathered_weights(), plan_u, loads_u, H)
+        row_plan = parallel.shard_rows_plan(n_shapes, H, world, 4, weights)
+        apply_rows(row_plan)
+        step()
+        calibration_steps = 3
+        if not fake:
+            step(measure=True)
+            loads_w = parallel.allgather_scalar(local_ms[-1], device=dev)
+            weights = parallel.refine_row_weights(weights, row_plan, loads_w, H)
+            row_plan = parallel.shard_rows_plan(n_shapes, H, world, 4, weights)
+            apply_rows(row_plan)
+            step()
+            calibration_steps = 5
+        if row_plan == plan_u:
+            row_plan = None                                          # nothing moved
+        else:
+            el_w, snap_w = timed_region()
+            timing['weighted'] = el_w
+            snaps['weighted'] = snap_w
+            diag['weighted_rows'] = rank_diagnostics()
+            if el_w < (1.0 - BALANCE_MARGIN) * elapsed or fake:
+                elapsed, snaps['chosen'] = el_w, snap_w
+            else:
+                timing['row_plan_tried'], row_plan = row_plan, None
+                apply_rows(plan_u)
 
     # ---- serial check (N > 1, outside the timed regions): rank 0 renders ALL the job's images itself, one whole image after the
     # other (the sum the reference accumulates serially before its single backward(), core/inv_optimizer/optimize_multi.py:62-81),
@@ -669,6 +743,12 @@ def main():
                 c['value_switch_margin'] = BALANCE_MARGIN
                 if timing.get('balance_plan_tried'):
                     c['balance_plan_tried'] = timing['balance_plan_tried']
+            if c5 and timing.get('uniform') is not None:
+                c['uniform_rows_ms_per_step'] = 1e3 * timing['uniform'] / args.steps
+                c['weighted_rows_ms_per_step'] = (1e3 * timing['weighted'] / args.steps) if timing.get('weighted') is not None else None
+                c['value_is'] = 'weighted_rows' if row_plan else 'uniform_rows'
+                c['value_switch_margin'] = BALANCE_MARGIN
+                c['row_plan'] = row_plan if row_plan else timing.get('row_plan_tried')
             # which of the timed modes is the N = 1 protocol run on N GPUs (one whole view per GPU, nothing moved between ranks): efficiency
             # against the N = 1 line compares like with like only through this mode's number
             c['n1_protocol_equivalent'] = 'unbalanced' if not c5 else 'row_bands (strong scaling: no N = 1 analogue per rank; compare total ms_per_step)'

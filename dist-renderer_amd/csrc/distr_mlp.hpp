@@ -1435,7 +1435,9 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
                                       : 8 * (cl_issued(GB, TOT, c) - cl_issued(GB, TOT, CS1));
           cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
           if constexpr (u == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
-          if (K == 256 && u == NUIN - 1 && tid < 48) X[253 * 16 + tid] = S.xyz[tid];   // lin4's input: rows 253..255 carry xyz (over the staged / own zeros)
+          // lin4's input: rows 253..255 carry xyz, over the (staged or own) zeros of lin3's padded rows -- written by the wave that staged
+          // that row block (wave 3: row block 15), behind its own copy in program order (another wave would race with it)
+          if (K == 256 && u == NUIN - 1 && wave == 3 && lane < 48) X[253 * 16 + lane] = S.xyz[lane];
           __syncthreads();
           if (S.fail) { failed = true; return; }
         }

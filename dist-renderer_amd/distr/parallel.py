@@ -28,9 +28,11 @@ def init_from_env(backend=None):
         kw = {}
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-            if backend == 'nccl':
+            if backend == 'nccl' and torch.cuda.device_count() >= int(os.environ.get('LOCAL_WORLD_SIZE', world)):
                 # bind the communicator to THIS rank's GPU at creation: RCCL then initialises eagerly on that device and
-                # barrier() / the first collective do not have to guess it from "the device under the current context"
+                # barrier() / the first collective do not have to guess it from "the device under the current context".
+                # (Fewer GPUs than local ranks -- a mis-launched job -- keeps the lazy path: the caller's own check reports
+                # "RCCL ranks cannot share a device" instead of an RCCL error from inside the constructor.)
                 kw['device_id'] = torch.device('cuda', local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
@@ -41,14 +43,26 @@ def shard_views(num_views, rank, world_size):
     return list(range(rank, num_views, world_size))
 
 
-def shard_rows(num_images, H, rank, world_size, align=4):
+def shard_rows(num_images, H, rank, world_size, align=4, weights=None, fixed=0.0):
     """Strong-scaling partition of `num_images` H-row images over the ranks (shape-major, then row
-    bands whose height is a multiple of `align` = 4 px so the 4x4 pyramid parents stay intact): the num_images*ceil(H/4)
+    bands whose height is a multiple of `align` = 4 px so the 4x4 pyramid parents stay intact, core/sdfrenderer/renderer.py:732-749;
+    depth2normal reaches across a cut through a 4-row halo, core/utils/render_utils.py:31-37): the num_images*ceil(H/4)
     row units are cut into world_size contiguous runs. Returns this rank's [(image, r0, r1), ...]; over all ranks the
-    pieces tile every image exactly once. Each piece is rendered with distr.functions.render_band_call."""
-    upi = (H + align - 1) // align                    # row units per image
-    total = num_images * upi
-    lo, hi = (rank * total) // world_size, ((rank + 1) * total) // world_size
+    pieces tile every image exactly once. Each piece is rendered with distr.functions.render_band_call.
+    weights = None: runs of equal unit COUNT (cost-blind). weights[image][unit] = relative cost of every row unit (row_profile of a
+    calibration render of every image; row_weights_from_counts): runs of (nearly) equal total COST -- the rows of an image are far from
+    equally expensive (the object sits in the middle; top and bottom rows only hold rays that cross the sphere without a surface).
+    `fixed` = cost of opening one more band, in the unit of `weights` (a band's latency-bound march tail does not shrink with
+    the band). A pure function of its arguments: every rank computes the same partition."""
+    if weights is None:
+        upi = (H + align - 1) // align                    # row units per image
+        total = num_images * upi
+        lo, hi = (rank * total) // world_size, ((rank + 1) * total) // world_size
+        return _units_to_pieces(lo, hi, upi, H, align)
+    return shard_rows_plan(num_images, H, world_size, align, weights, fixed)[rank]
+
+
+def _units_to_pieces(lo, hi, upi, H, align):
     out = []
     u = lo
     while u < hi:
@@ -57,6 +71,84 @@ def shard_rows(num_images, H, rank, world_size, align=4):
         out.append((img, (u - img * upi) * align, min(H, (end - img * upi) * align)))
         u = end
     return out
+
+
+def shard_rows_plan(num_images, H, world_size, align=4, weights=None, fixed=0.0):
+    """plan[rank] = [(image, r0, r1), ...] of the cost-weighted cut (see shard_rows). Greedy left to right: rank r takes units until it
+    holds its share of what is left (remaining cost / remaining ranks, rounded to the nearer unit boundary; every opened band adds
+    `fixed`), never so many that a later rank would get none. Contiguous, 4-row aligned, every unit exactly once."""
+    upi = (H + align - 1) // align
+    total_units = num_images * upi
+    if weights is None:
+        return [_units_to_pieces((r * total_units) // world_size, ((r + 1) * total_units) // world_size, upi, H, align) for r in range(world_size)]
+    cost = []
+    for img in range(num_images):
+        w = list(weights[img]) if (weights[img] is not None and len(weights[img]) == upi) else [1.0] * upi
+        cost.extend(max(float(x), 0.0) for x in w)
+    if sum(cost) <= 0.0:
+        cost = [1.0] * total_units
+    remaining = sum(cost)
+    cuts = [0]
+    u = 0
+    for r in range(world_size - 1):
+        ranks_left = world_size - r
+        target = remaining / ranks_left
+        must_leave = min(ranks_left - 1, total_units - u)       # a unit for each later rank while units last
+        acc = 0.0
+        start = u
+        while u < total_units - must_leave:
+            opens = (u == start) or (u % upi == 0)              # the first unit of a piece: a new band
+            c = cost[u] + (fixed if opens else 0.0)
+            if u > start and acc + 0.5 * c > target:
+                break
+            acc += c
+            u += 1
+        # a cut within 2 % of the rank's share of an image boundary moves onto it (no band of a few rows; symmetric images cut in halves
+        # stay exact halves instead of drifting by a unit per rank)
+        for b in ((u // upi) * upi, (u // upi + 1) * upi):
+            if start < b <= total_units - must_leave and b != u:
+                lo_, hi_ = min(b, u), max(b, u)
+                if sum(cost[lo_:hi_]) <= 0.02 * target:
+                    u = b
+                    break
+        remaining -= sum(cost[start:u])
+        cuts.append(u)
+    cuts.append(total_units)
+    return [_units_to_pieces(cuts[r], cuts[r + 1], upi, H, align) for r in range(world_size)]
+
+
+def row_weights_from_counts(counts, W, align=4, H=None):
+    """counts[unit] = surface pixels (rendered mask == 1) in every `align`-row unit of one image -> relative cost per unit, the same
+    model as row_profile: a surface pixel counts 1, a background pixel BG_WEIGHT. (`H`: the last unit may hold fewer rows.)"""
+    out = []
+    n = len(counts)
+    for u, c in enumerate(counts):
+        rows = align if (H is None or (u + 1) * align <= H) else max(H - u * align, 0)
+        out.append(BG_WEIGHT * W * rows + (1.0 - BG_WEIGHT) * float(c))
+    return out
+
+
+def refine_row_weights(weights, plan, loads, H, align=4):
+    """One feedback step of the cost-weighted cut: `loads[r]` = what rank r measured for its pieces under `plan`. The weights of every
+    rank's units are scaled by (measured share / predicted share), clamped to [0.5, 2]: bands that hold the object's silhouette rows
+    (grazing rays: long marches) cost more per surface pixel than the profile says, and every band pays a latency-bound tail the
+    profile does not know. Returns new weights; shard_rows_plan(..., weights=new) is the refined cut."""
+    upi = (H + align - 1) // align
+    new = [list(w) if w is not None and len(w) == upi else [1.0] * upi for w in weights]
+    pred = []
+    for r, pieces in enumerate(plan):
+        pred.append(sum(sum(new[img][r0 // align:(r1 + align - 1) // align]) for (img, r0, r1) in pieces))
+    tp, tl = sum(pred), sum(loads)
+    if tp <= 0 or tl <= 0:
+        return new
+    for r, pieces in enumerate(plan):
+        if pred[r] <= 0:
+            continue
+        k = min(2.0, max(0.5, (loads[r] / tl) / (pred[r] / tp)))
+        for (img, r0, r1) in pieces:
+            for u in range(r0 // align, (r1 + align - 1) // align):
+                new[img][u] *= k
+    return new
 
 
 def is_distributed(group=None):

@@ -187,6 +187,70 @@ def test_row_sharding_tiles_every_image_once():
     assert parallel.shard_rows(4, 1024, 1, 2) == [(2, 0, 1024), (3, 0, 1024)]
 
 
+def test_weighted_row_sharding_tiles_every_image_once_and_balances_cost():
+    """the cost-weighted C5 cut (distr.parallel.shard_rows(..., weights=)): for N in 1..8 and 16 the pieces tile every
+    image exactly once, every cut is a multiple of 4 rows (the 4x4 pyramid parents, core/sdfrenderer/renderer.py:732-749), the cut is a
+    pure function of its arguments (every rank computes it), it balances the COST it was given (slowest / mean <= 1.03 where the
+    cost-blind cut is off by tens of per cent), equal weights reproduce the image-boundary cuts of the cost-blind partition, and one
+    feedback step (refine_row_weights) moves rows away from a rank that measured slower than predicted."""
+    from distr import parallel
+    n, H, W, align = 4, 1024, 1024, 4
+    upi = H // align
+    rs = np.random.RandomState(3)
+    weights = []
+    for i in range(n):           # an object in the middle rows of every image, different size / position per shape
+        rows = np.arange(upi)
+        counts = 4 * W * 0.6 * np.exp(-((rows - (110 + 15 * i)) / (38.0 + 6 * i)) ** 2)
+        weights.append(parallel.row_weights_from_counts(counts.tolist(), W, align, H))
+
+    def load(plan, w):
+        return [sum(sum(w[img][r0 // align:(r1 + align - 1) // align]) for (img, r0, r1) in pieces) for pieces in plan]
+
+    for world in list(range(1, 9)) + [16]:
+        plan = parallel.shard_rows_plan(n, H, world, align, weights)
+        assert plan == parallel.shard_rows_plan(n, H, world, align, [list(w) for w in weights])          # deterministic
+        cover = np.zeros((n, H), np.int32)
+        for r, pieces in enumerate(plan):
+            assert pieces == parallel.shard_rows(n, H, r, world, align, weights)
+            assert len(pieces) >= 1
+            for (img, r0, r1) in pieces:
+                assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H) and r0 < r1
+                cover[img, r0:r1] += 1
+        assert (cover == 1).all(), world
+        lw = load(plan, weights)
+        assert max(lw) <= 1.03 * (sum(lw) / world), (world, lw)
+        if world in (2, 8, 16):
+            blind = [parallel.shard_rows(n, H, r, world) for r in range(world)]
+            lb = load(blind, weights)
+            assert max(lb) / (sum(lb) / world) >= max(lw) / (sum(lw) / world) - 1e-9
+    # the cost-blind cut of 8 ranks over these images is visibly unbalanced (what the weights are for)
+    lb = load([parallel.shard_rows(n, H, r, 8) for r in range(8)], weights)
+    assert max(lb) / (sum(lb) / 8) > 1.10
+    # equal weights: the same partition as the cost-blind one wherever that one cuts on unit boundaries
+    eq = [[1.0] * upi for _ in range(n)]
+    for world in (1, 2, 4, 8):
+        assert parallel.shard_rows_plan(n, H, world, align, eq) == [parallel.shard_rows(n, H, r, world) for r in range(world)]
+    # odd image height (last unit short) and fewer units than ranks
+    for (n2, H2, world) in [(1, 70, 4), (3, 64, 16), (2, 10, 8)]:
+        w2 = [list(rs.rand((H2 + 3) // 4) + 0.1) for _ in range(n2)]
+        cover = np.zeros((n2, H2), np.int32)
+        for pieces in parallel.shard_rows_plan(n2, H2, world, 4, w2):
+            for (img, r0, r1) in pieces:
+                assert r0 % 4 == 0 and (r1 % 4 == 0 or r1 == H2) and r0 < r1
+                cover[img, r0:r1] += 1
+        assert (cover == 1).all()
+    # feedback: rank 2 measured 40 % more than its share -> its pieces shrink in the refined cut
+    plan = parallel.shard_rows_plan(n, H, 8, align, weights)
+    lw = load(plan, weights)
+    measured = [x * (1.4 if r == 2 else 1.0) for r, x in enumerate(lw)]
+    w2 = parallel.refine_row_weights(weights, plan, measured, H, align)
+    plan2 = parallel.shard_rows_plan(n, H, 8, align, w2)
+    rows = lambda pieces: sum(r1 - r0 for (_, r0, r1) in pieces)
+    assert rows(plan2[2]) < rows(plan[2])
+    l2 = load(plan2, w2)
+    assert max(l2) <= 1.03 * (sum(l2) / 8)
+
+
 def test_c_abi_from_plain_c(libdistr, tmp_path):
     """include/distr.h compiles as C (gcc -std=c99 -pedantic) and a plain-C program resolves every entry point from the
     shared library and runs the GPU-free calls."""
