@@ -55,6 +55,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FLOP_PER_EVAL = 3146752          # 1 573 376 MAC per point with the latent columns hoisted
+ROW_BAND_FIXED = 0.05            # c5 cost-weighted cut: cost of opening one more band, as a fraction of a whole image's cost (measured: two half-image
+                                 # bands cost 7-14 % more than the image, profiles/r05_plan_check_c5_n8.md)
+ROW_FEEDBACK_ROUNDS = 3          # ... and how many measure-and-refine rounds the calibration may take (the best measured cut is kept)
 BALANCE_MARGIN = 0.02            # N > 1: the balanced timing becomes `value` only when it beats the unbalanced one by more than this
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
@@ -508,18 +511,25 @@ def main():
         step(measure=True)
         loads_u = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(local_ms[-1], device=dev)
         weights = parallel.refine_row_weights(gathered_weights(), plan_u, loads_u, H)
-        row_plan = parallel.shard_rows_plan(n_shapes, H, world, 4, weights)
+        fixed = ROW_BAND_FIXED * sum(sum(w) for w in weights) / n_shapes          # cost of opening one more band (a band's latency-bound tail)
+        best = (max(loads_u), None)                                               # (slowest rank's ms, plan); None = the cost-blind cut
+        calibration_steps = 2
+        for _ in range(1 if fake else ROW_FEEDBACK_ROUNDS):
+            cand = parallel.shard_rows_plan(n_shapes, H, world, 4, weights, fixed)
+            if cand == plan_u:
+                break
+            apply_rows(cand)
+            step()                                                                # new band shapes: allocator
+            step(measure=True)
+            calibration_steps += 2
+            loads_w = [float(x) for x in fake.split(',')] if fake else parallel.allgather_scalar(local_ms[-1], device=dev)
+            if max(loads_w) < best[0] or fake:
+                best = (max(loads_w), cand)
+            weights = parallel.refine_row_weights(weights, cand, loads_w, H)
+        row_plan = best[1] if best[1] is not None else plan_u
         apply_rows(row_plan)
         step()
-        calibration_steps = 3
-        if not fake:
-            step(measure=True)
-            loads_w = parallel.allgather_scalar(local_ms[-1], device=dev)
-            weights = parallel.refine_row_weights(weights, row_plan, loads_w, H)
-            row_plan = parallel.shard_rows_plan(n_shapes, H, world, 4, weights)
-            apply_rows(row_plan)
-            step()
-            calibration_steps = 5
+        calibration_steps += 1
         if row_plan == plan_u:
             row_plan = None                                          # nothing moved
         else:

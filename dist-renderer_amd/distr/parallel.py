@@ -92,7 +92,10 @@ def shard_rows_plan(num_images, H, world_size, align=4, weights=None, fixed=0.0)
     u = 0
     for r in range(world_size - 1):
         ranks_left = world_size - r
-        target = remaining / ranks_left
+        # a rank's load = the cost of its units + `fixed` per piece; pieces still to be opened ~ one per remaining rank + one per image
+        # boundary ahead (a run that crosses it opens a second band)
+        bounds_ahead = (total_units - 1) // upi - u // upi
+        target = (remaining + fixed * (ranks_left + bounds_ahead)) / ranks_left
         must_leave = min(ranks_left - 1, total_units - u)       # a unit for each later rank while units last
         acc = 0.0
         start = u

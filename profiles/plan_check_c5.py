@@ -3,10 +3,10 @@ bands) -- NOT a scaling measurement: every rank's pieces of the N = 2 / 4 / 8 pa
 loss + backward, the step of `bench.py --workload c5`), one rank after the other. What it shows is how evenly a partition spreads the
 COST: predicted efficiency = (N = 1 step / N) / slowest rank. It cannot see the all-reduce or a node's fabric.
 
-Three partitions per N: the cost-blind one (distr.parallel.shard_rows: equal row-unit runs), the cost-weighted one (shard_rows_plan with the
-row profile of a calibration render of every shape, surface pixel = 1, background pixel = BG_WEIGHT) and the weighted one after ONE
-feedback step (refine_row_weights with the times measured under the first weighted cut) -- what `bench.py --workload c5 --gpus N` does
-before its second timed region.
+Per N: the cost-blind partition (distr.parallel.shard_rows: equal row-unit runs) and up to bench.ROW_FEEDBACK_ROUNDS cost-weighted ones
+(shard_rows_plan with the row profile of the rendered masks of every shape -- surface pixel = 1, background pixel = BG_WEIGHT, a fixed
+cost per opened band -- each scaled by the measured / predicted share of every rank under the previous cut, refine_row_weights): what
+`bench.py --workload c5 --gpus N` does in its calibration before its second timed region.
 
     python profiles/plan_check_c5.py gpurun_out/r05_plan [--steps 3] [--n 2,4,8]      -> r05_plan_check_c5_n{2,4,8}.md in that directory
 """
@@ -105,14 +105,13 @@ def main():
                  'ALONE on one MI355X, one rank after the other (`profiles/plan_check_c5.py`, %d timed steps per rank after one warm-up). N = 1 (the four' % args.steps,
                  'shapes as one batched launch sequence): **%.1f ms per step**. Predicted efficiency = (N = 1 / N) / slowest rank: what the partition' % n1,
                  'alone would cost on N GPUs -- the all-reduce (one ~4 KiB packed buffer) and the node are not in it.', '']
-        plans = [('cost-blind (`shard_rows`: equal row-unit runs)', [parallel.shard_rows(N_SHAPES, H, r, N) for r in range(N)])]
-        plans.append(('cost-weighted (`shard_rows_plan`, row profile of a calibration render: surface pixel 1, background pixel %.3f)' % parallel.BG_WEIGHT,
-                      parallel.shard_rows_plan(N_SHAPES, H, N, 4, weights0)))
+        fixed = bench.ROW_BAND_FIXED * sum(sum(w) for w in weights0) / N_SHAPES
         summary = []
-        weights = weights0
-        k = 0
-        while k < len(plans):
-            title, plan = plans[k]
+        weights = None
+        plan = [parallel.shard_rows(N_SHAPES, H, r, N) for r in range(N)]
+        title = 'cost-blind (`shard_rows`: equal row-unit runs)'
+        seen = []
+        for rnd in range(bench.ROW_FEEDBACK_ROUNDS + 1):
             loads = [time_items(pieces) for pieces in plan]
             lines += ['## %s' % title, '', '| rank | pieces (shape: rows) | rows | measured ms |', '|---|---|---|---|']
             for r, pieces in enumerate(plan):
@@ -121,16 +120,23 @@ def main():
             lines += ['', 'slowest rank %.1f ms, mean %.1f ms, slowest / mean %.3f; predicted efficiency (%.1f / %d) / %.1f = **%.3f**' % (
                 slow, mean, slow / mean, n1, N, slow, (n1 / N) / slow), '']
             summary.append((title.split(' (')[0], slow, mean, (n1 / N) / slow))
-            if k == 1:     # one feedback step from the measured loads of the first weighted cut
-                weights = parallel.refine_row_weights(weights0, plan, loads, H)
-                plans.append(('cost-weighted after one feedback step (`refine_row_weights` with the times above)', parallel.shard_rows_plan(N_SHAPES, H, N, 4, weights)))
-            k += 1
+            seen.append(plan)
+            # what bench.py --workload c5 --gpus N does in its calibration: weights from the rendered masks, scaled by measured / predicted share
+            weights = parallel.refine_row_weights(weights0 if weights is None else weights, plan, loads, H)
+            plan = parallel.shard_rows_plan(N_SHAPES, H, N, 4, weights, fixed)
+            title = 'cost-weighted, feedback round %d (`shard_rows_plan`: row profile of the rendered masks -- surface pixel 1, background %.3f, %.0f %% of an image per opened band -- scaled by measured / predicted share of every rank, `refine_row_weights`)' % (
+                rnd + 1, parallel.BG_WEIGHT, 100 * bench.ROW_BAND_FIXED)
+            if plan in seen:
+                break
+        best = min(summary, key=lambda t: t[1])
+        lines += ['`bench.py --workload c5 --gpus %d` keeps the cut with the fastest slowest rank among these (here: %s, predicted efficiency %.3f) and times it' % (N, best[0], best[3]),
+                  'next to the cost-blind one; `value` switches only when it wins by more than %.0f %%.' % (100 * bench.BALANCE_MARGIN), '']
         lines += ['## summary', '', '| partition | slowest rank ms | mean ms | slowest / mean | predicted efficiency |', '|---|---|---|---|---|']
         for (t, slow, mean, eff) in summary:
             lines.append('| %s | %.1f | %.1f | %.3f | %.3f |' % (t, slow, mean, slow / mean, eff))
         lines += ['', 'Sum of the ranks\' times vs N = 1: the bands of a partition cost more in total than the four whole images as one batch (every band pays',
-                  'its own latency-bound march tail and a 4-row depth2normal halo, and a rank\'s pieces do not share launches): mean x N = %.1f ms against %.1f ms.' % (
-                      summary[-1][2] * N, n1), '']
+                  'its own latency-bound march tail and a 4-row depth2normal halo, and a rank\'s pieces do not share launches): mean x N = %.1f ms (cost-blind) against %.1f ms.' % (
+                      summary[0][2] * N, n1), '']
         path = os.path.join(args.out, 'r05_plan_check_c5_n%d.md' % N)
         open(path, 'w').write('\n'.join(lines))
         print('\n'.join(lines[-12:]))
