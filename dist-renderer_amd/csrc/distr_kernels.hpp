@@ -761,7 +761,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
                                               int tile, int member, int64_t base, int64_t count) {
   constexpr int TILE = 16;
   const int tid = threadIdx.x;
-  const bool lead = member == 0;
+  const bool lead = member == cl_lead(8);
   const int32_t* list = live_sel(V, A.step);
   const float* c0 = V.C->c0;
   const float* c4 = V.C->c4;
@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
       else if (cl == 4) pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
       else pre = mlp_forward16_cl<2, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
     } else pre = 0.f;
-    if (member != 0) return;            // only the lead member runs the epilogue
+    if (member != cl_lead(cl)) return;   // only the lead member runs the epilogue
     clustered = S.fail == 0;
     if (!clustered) {
       // the cluster did not assemble (compute units held by other streams / ranks) or a barrier timed out: the lead member

@@ -1160,17 +1160,14 @@ __device__ __forceinline__ void cl_req4(uint32_t voff, const void* p0, const voi
                "global_load_dwordx4 v[%5+12:%5+15], %0, %4 sc1"
                ::"v"(voff), "s"(cl_uni(p0)), "s"(cl_uni(p1)), "s"(cl_uni(p2)), "s"(cl_uni(p3)), "n"(LAND) : "memory");
 }
-// ... the granules of entry E (requests 2E, 2E+1 = four rows of one ray) after the counted wait:
-// lanes whose four tags are not all `tag` (as a wave mask: SALU work apart from the four compares)
+// ... the granules of the unit after the counted wait. Tag check of entry E (requests 2E, 2E+1 = four rows of one ray): the byte-wise
+// sum of absolute differences of its four tags against `tag`, added to acc -- 0 iff every tag matched. One vector instruction per
+// tag and no scalar round trip (a v_cmp / s_or pair per tag measured 0.16 us per unit beside the MFMAs: ~40 cycles a pair).
 template <int CL, int LAND, int E>
-__device__ __forceinline__ unsigned long long cl_land_bad(uint32_t tag) {
-  unsigned long long m;
-  CL_ASM(CL, "v_cmp_ne_u32 vcc, %1, v[%2+1]\n\ts_mov_b64 %0, vcc\n\t"
-             "v_cmp_ne_u32 vcc, %1, v[%2+3]\n\ts_or_b64 %0, %0, vcc\n\t"
-             "v_cmp_ne_u32 vcc, %1, v[%2+5]\n\ts_or_b64 %0, %0, vcc\n\t"
-             "v_cmp_ne_u32 vcc, %1, v[%2+7]\n\ts_or_b64 %0, %0, vcc"
-             : "=&s"(m) : "v"(tag), "n"(LAND + 8 * E) : "memory", "vcc");
-  return m;
+__device__ __forceinline__ uint32_t cl_land_diff(uint32_t tag, uint32_t acc) {
+  CL_ASM(CL, "v_sad_u8 %0, v[%2+1], %1, %0\n\tv_sad_u8 %0, v[%2+3], %1, %0\n\tv_sad_u8 %0, v[%2+5], %1, %0\n\tv_sad_u8 %0, v[%2+7], %1, %0"
+             : "+v"(acc) : "v"(tag), "n"(LAND + 8 * E) : "memory");
+  return acc;
 }
 // its four values -> X[row .. row+3][ray] (lds = byte address of X[row][ray]; rows are 64 bytes apart)
 template <int CL, int LAND, int E>
@@ -1225,11 +1222,18 @@ __device__ __forceinline__ void cl_load_start(const float* __restrict__ init, in
 // Assembly of a cluster (see CL_T_*). Returns with *fail set (all threads see it after the barrier) when this member must not
 // take part: the lead then evaluates the tile alone, the others leave. *sc1 (LDS, valid when the cluster assembled) = 1: the
 // members sit on more than one XCD, slices must be stored write-through.
+// The LEAD member of a cluster (it coordinates the assembly, runs the tile's epilogue -- march update, selected rows, mask blocks --
+// and evaluates the tile alone if the cluster breaks up) is its LAST member, not its first: everything only the lead does (the ReLU
+// bits of every staged unit, the epilogue of a sticky step) delays ITS slice, and a layer's k-loop consumes the slices in member
+// order -- the last member's rows are needed ~1.5 us after the first member's, so up to that much lead-only work is hidden, while
+// the same work on member 0 stalls every member at the start of every layer.
+__device__ __forceinline__ constexpr int cl_lead(int cl) { return cl - 1; }
+
 template <int CL>
 __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int32_t* sc1, int test_abort, int force_sc1) {
   if (tid < 64) {
     const long long t0 = (long long)wall_clock64();
-    if (member == 0) {
+    if (member == cl_lead(CL)) {
       bool ok = false, mixed = false;
       for (;;) {
         const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (epoch << 4);
@@ -1319,10 +1323,10 @@ __device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, in
   // own rows of the producing layer (wave-uniform: a wave's two entries are whole row blocks): neither checked nor copied
   const bool own0 = (unsigned)(U * 8 + wave - own_lo) < (unsigned)own_n, own1 = (unsigned)(U * 8 + wave + 4 - own_lo) < (unsigned)own_n;
   auto bad = [&]() {
-    unsigned long long m = 0ull;
-    if (!own0) m |= cl_land_bad<CL, LAND, 0>(tag);
-    if (!own1) m |= cl_land_bad<CL, LAND, 1>(tag);
-    return m != 0ull;
+    uint32_t d = 0u;
+    if (!own0) d = cl_land_diff<CL, LAND, 0>(tag, d);
+    if (!own1) d = cl_land_diff<CL, LAND, 1>(tag, d);
+    return __ballot(d != 0u) != 0ull;
   };
   if (bad()) {
     const long long t0 = (long long)wall_clock64();
@@ -1384,7 +1388,6 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   const uint32_t tag_in = (xc.epoch << 3) | (uint32_t)(layer - 1), tag_out = (xc.epoch << 3) | (uint32_t)layer;
   constexpr int wr_in = (LAYER - 1 == 3) ? 6 : 7;
   const int rb0 = member * PER + wave * NBL;
-  bool failed = false;
   if constexpr (NUIN > 0) {   // the first 128 input rows (the only exposed hand-off of the layer); everything requested earlier has landed with them
     cl_stage_unit<CL, 0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
     // (units 1 and 2 before this layer's first weight request: the counts below rely on it)
@@ -1400,7 +1403,6 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   for (int s4 = 0; s4 < 4; ++s4) { b[0][s4] = xb[(4 * s4) * 16]; b[1][s4] = xb[(16 * (NG > 1 ? 1 : 0) + 4 * s4) * 16]; }
   static_for<NCH>([&](auto c_) {
     constexpr int c = decltype(c_)::value;
-    if (failed) return;
     constexpr int t = c + CL_AHEAD;
     if constexpr (t < NCH) cl_load_chunk<K, O, CL, (GB + t) & 3, t>(Wf, member, wave, lane);
     else if constexpr (t - NCH < NCHN) cl_load_chunk<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL, (GB + t) & 3, t - NCH>(WfNext, member, wave, lane);
@@ -1424,8 +1426,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     static_for<G>([&](auto gi_) {
       constexpr int gi = decltype(gi_)::value;
       constexpr int g = c * G + gi;
-      if (failed) return;
-      if constexpr (g < NG) {
+        if constexpr (g < NG) {
         if constexpr (NUIN > 1 && (g % 8) == 6 && g + 2 < NG) {   // next unit: in LDS before the B fragments of its first group are read (two groups ahead)
           constexpr int u = (g + 2) / 8;
           // younger than unit u's requests: unit 1: unit 2's + the weight chunks of iterations 0..c; unit 2: unit 3's (requested behind the
@@ -1439,7 +1440,6 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
           // that row block (wave 3: row block 15), behind its own copy in program order (another wave would race with it)
           if (K == 256 && u == NUIN - 1 && wave == 3 && lane < 48) X[253 * 16 + lane] = S.xyz[lane];
           __syncthreads();
-          if (S.fail) { failed = true; return; }
         }
         if (wave < ACT) {
           constexpr int gn = (g + 2 < NG) ? g + 2 : NG - 1;
@@ -1452,10 +1452,12 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     });
     __builtin_amdgcn_sched_barrier(0);
   });
-  if (failed) { cl_wait_vm<0>(); return false; }
   if constexpr (KN > 0) cl_load_start<KN, ON, CL, (LAYER + 1) & 1>(initNext, member, wave, kq);   // lands with the next layer's first unit
   DISTR_XTS(4 * layer);
   __syncthreads();                         // everybody is done reading the layer input
+  // A member that gave up inside this layer (a unit never arrived) must not publish: its rows are garbage. (S.fail is looked at here
+  // and after the first unit only: a later unit that times out ends its wait and the layer finishes on whatever was there.)
+  if (NUIN > 1 && S.fail) { cl_wait_vm<0>(); return false; }
   if (wave < ACT) {
     f32x4 tg;
     tg[1] = __uint_as_float(tag_out); tg[3] = tg[1];
@@ -1502,7 +1504,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   float* X = S.X;
   char* xbase = xc.buf + (size_t)cluster * XCLUSTER_BYTES;
   uint32_t* flags = xc.flags + (size_t)cluster * 128;
-  const bool lead = (member == 0);
+  const bool lead = (member == CL - 1);      // the LAST member leads (see cl_lead)
   DISTR_XTS(0);
   if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
     S.fail = 0;
