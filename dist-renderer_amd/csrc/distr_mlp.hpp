@@ -1007,7 +1007,9 @@ constexpr int XCLUSTER_BYTES = 2 * XSLOT_BYTES;
 constexpr long long CL_T_ARRIVE = 30 * 100;      // 30 us (members of a cluster are dispatched within ~1 us of each other when CUs are free)
 constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for the lead's verdict
 constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per staging unit
-#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); __builtin_amdgcn_s_waitcnt(0); } } while (0)
+#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); \
+    if ((i) == 0 || (i) == 32) xc.ts[40 + ((i) >> 5)] = (long long)__builtin_readcyclecounter();   /* shader clock of the phase: stamps 40 / 41 */ \
+    __builtin_amdgcn_s_waitcnt(0); } } while (0)
 
 
 // Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
@@ -1043,7 +1045,7 @@ constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
 //   * the granule requests land in fixed registers too (v[224:255]: two slots of 16 per thread); after the counted wait their tags
 //     are compared and their values stored to LDS by asm statements that name those registers. (LDS-DMA into a landing zone in LDS is register-safe as well and was tried first: it delivers 16 KiB per
 //     0.6 us and compute unit -- the 64 KiB of granules of a layer then take longer than the layer's k-loop.)
-#define CL_CLOB8 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define CL_CLOB8 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
 #define CL_CLOB4 "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 #define CL_CLOB2 "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 // one statement, clobber list by cluster size (the fixed range is smaller for larger clusters: fewer row blocks per wave)
@@ -1203,6 +1205,181 @@ __device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, int 
   const char* wp = reinterpret_cast<const char*>(Wf) + (size_t)rb0 * 1024;          // float4 index (g*RBT + rb)*64 + lane
   auto at = [&](int i) { return wp + ((size_t)(C * Ge::G + i / Ge::NBL) * Ge::RBT + (i % Ge::NBL)) * 1024; };
   cl_ld_a8<CL, ClRegs<CL>::RING0 + 32 * SLOT>((uint32_t)lane * 16u, at(0), at(1), at(2), at(3), at(4), at(5), at(6), at(7));
+}
+
+// ---- 8 members: the k-loop of a unit (8 k-groups = 32 dependent MFMAs of a wave's ONE 16-row block) as two hand-scheduled statements.
+// Between two MFMAs on the same accumulator every instruction that makes the wave leave the MFMA stream costs ~43 cycles on top of
+// the MFMA's 32 (MI355X_MICROARCH.md price list; with one statement per k-group a 512-feature layer measured 5660 cycles for 4096 of
+// MFMAs at 2.4 GHz). So everything else travels INSIDE the statements, in the shadow of the dependent MFMAs: the B fragments
+// (ds_read2st64 two k-groups ahead into four fixed 4-register buffers v[208:223]), their lgkmcnt waits, the wait for the weight
+// chunk and the eight requests of the chunk three further on. Statement A = groups 0..5 (the next unit is staged behind it),
+// statement B = groups 6, 7 (reads the next unit's first two groups: its rows are in LDS by then).
+__device__ __forceinline__ void cl8_b_prologue(uint32_t xb) {      // B fragments of groups 0, 1 of a layer's first unit
+  CL_ASM(8, "ds_read2st64_b32 v[208:209], %0 offset0:0 offset1:1\n\t"
+               "ds_read2st64_b32 v[210:211], %0 offset0:2 offset1:3\n\t"
+               "ds_read2st64_b32 v[212:213], %0 offset0:4 offset1:5\n\t"
+               "ds_read2st64_b32 v[214:215], %0 offset0:6 offset1:7"
+         ::"v"(xb) : "memory");
+}
+template <int AB, int RB, int NWAIT, int NRB>
+__device__ __forceinline__ void cl8_unit_a(uint32_t xb, uint32_t voff, const char* const (&p)[8]) {
+  CL_ASM(8, "s_nop 4\n\t"
+               "s_waitcnt vmcnt(%12)\n\t"
+               "ds_read2st64_b32 v[216:217], %0 offset0:8 offset1:9\n\t"
+               "ds_read2st64_b32 v[218:219], %0 offset0:10 offset1:11\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+0], v208, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+0:%13+3], %1, %2\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+1], v209, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+4:%13+7], %1, %3\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+2], v210, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+3], v211, a[%10:%10+3]\n\t"
+               "ds_read2st64_b32 v[220:221], %0 offset0:12 offset1:13\n\t"
+               "ds_read2st64_b32 v[222:223], %0 offset0:14 offset1:15\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+4], v212, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+8:%13+11], %1, %4\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+5], v213, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+12:%13+15], %1, %5\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+6], v214, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+7], v215, a[%10:%10+3]\n\t"
+               "ds_read2st64_b32 v[208:209], %0 offset0:16 offset1:17\n\t"
+               "ds_read2st64_b32 v[210:211], %0 offset0:18 offset1:19\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+8], v216, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+16:%13+19], %1, %6\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+9], v217, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+20:%13+23], %1, %7\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+10], v218, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+11], v219, a[%10:%10+3]\n\t"
+               "ds_read2st64_b32 v[212:213], %0 offset0:20 offset1:21\n\t"
+               "ds_read2st64_b32 v[214:215], %0 offset0:22 offset1:23\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+12], v220, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+24:%13+27], %1, %8\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+13], v221, a[%10:%10+3]\n\t"
+               "global_load_dwordx4 a[%13+28:%13+31], %1, %9\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+14], v222, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+15], v223, a[%10:%10+3]\n\t"
+               "ds_read2st64_b32 v[216:217], %0 offset0:24 offset1:25\n\t"
+               "ds_read2st64_b32 v[218:219], %0 offset0:26 offset1:27\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+16], v208, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+17], v209, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+18], v210, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+19], v211, a[%10:%10+3]\n\t"
+               "ds_read2st64_b32 v[220:221], %0 offset0:28 offset1:29\n\t"
+               "ds_read2st64_b32 v[222:223], %0 offset0:30 offset1:31\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+20], v212, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+21], v213, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+22], v214, a[%10:%10+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+23], v215, a[%10:%10+3]"
+         ::"v"(xb), "v"(voff), "s"(cl_uni(p[0])), "s"(cl_uni(p[1])), "s"(cl_uni(p[2])), "s"(cl_uni(p[3])), "s"(cl_uni(p[4])), "s"(cl_uni(p[5])), "s"(cl_uni(p[6])),
+           "s"(cl_uni(p[7])), "n"(AB), "n"(RB), "n"(NWAIT > 63 ? 63 : NWAIT), "n"(NRB) : "memory");
+}
+template <int AB, int RB, int NWAIT>
+__device__ __forceinline__ void cl8_unit_a0(uint32_t xb) {          // ... when no further chunk exists
+  CL_ASM(8, "s_waitcnt vmcnt(%3)\n\t"
+               "ds_read2st64_b32 v[216:217], %0 offset0:8 offset1:9\n\t"
+               "ds_read2st64_b32 v[218:219], %0 offset0:10 offset1:11\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+0], v208, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+1], v209, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+2], v210, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+3], v211, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[220:221], %0 offset0:12 offset1:13\n\t"
+               "ds_read2st64_b32 v[222:223], %0 offset0:14 offset1:15\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+4], v212, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+5], v213, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+6], v214, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+7], v215, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[208:209], %0 offset0:16 offset1:17\n\t"
+               "ds_read2st64_b32 v[210:211], %0 offset0:18 offset1:19\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+8], v216, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+9], v217, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+10], v218, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+11], v219, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[212:213], %0 offset0:20 offset1:21\n\t"
+               "ds_read2st64_b32 v[214:215], %0 offset0:22 offset1:23\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+12], v220, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+13], v221, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+14], v222, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+15], v223, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[216:217], %0 offset0:24 offset1:25\n\t"
+               "ds_read2st64_b32 v[218:219], %0 offset0:26 offset1:27\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+16], v208, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+17], v209, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+18], v210, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+19], v211, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[220:221], %0 offset0:28 offset1:29\n\t"
+               "ds_read2st64_b32 v[222:223], %0 offset0:30 offset1:31\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+20], v212, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+21], v213, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+22], v214, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+23], v215, a[%1:%1+3]"
+         ::"v"(xb), "n"(AB), "n"(RB), "n"(NWAIT > 63 ? 63 : NWAIT) : "memory");
+}
+template <int NRB>
+__device__ __forceinline__ void cl8_unit_loads(uint32_t voff, const char* const (&p)[8]) {     // a wave without rows in this layer: the requests only
+  CL_ASM(8, "s_nop 4\n\t"
+               "global_load_dwordx4 a[%9+0:%9+3], %0, %1\n\t"
+               "global_load_dwordx4 a[%9+4:%9+7], %0, %2\n\t"
+               "global_load_dwordx4 a[%9+8:%9+11], %0, %3\n\t"
+               "global_load_dwordx4 a[%9+12:%9+15], %0, %4\n\t"
+               "global_load_dwordx4 a[%9+16:%9+19], %0, %5\n\t"
+               "global_load_dwordx4 a[%9+20:%9+23], %0, %6\n\t"
+               "global_load_dwordx4 a[%9+24:%9+27], %0, %7\n\t"
+               "global_load_dwordx4 a[%9+28:%9+31], %0, %8"
+         ::"v"(voff), "s"(cl_uni(p[0])), "s"(cl_uni(p[1])), "s"(cl_uni(p[2])), "s"(cl_uni(p[3])), "s"(cl_uni(p[4])), "s"(cl_uni(p[5])), "s"(cl_uni(p[6])),
+           "s"(cl_uni(p[7])), "n"(NRB) : "memory");
+}
+template <int AB, int RB, bool NEXT>
+__device__ __forceinline__ void cl8_unit_b(uint32_t xb) {
+  if constexpr (NEXT) {
+    CL_ASM(8, "ds_read2st64_b32 v[208:209], %0 offset0:32 offset1:33\n\t"
+               "ds_read2st64_b32 v[210:211], %0 offset0:34 offset1:35\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+24], v216, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+25], v217, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+26], v218, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+27], v219, a[%1:%1+3]\n\t"
+               "ds_read2st64_b32 v[212:213], %0 offset0:36 offset1:37\n\t"
+               "ds_read2st64_b32 v[214:215], %0 offset0:38 offset1:39\n\t"
+               "s_waitcnt lgkmcnt(4)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+28], v220, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+29], v221, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+30], v222, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+31], v223, a[%1:%1+3]"
+           ::"v"(xb), "n"(AB), "n"(RB) : "memory");
+  } else {
+    CL_ASM(8, "s_waitcnt lgkmcnt(2)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+24], v216, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+25], v217, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+26], v218, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+27], v219, a[%1:%1+3]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+28], v220, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+29], v221, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+30], v222, a[%1:%1+3]\n\t"
+               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+31], v223, a[%1:%1+3]"
+           ::"v"(xb), "n"(AB), "n"(RB) : "memory");
+  }
+}
+
+// the eight request bases of chunk C of a K x O layer (see cl_load_chunk)
+template <int K, int O, int CL, int C>
+__device__ __forceinline__ void cl_chunk_ptrs(const float* __restrict__ Wf, int member, int wave, const char* (&p)[8]) {
+  using Ge = ClGeom<K, O, CL>;
+  const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1)) * Ge::NBL;
+  const char* wp = reinterpret_cast<const char*>(Wf) + (size_t)rb0 * 1024;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = wp + ((size_t)(C * Ge::G + i / Ge::NBL) * Ge::RBT + (i % Ge::NBL)) * 1024;
 }
 
 // start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector) straight into accumulator set P
@@ -1397,6 +1574,48 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     if (S.fail) { cl_wait_vm<0>(); return false; }
     DISTR_XTS(4 * (layer - 1) + 3);
   }
+  if constexpr (CL == 8) {
+    // hand-scheduled units (cl8_unit_a / _b): a weight chunk = a unit (G = 8), one row block per wave
+    static_assert(G == 8 && NBL == 1 && NG % 8 == 0, "8 members: one 16-row block per wave, a chunk per unit");
+    constexpr int NU = NG / 8;
+    const uint32_t xb0 = lds_off(X) + (uint32_t)lane * 4u, voff = (uint32_t)lane * 16u;
+    if (wave < ACT) cl8_b_prologue(xb0);
+    static_for<NU>([&](auto u_) {
+      constexpr int u = decltype(u_)::value;
+      constexpr int t = u + CL_AHEAD;
+      constexpr int RB = ClRegs<8>::RING0 + 32 * ((GB + u) & 3), NRB = ClRegs<8>::RING0 + 32 * ((GB + t) & 3);
+      // this unit's chunk: requested three units ago -- younger = the chunks of the two units in between, and unit 3 of the input if it
+      // was requested (behind the staging of unit 1, inside unit 0) since; chunks 0..2 of a layer landed with its first input unit
+      // (first layer: requested before lin0, like the start values, which are the youngest request there)
+      constexpr int NWAIT = (FIRST && u == 0) ? 0 : (u >= CL_AHEAD) ? 8 * (((GB + u - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + u - 2 + CL_AHEAD < TOT) ? 1 : 0)) +
+                                                                        ((NUIN == 4 && u - 3 <= 0 && 0 <= u - 1) ? 4 : 0) : 63;
+      const uint32_t xb = xb0 + (uint32_t)u * 8192u;
+      if constexpr (GB + t < TOT) {
+        const char* p[8];
+        if constexpr (t < NCH) cl_chunk_ptrs<K, O, 8, t>(Wf, member, wave, p);
+        else if constexpr (t - NCH < NCHN) cl_chunk_ptrs<(KN > 0 ? KN : 128), (KN > 0 ? ON : 512), 8, t - NCH>(WfNext, member, wave, p);
+        else cl_chunk_ptrs<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 512), 8, t - NCH - NCHN>(WfNext2, member, wave, p);
+        if (wave < ACT) cl8_unit_a<ACC, RB, NWAIT, NRB>(xb, voff, p);
+        else cl8_unit_loads<NRB>(voff, p);
+      } else {
+        if (wave < ACT) cl8_unit_a0<ACC, RB, NWAIT>(xb);
+      }
+      if constexpr (NUIN > 1 && u + 1 < NU) {     // the next unit: in LDS before statement B reads the B fragments of its first groups
+        constexpr int un = u + 1;
+        // younger than unit un's requests: unit 1: unit 2's + the weight chunks requested in units 0..u; unit 2: unit 3's (requested
+        // behind the staging of unit 1) + the chunks of units 0..u; unit 3: the chunks requested in units 1..u
+        constexpr int NW = (un == 1) ? ((NUIN > 2 ? 4 : 0) + 8 * cl_issued(GB, TOT, u)) : (un == 2) ? ((NUIN > 3 ? 4 : 0) + 8 * cl_issued(GB, TOT, u))
+                                     : 8 * (cl_issued(GB, TOT, u) - cl_issued(GB, TOT, 0));
+        cl_stage_unit<CL, un, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+        if constexpr (un == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
+        // lin4's input: rows 253..255 carry xyz, over the (staged or own) zeros of lin3's padded rows -- written by the wave that staged
+        // that row block (wave 3: row block 15), behind its own copy in program order (another wave would race with it)
+        if (K == 256 && un == NUIN - 1 && wave == 3 && lane < 48) X[253 * 16 + lane] = S.xyz[lane];
+        __syncthreads();
+      }
+      if (wave < ACT) cl8_unit_b<ACC, RB, (u + 1 < NU)>(xb);
+    });
+  } else {
   const float* xb = X + lane;
   float b[3][4];                      // B fragments (LDS) run two feature groups ahead
 #pragma unroll
@@ -1452,6 +1671,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     });
     __builtin_amdgcn_sched_barrier(0);
   });
+  }
   if constexpr (KN > 0) cl_load_start<KN, ON, CL, (LAYER + 1) & 1>(initNext, member, wave, kq);   // lands with the next layer's first unit
   DISTR_XTS(4 * layer);
   __syncthreads();                         // everybody is done reading the layer input

@@ -34,3 +34,4 @@ for l in range(1, 8):
           'unit 0 staged' if l < 7 else 'all of h7 staged', (d - b) / 100.0))
     prev = d
 print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))
+print('shader clock between the first and the last stamp: %.2f GHz (%.0f cycles in %.2f us)' % ((ts[41] - ts[40]) / ((ts[32] - ts[0]) * 10.0) , ts[41] - ts[40], (ts[32] - ts[0]) / 100.0))
