@@ -13,6 +13,7 @@ for e in c3_reference_loss c5_n1 c2_256 c1_64 c3_recursive c3_trivial c3_f2; do 
 grep -v amdgpu.ids $F/loop.log > $P/${R}_single_view_loop.log
 cp $F/batch_round.log $P/${R}_batch_round.log
 cp $F/cluster_phases.log $P/${R}_cluster_phases.log
+cp $F/ubench_mfma_chain_agpr.log $P/ubench/mfma_chain_agpr.log; cp $F/ubench_cluster_exchange2.log $P/ubench/cluster_exchange2.log
 cp $F/bench_c5_n2_gloo.json $P/${R}_bench_c5_n2_one_gpu_gloo.json
 for k in 2 4 8; do cp $F/r05_plan_check_c5_n$k.md $P/${R}_plan_check_c5_n$k.md; done
 # the timed GPU test run: summary line, slowest tests, wall clock

@@ -43,6 +43,7 @@ python bench.py --marcher trivial --steps 3 --warmup 1 --no-cpu-baseline --no-sp
 python bench.py --fixture f2 --no-cpu-baseline --no-split-bf16-pass > "$OUT/extra_c3_f2.json" 2>/dev/null
 python tests/gpu_diag_loop.py 64 137 224 > "$OUT/loop.log" 2>&1
 python tests/gpu_diag_cluster.py 64 99 2>&1 | grep -v amdgpu.ids > "$OUT/cluster_phases.log"
+for b in cluster_exchange2 mfma_chain_agpr; do [ -x profiles/ubench/$b ] && timeout 120 profiles/ubench/$b > "$OUT/ubench_$b.log" 2>&1; done
 DISTR_DIST_BACKEND=gloo python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 > "$OUT/bench_c5_n2_gloo.json" 2> "$OUT/bench_c5_n2_gloo.err"
 python profiles/plan_check_c5.py "$OUT" > "$OUT/plan_check_c5.log" 2>&1
 python tests/gpu_diag_batch.py 137 8 recursive 2>&1 | grep -v "amdgpu.ids\|Warning\|warn\|Consider\|return Variable" > "$OUT/batch_round.log"

@@ -265,7 +265,7 @@ int main() {
     printf("uncached malloc failed\n"); return 1; }
   hipMemset(buf, 0, bb); hipMemset(ubuf, 0, bb);
   for (int same = 1; same >= 0; --same) {
-    for (int ncl : {8, 28}) {
+    for (int ncl : {8, 24}) {
       // what ships today: flag protocol on uncached memory
       run<8, 0, 0>(1, ncl, same, ubuf, uflags, out, ticks, fail, errs, xcc);
       // granules, cached memory, plain / sc1 stores
@@ -281,9 +281,9 @@ int main() {
       // flag protocol on cached memory with sc1 payload (handoff-flag R1 without the acquire: loads are sc1)
       run<8, 0, 1>(0, ncl, same, buf, uflags, out, ticks, fail, errs, xcc);
     }
-    run<4, 2, 1>(0, 60, same, buf, flags, out, ticks, fail, errs, xcc);
-    run<4, 3, 1>(0, 60, same, buf, flags, out, ticks, fail, errs, xcc);
-    run<4, 3, 0>(0, 60, same, buf, flags, out, ticks, fail, errs, xcc);
+    run<4, 2, 1>(0, 56, same, buf, flags, out, ticks, fail, errs, xcc);
+    run<4, 3, 1>(0, 56, same, buf, flags, out, ticks, fail, errs, xcc);
+    run<4, 3, 0>(0, 56, same, buf, flags, out, ticks, fail, errs, xcc);
     run<2, 2, 1>(0, 120, same, buf, flags, out, ticks, fail, errs, xcc);
     run<2, 3, 1>(0, 120, same, buf, flags, out, ticks, fail, errs, xcc);
     run<2, 3, 0>(0, 120, same, buf, flags, out, ticks, fail, errs, xcc);
