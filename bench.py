@@ -228,6 +228,12 @@ def main():
             raise SystemExit('bench.py: spawned rank without RANK / WORLD_SIZE in its environment')
         sys.exit(spawn_ranks(args.gpus))                 # no launcher around us: become the launcher (an external torchrun still works)
 
+    # stdout carries exactly ONE line, the JSON: whatever a library writes to fd 1 on the way (gloo prints "[Gloo] Rank i is connected to
+    # ..." there) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     global H, W, MARCH_STEP
     c5 = args.workload == 'c5'
     if c5 and (args.size, args.march_step) == (512, 50):
@@ -765,7 +771,7 @@ def main():
         if not args.no_cpu_baseline and args.gpus == 1:      # reported baselines, rank 0 at N=1 only (~30 s + ~20 s of CPU work)
             out['cpu_baseline'] = cpu_baseline(fixture, Ws, bs, latent_np, H, MARCH_STEP, args.marcher)
             out['cpu_baseline_torch'] = cpu_baseline_torch(fixture, Ws, bs, latent_np, MARCH_STEP, args.marcher)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     parallel.barrier()
     if world > 1:
         ok = parallel.allreduce_max_scalar(0.0 if (rank != 0 or serial_check.get('ok')) else 1.0, device=dev) == 0.0

@@ -47,7 +47,7 @@ def main():
         'l2_hit_rate': {'k_step': round(hit('k_step'), 3), 'k_march_coarse': round(hit('k_march'), 3),
                         'how': 'TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), profiles/%s_pmc_l2.md' % name},
         'note': 'fabric-side bytes (L2 misses, mostly served by the 256 MiB Infinity Cache: the 6.3 MB weight stream is re-fetched by every '
-                'XCD once per tile round because it exceeds the 4 MiB L2; includes the uncached slice exchange of the cluster tiles); '
+                'XCD once per tile round because it exceeds the 4 MiB L2; includes the granule exchange of the cluster tiles: ordinary cached device memory since round 5, polled with sc1 loads); '
                 'algorithmic HBM bytes per launch ~27 MB (weights once + 32 B state + 512 B saved mask per decoder evaluation). At ~0.87 ms '
                 'per launch this is ~3 % of HBM peak: the kernel is MFMA-bound. Experiments: aliasing all 512x512 layers onto one weight array '
                 '(stream fits L2) changes the dense rate by 0.3 %; a non-temporal hint on layers 1-4 cut the coarse launches\' fetches by 15 % '
