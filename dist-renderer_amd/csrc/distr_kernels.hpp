@@ -479,6 +479,24 @@ __device__ __forceinline__ int topk_insert_pre(const View& V, const RayPre& st, 
   return free_slot;
 }
 
+// ... the slot only (what topk_insert_pre returns), nothing written: the members of a sticky cluster tile that do not lead mirror the
+// lead's insertion on their copy of the keys to know where this step's mask block goes
+__device__ __forceinline__ int topk_slot_pre(const View& V, const RayPre& st, float s) {
+  const int bs = V.cfg.buffer_size;
+  const float key = fabsf(s);
+  int pos = bs;
+  bool open = true;
+#pragma unroll
+  for (int k = MAX_BS - 1; k >= 0; --k) {
+    if (k < bs && open) { if (key < fabsf(st.ks[k])) pos = k; else open = false; }
+  }
+  if (pos >= bs) return -1;
+  int used = 0;
+#pragma unroll
+  for (int k = 0; k < MAX_BS; ++k) used += (k < bs) ? st.sl[k] : 0;
+  return bs * (bs + 1) / 2 - used;
+}
+
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
 __global__ void __launch_bounds__(256) k_fine_init(View V0) {
   const View V = view_at(V0, blockIdx.y);
@@ -804,7 +822,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       Xchg xs = A.xc;
       xs.epoch = A.xc.epoch + (uint32_t)k;          // one epoch per march step (the host reserved them: Xchg::epochs)
       xs.par = k & 1;                                // alternate the exchange slots: layer 1 of step k+1 must not reuse layer 7's
-      pre = mlp_forward16_cl<8, KEEP, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0);
+      pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0);
       clustered = S.fail == 0;
       if (!clustered) {
         if (!lead) return;
@@ -825,16 +843,18 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         const float mn = m + clampf(s, -cd, cd) * ratio;
         const float za = mn + init_now;
         const float a = fabsf(s);
-        if (lead) {
+        {
           // (the ray's row addresses are recomputed from id + an opaque zero every step: hoisted out of the step loop they would be ~40
           // 64-bit values alive across the decoder evaluation)
           const int32_t id_ = id + zero;
-          V.m[id_] = mn;
+          if (lead) V.m[id_] = mn;
           RayPre st;                   // this step's view of the selected rows (only the keys and slots are read)
           st.m = m; st.init_now = init_now; st.maxbound = maxbound; st.minabs = minabs;
 #pragma unroll
           for (int k = 0; k < MAX_BS; ++k) { st.ks[k] = S.sk[k][tid]; st.sl[k] = S.ssl[k][tid]; }
-          const int slot = topk_insert_pre(V, st, id_, s, zd, V.pyramid ? za : mn, id_);
+          // only the lead writes the selected rows; every member mirrors the insertion on its LDS copy of the keys / slots: the slot says
+          // where this step's mask block goes, and every member stores its own words of it (mlp_forward16_cl, MASK_OWN)
+          const int slot = lead ? topk_insert_pre(V, st, id_, s, zd, V.pyramid ? za : mn, id_) : topk_slot_pre(V, st, s);
           if (slot >= 0) {
             mblock = (long long)id_ * (V.cfg.buffer_size + 1) + slot;
             // the same insertion on the LDS copy: rows behind the new one move down, the new row takes its place
@@ -854,8 +874,10 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
               if (k == pos) { S.sk[k][tid] = s; S.ssl[k][tid] = slot; }
             }
           }
-          if (a < minabs) V.minabs[id_] = a;
-          if (step == 0) V.first_sdf[id_] = s;
+          if (lead) {
+            if (a < minabs) V.minabs[id_] = a;
+            if (step == 0) V.first_sdf[id_] = s;
+          }
         }
         if (a < minabs) minabs = a;
         m = mn;
@@ -875,17 +897,26 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         if (lead && k > 0) atomicAdd(&V.C->cnt_sticky[step], __popcll(was));   // (step A.step itself is counted in cnt_live)
       }
     }
-    if (KEEP && lead) {
+    if (KEEP && (lead || clustered)) {
       if (tid < TILE) S.mb[tid] = mblock;
       __syncthreads();
-      if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (mask_nibble_or)
+      if (clustered) {
+        // every member holds the ReLU bits of the rows IT computed (S.mk, zero elsewhere): per layer and half (h) one 32-bit word of the
+        // ray's mask block -- word 32 (member / 2) + 2 layer + (member & 1) + 16 h: the member's four row blocks are its four bytes -- except
+        // for lin3 (256 rows): members 2 w and 2 w + 1 own the two 16-bit halves of word 32 w + 6 + 16 h, word 32 w + 7 + 16 h stays zero.
+        // Thread (ray, layer, h) stores the member's word: the eight members together write the whole 512-byte block, nobody gathers.
         const int j = tid >> 4, q = tid & 15;
         const long long b = S.mb[j];
         if (b >= 0) {
-          const uint4* src = reinterpret_cast<const uint4*>(&S.mk[j][0]);
-          uint4* dst = V.mstore + (size_t)b * 32;
-          dst[q] = src[q];
-          dst[q + 16] = src[q + 16];
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.mk[j][0]);
+          uint32_t* dst = reinterpret_cast<uint32_t*>(V.mstore + (size_t)b * 32);
+          const int layer = q >> 1, wi = 32 * (member >> 1) + 2 * layer + 16 * (q & 1);
+          if (layer != 3) {
+            dst[wi + (member & 1)] = src[wi + (member & 1)];
+          } else {
+            reinterpret_cast<uint16_t*>(dst + wi)[member & 1] = reinterpret_cast<const uint16_t*>(src + wi)[member & 1];
+            if (member & 1) dst[wi + 1] = 0u;
+          }
         }
       } else {
         store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);

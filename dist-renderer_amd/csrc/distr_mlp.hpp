@@ -757,7 +757,7 @@ struct Smem16 {
 };
 
 struct Smem16CL : Smem16 {
-  uint16_t mk[16][256];   // member 0, KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format
+  uint16_t mk[16][256];   // KEEP: the 16 rays' 512-byte mask blocks in store_mask_chunk's format (lead member: every row; sticky tiles: every member, its own rows)
   int32_t fail;           // != 0: this member gave up on the cluster (assembly or a staging unit timed out / aborted)
   int32_t sc1;            // the cluster's members sit on more than one XCD: slices are stored write-through (cl_assemble)
   int32_t cont;           // sticky tiles: any ray of the tile still live after this step
@@ -1007,10 +1007,25 @@ constexpr int XCLUSTER_BYTES = 2 * XSLOT_BYTES;
 constexpr long long CL_T_ARRIVE = 30 * 100;      // 30 us (members of a cluster are dispatched within ~1 us of each other when CUs are free)
 constexpr long long CL_T_GO = 2000 * 100;        // 2 ms: a member waiting for the lead's verdict
 constexpr long long CL_T_BARRIER = 1000 * 100;   // 1 ms per staging unit
-#define DISTR_XTS(i) do { if (xc.ts && threadIdx.x == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); \
+// (tid: the cluster tile's own copy of the thread index, cl_tid)
+#define DISTR_XTS(i) do { if (xc.ts && tid == 0 && member == 0 && (xbase == xc.buf)) { xc.ts[(i)] = (long long)wall_clock64(); \
     if ((i) == 0 || (i) == 32) xc.ts[40 + ((i) >> 5)] = (long long)__builtin_readcyclecounter();   /* shader clock of the phase: stamps 40 / 41 */ \
     __builtin_amdgcn_s_waitcnt(0); } } while (0)
 
+
+// The cluster tile's own copy of the thread index / the wave index (opaque to the optimiser). k_step holds every role of a march step;
+// with the thread index as ONE value across all of them the register allocator spills it (scratch) and re-derives the wave index from
+// the reload in front of every use inside the cluster tile -- a scratch load followed by vmcnt(0), which drains the request pipeline.
+__device__ __forceinline__ int cl_tid() {
+  int t;
+  asm("v_mov_b32 %0, %1" : "=v"(t) : "v"(threadIdx.x));
+  return t;
+}
+__device__ __forceinline__ int cl_wave(int tid) {
+  int w;
+  asm("s_lshr_b32 %0, %1, 6" : "=s"(w) : "s"(__builtin_amdgcn_readfirstlane(tid)));
+  return w;
+}
 
 // Geometry of one layer of the cluster tile: RBT 16-row blocks in total, PER per member, NBL per wave (ACT active waves).
 // The A-fragments a wave needs are streamed in chunks of 8 float4 (G = 8/NBL feature groups of 16) through a RING of four
@@ -1045,7 +1060,7 @@ constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
 //   * the granule requests land in fixed registers too (v[224:255]: two slots of 16 per thread); after the counted wait their tags
 //     are compared and their values stored to LDS by asm statements that name those registers. (LDS-DMA into a landing zone in LDS is register-safe as well and was tried first: it delivers 16 KiB per
 //     0.6 us and compute unit -- the 64 KiB of granules of a layer then take longer than the layer's k-loop.)
-#define CL_CLOB8 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223"
+#define CL_CLOB8 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v202", "v203", "v204", "v205", "v206", "v207"
 #define CL_CLOB4 "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 #define CL_CLOB2 "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 // one statement, clobber list by cluster size (the fixed range is smaller for larger clusters: fewer row blocks per wave)
@@ -1208,178 +1223,388 @@ __device__ __forceinline__ void cl_load_chunk(const float* __restrict__ Wf, int 
 }
 
 // ---- 8 members: the k-loop of a unit (8 k-groups = 32 dependent MFMAs of a wave's ONE 16-row block) as two hand-scheduled statements.
-// Between two MFMAs on the same accumulator every instruction that makes the wave leave the MFMA stream costs ~43 cycles on top of
-// the MFMA's 32 (MI355X_MICROARCH.md price list; with one statement per k-group a 512-feature layer measured 5660 cycles for 4096 of
-// MFMAs at 2.4 GHz). So everything else travels INSIDE the statements, in the shadow of the dependent MFMAs: the B fragments
-// (ds_read2st64 two k-groups ahead into four fixed 4-register buffers v[208:223]), their lgkmcnt waits, the wait for the weight
-// chunk and the eight requests of the chunk three further on. Statement A = groups 0..5 (the next unit is staged behind it),
-// statement B = groups 6, 7 (reads the next unit's first two groups: its rows are in LDS by then).
-__device__ __forceinline__ void cl8_b_prologue(uint32_t xb) {      // B fragments of groups 0, 1 of a layer's first unit
-  CL_ASM(8, "ds_read2st64_b32 v[208:209], %0 offset0:0 offset1:1\n\t"
-               "ds_read2st64_b32 v[210:211], %0 offset0:2 offset1:3\n\t"
-               "ds_read2st64_b32 v[212:213], %0 offset0:4 offset1:5\n\t"
-               "ds_read2st64_b32 v[214:215], %0 offset0:6 offset1:7"
-         ::"v"(xb) : "memory");
+// Between two MFMAs on the same accumulator every instruction that makes the wave leave the MFMA stream costs matrix time: a scalar
+// instruction nothing, an LDS instruction nothing, a vector instruction 10..16 cycles, a v_accvgpr_read 30..95, a taken branch or a
+// dozen scalar instructions in a row more than the 32 cycles the running MFMA hides (profiles/ubench/mfma_fillers.log; with one
+// statement per k-group a 512-feature layer measured 5660 cycles for 4096 of MFMAs at 2.4 GHz). So everything else travels INSIDE
+// the statements, in the shadow of the dependent MFMAs: the B fragments (ds_read2st64 two k-groups ahead into four fixed 4-register
+// buffers v[208:223]), their lgkmcnt waits, the wait for the weight chunk, the eight requests of the chunk three further on and --
+// statement AS -- the staging of the NEXT input unit (counted wait for its granules, tag check, LDS stores). Statement A / AS =
+// groups 0..5, statement B = groups 6, 7 (reads the next unit's first two groups: its rows are in LDS by then, behind a barrier).
+// What the compiler generates between two statements is a handful of scalar instructions: every per-lane value the statements need
+// lives in FIXED registers only they name (the compiler parks long-lived per-lane values in accumulation registers and fetches
+// them back with a v_accvgpr_read in front of every statement otherwise -- 50..95 cycles each, eight times a layer):
+//   v207 = LDS address of X[0][lane]      (B fragments: unit u, k-step s at offset 256 B x (32 u + s), inside the 8-bit offset field)
+//   v206 = LDS address of X[4 kq][ray]    (staging stores: + 1 KiB x row block)
+//   v[202:205] = 16 lane + i x 32 KiB     (weight requests: request i of a chunk = base + i x 32 KiB for a 512-row layer -- two scalar
+//                                          bases 128 KiB apart --, base + i x 16 KiB for the 256-row layer: bases 16 KiB apart)
+// The staging block needs no register of its own: the tag differences are summed in place (v_sad_u8 over the landed tags of an
+// entry), the store address then takes the place of the entry's first tag.
+__device__ __forceinline__ void cl8_set_fixed(uint32_t xb0, uint32_t xs0, uint32_t lane16) {
+  CL_ASM(8, "v_mov_b32 v207, %0\n\tv_mov_b32 v206, %1\n\tv_mov_b32 v202, %2\n\tv_add_u32 v203, 0x8000, %2\n\tv_add_u32 v204, 0x10000, %2\n\t"
+            "v_add_u32 v205, 0x18000, %2" ::"v"(xb0), "v"(xs0), "v"(lane16) : "memory");
 }
-template <int AB, int RB, int NWAIT, int NRB>
-__device__ __forceinline__ void cl8_unit_a(uint32_t xb, uint32_t voff, const char* const (&p)[8]) {
-  CL_ASM(8, "s_nop 4\n\t"
-               "s_waitcnt vmcnt(%12)\n\t"
-               "ds_read2st64_b32 v[216:217], %0 offset0:8 offset1:9\n\t"
-               "ds_read2st64_b32 v[218:219], %0 offset0:10 offset1:11\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+0], v208, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+0:%13+3], %1, %2\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+1], v209, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+4:%13+7], %1, %3\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+2], v210, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+3], v211, a[%10:%10+3]\n\t"
-               "ds_read2st64_b32 v[220:221], %0 offset0:12 offset1:13\n\t"
-               "ds_read2st64_b32 v[222:223], %0 offset0:14 offset1:15\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+4], v212, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+8:%13+11], %1, %4\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+5], v213, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+12:%13+15], %1, %5\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+6], v214, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+7], v215, a[%10:%10+3]\n\t"
-               "ds_read2st64_b32 v[208:209], %0 offset0:16 offset1:17\n\t"
-               "ds_read2st64_b32 v[210:211], %0 offset0:18 offset1:19\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+8], v216, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+16:%13+19], %1, %6\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+9], v217, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+20:%13+23], %1, %7\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+10], v218, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+11], v219, a[%10:%10+3]\n\t"
-               "ds_read2st64_b32 v[212:213], %0 offset0:20 offset1:21\n\t"
-               "ds_read2st64_b32 v[214:215], %0 offset0:22 offset1:23\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+12], v220, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+24:%13+27], %1, %8\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+13], v221, a[%10:%10+3]\n\t"
-               "global_load_dwordx4 a[%13+28:%13+31], %1, %9\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+14], v222, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+15], v223, a[%10:%10+3]\n\t"
-               "ds_read2st64_b32 v[216:217], %0 offset0:24 offset1:25\n\t"
-               "ds_read2st64_b32 v[218:219], %0 offset0:26 offset1:27\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+16], v208, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+17], v209, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+18], v210, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+19], v211, a[%10:%10+3]\n\t"
-               "ds_read2st64_b32 v[220:221], %0 offset0:28 offset1:29\n\t"
-               "ds_read2st64_b32 v[222:223], %0 offset0:30 offset1:31\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+20], v212, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+21], v213, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+22], v214, a[%10:%10+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%10:%10+3], a[%11+23], v215, a[%10:%10+3]"
-         ::"v"(xb), "v"(voff), "s"(cl_uni(p[0])), "s"(cl_uni(p[1])), "s"(cl_uni(p[2])), "s"(cl_uni(p[3])), "s"(cl_uni(p[4])), "s"(cl_uni(p[5])), "s"(cl_uni(p[6])),
-           "s"(cl_uni(p[7])), "n"(AB), "n"(RB), "n"(NWAIT > 63 ? 63 : NWAIT), "n"(NRB) : "memory");
+#define CL8_LDW(i, V, B) "global_load_dwordx4 a[%[nrb]+" #i "*4:%[nrb]+" #i "*4+3], " V ", " B "\n\t"
+// 512-row layer: request i at base + i x 32 KiB (b1 = b0 + 128 KiB); 256-row layer: at base + i x 16 KiB (b1 = b0 + 16 KiB)
+#define CL8_LOADS32 CL8_LDW(0, "v202", "%[b0]"), CL8_LDW(1, "v203", "%[b0]"), CL8_LDW(2, "v204", "%[b0]"), CL8_LDW(3, "v205", "%[b0]"), \
+                    CL8_LDW(4, "v202", "%[b1]"), CL8_LDW(5, "v203", "%[b1]"), CL8_LDW(6, "v204", "%[b1]"), CL8_LDW(7, "v205", "%[b1]")
+#define CL8_LOADS16 CL8_LDW(0, "v202", "%[b0]"), CL8_LDW(1, "v202", "%[b1]"), CL8_LDW(2, "v203", "%[b0]"), CL8_LDW(3, "v203", "%[b1]"), \
+                    CL8_LDW(4, "v204", "%[b0]"), CL8_LDW(5, "v204", "%[b1]"), CL8_LDW(6, "v205", "%[b0]"), CL8_LDW(7, "v205", "%[b1]")
+// (generated by a script from the schedule above: B buffers rotate 208 / 212 / 216 / 220, requests behind the first two MFMAs of groups 0..3,
+// the staging block behind MFMAs 17 and 19, its verdict behind 21)
+#define CL8_A_TEXT(CL8_L0, CL8_L1, CL8_L2, CL8_L3, CL8_L4, CL8_L5, CL8_L6, CL8_L7) \
+  "s_nop 4\n\t" \
+  "s_waitcnt vmcnt(%[nw])\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+8 offset1:%[uo]+9\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+10 offset1:%[uo]+11\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+0], v208, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L0 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+1], v209, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L1 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+2], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+3], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+12 offset1:%[uo]+13\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+14 offset1:%[uo]+15\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+4], v212, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L2 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+5], v213, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L3 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+6], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+7], v215, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[208:209], v207 offset0:%[uo]+16 offset1:%[uo]+17\n\t" \
+  "ds_read2st64_b32 v[210:211], v207 offset0:%[uo]+18 offset1:%[uo]+19\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+8], v216, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L4 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+9], v217, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L5 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+10], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+11], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[212:213], v207 offset0:%[uo]+20 offset1:%[uo]+21\n\t" \
+  "ds_read2st64_b32 v[214:215], v207 offset0:%[uo]+22 offset1:%[uo]+23\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+12], v220, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L6 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+13], v221, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L7 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+14], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+15], v223, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+24 offset1:%[uo]+25\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+26 offset1:%[uo]+27\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+16], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+17], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+18], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+19], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+28 offset1:%[uo]+29\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+30 offset1:%[uo]+31\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+20], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+21], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+22], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+23], v215, a[%[ab]:%[ab]+3]\n\t"
+
+#define CL8_AS_TEXT(CL8_L0, CL8_L1, CL8_L2, CL8_L3, CL8_L4, CL8_L5, CL8_L6, CL8_L7) \
+  "s_nop 4\n\t" \
+  "s_waitcnt vmcnt(%[nw])\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+8 offset1:%[uo]+9\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+10 offset1:%[uo]+11\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+0], v208, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L0 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+1], v209, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L1 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+2], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+3], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+12 offset1:%[uo]+13\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+14 offset1:%[uo]+15\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+4], v212, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L2 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+5], v213, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L3 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+6], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+7], v215, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[208:209], v207 offset0:%[uo]+16 offset1:%[uo]+17\n\t" \
+  "ds_read2st64_b32 v[210:211], v207 offset0:%[uo]+18 offset1:%[uo]+19\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+8], v216, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L4 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+9], v217, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L5 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+10], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+11], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[212:213], v207 offset0:%[uo]+20 offset1:%[uo]+21\n\t" \
+  "ds_read2st64_b32 v[214:215], v207 offset0:%[uo]+22 offset1:%[uo]+23\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+12], v220, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L6 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+13], v221, a[%[ab]:%[ab]+3]\n\t" \
+  CL8_L7 \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+14], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+15], v223, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+24 offset1:%[uo]+25\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+26 offset1:%[uo]+27\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+16], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+17], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "s_waitcnt vmcnt(%[nws])\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_sad_u8 v[%[land]+1], v[%[land]+1], %[tag], 0\n\t" \
+  "v_sad_u8 v[%[land]+3], v[%[land]+3], %[tag], v[%[land]+1]\n\t" \
+  "v_sad_u8 v[%[land]+5], v[%[land]+5], %[tag], v[%[land]+3]\n\t" \
+  "v_sad_u8 v[%[land]+7], v[%[land]+7], %[tag], v[%[land]+5]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+18], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_sad_u8 v[%[land]+9], v[%[land]+9], %[tag], 0\n\t" \
+  "v_sad_u8 v[%[land]+11], v[%[land]+11], %[tag], v[%[land]+9]\n\t" \
+  "v_sad_u8 v[%[land]+13], v[%[land]+13], %[tag], v[%[land]+11]\n\t" \
+  "v_sad_u8 v[%[land]+15], v[%[land]+15], %[tag], v[%[land]+13]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+19], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "v_add_u32 v[%[land]+1], %[so0], v206\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "ds_write2_b32 v[%[land]+1], v[%[land]+0], v[%[land]+2] offset1:16\n\t" \
+  "ds_write2_b32 v[%[land]+1], v[%[land]+4], v[%[land]+6] offset0:32 offset1:48\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+8] offset:4096\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+10] offset:4160\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+12] offset:4224\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+14] offset:4288\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+28 offset1:%[uo]+29\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+30 offset1:%[uo]+31\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+20], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_cmp_ne_u32 vcc, 0, v[%[land]+7]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+21], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "s_mov_b64 %[flag], vcc\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_cmp_ne_u32 vcc, 0, v[%[land]+15]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+22], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "s_or_b64 %[flag], %[flag], vcc\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+23], v215, a[%[ab]:%[ab]+3]\n\t"
+
+#define CL8_A0_TEXT \
+  "s_waitcnt vmcnt(%[nw])\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+8 offset1:%[uo]+9\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+10 offset1:%[uo]+11\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+0], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+1], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+2], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+3], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+12 offset1:%[uo]+13\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+14 offset1:%[uo]+15\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+4], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+5], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+6], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+7], v215, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[208:209], v207 offset0:%[uo]+16 offset1:%[uo]+17\n\t" \
+  "ds_read2st64_b32 v[210:211], v207 offset0:%[uo]+18 offset1:%[uo]+19\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+8], v216, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+9], v217, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+10], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+11], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[212:213], v207 offset0:%[uo]+20 offset1:%[uo]+21\n\t" \
+  "ds_read2st64_b32 v[214:215], v207 offset0:%[uo]+22 offset1:%[uo]+23\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+12], v220, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+13], v221, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+14], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+15], v223, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+24 offset1:%[uo]+25\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+26 offset1:%[uo]+27\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+16], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+17], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+18], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+19], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+28 offset1:%[uo]+29\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+30 offset1:%[uo]+31\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+20], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+21], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+22], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+23], v215, a[%[ab]:%[ab]+3]\n\t"
+
+#define CL8_A0S_TEXT \
+  "s_waitcnt vmcnt(%[nw])\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+8 offset1:%[uo]+9\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+10 offset1:%[uo]+11\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+0], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+1], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+2], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+3], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+12 offset1:%[uo]+13\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+14 offset1:%[uo]+15\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+4], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+5], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+6], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+7], v215, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[208:209], v207 offset0:%[uo]+16 offset1:%[uo]+17\n\t" \
+  "ds_read2st64_b32 v[210:211], v207 offset0:%[uo]+18 offset1:%[uo]+19\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+8], v216, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+9], v217, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+10], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+11], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[212:213], v207 offset0:%[uo]+20 offset1:%[uo]+21\n\t" \
+  "ds_read2st64_b32 v[214:215], v207 offset0:%[uo]+22 offset1:%[uo]+23\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+12], v220, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+13], v221, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+14], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+15], v223, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[216:217], v207 offset0:%[uo]+24 offset1:%[uo]+25\n\t" \
+  "ds_read2st64_b32 v[218:219], v207 offset0:%[uo]+26 offset1:%[uo]+27\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+16], v208, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+17], v209, a[%[ab]:%[ab]+3]\n\t" \
+  "s_waitcnt vmcnt(%[nws])\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_sad_u8 v[%[land]+1], v[%[land]+1], %[tag], 0\n\t" \
+  "v_sad_u8 v[%[land]+3], v[%[land]+3], %[tag], v[%[land]+1]\n\t" \
+  "v_sad_u8 v[%[land]+5], v[%[land]+5], %[tag], v[%[land]+3]\n\t" \
+  "v_sad_u8 v[%[land]+7], v[%[land]+7], %[tag], v[%[land]+5]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+18], v210, a[%[ab]:%[ab]+3]\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_sad_u8 v[%[land]+9], v[%[land]+9], %[tag], 0\n\t" \
+  "v_sad_u8 v[%[land]+11], v[%[land]+11], %[tag], v[%[land]+9]\n\t" \
+  "v_sad_u8 v[%[land]+13], v[%[land]+13], %[tag], v[%[land]+11]\n\t" \
+  "v_sad_u8 v[%[land]+15], v[%[land]+15], %[tag], v[%[land]+13]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+19], v211, a[%[ab]:%[ab]+3]\n\t" \
+  "v_add_u32 v[%[land]+1], %[so0], v206\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "ds_write2_b32 v[%[land]+1], v[%[land]+0], v[%[land]+2] offset1:16\n\t" \
+  "ds_write2_b32 v[%[land]+1], v[%[land]+4], v[%[land]+6] offset0:32 offset1:48\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+8] offset:4096\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+10] offset:4160\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+12] offset:4224\n\t" \
+  "ds_write_b32 v[%[land]+1], v[%[land]+14] offset:4288\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "ds_read2st64_b32 v[220:221], v207 offset0:%[uo]+28 offset1:%[uo]+29\n\t" \
+  "ds_read2st64_b32 v[222:223], v207 offset0:%[uo]+30 offset1:%[uo]+31\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+20], v212, a[%[ab]:%[ab]+3]\n\t" \
+  "s_bitcmp1_b32 %[own], 0\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_cmp_ne_u32 vcc, 0, v[%[land]+7]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+21], v213, a[%[ab]:%[ab]+3]\n\t" \
+  "s_mov_b64 %[flag], vcc\n\t" \
+  "s_bitcmp1_b32 %[own], 1\n\ts_cselect_b64 exec, 0, -1\n\t" \
+  "v_cmp_ne_u32 vcc, 0, v[%[land]+15]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+22], v214, a[%[ab]:%[ab]+3]\n\t" \
+  "s_or_b64 %[flag], %[flag], vcc\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+23], v215, a[%[ab]:%[ab]+3]\n\t"
+
+#define CL8_B_NEXT_TEXT \
+  "ds_read2st64_b32 v[208:209], v207 offset0:%[uo]+32 offset1:%[uo]+33\n\t" \
+  "ds_read2st64_b32 v[210:211], v207 offset0:%[uo]+34 offset1:%[uo]+35\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+24], v216, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+25], v217, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+26], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+27], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "ds_read2st64_b32 v[212:213], v207 offset0:%[uo]+36 offset1:%[uo]+37\n\t" \
+  "ds_read2st64_b32 v[214:215], v207 offset0:%[uo]+38 offset1:%[uo]+39\n\t" \
+  "s_waitcnt lgkmcnt(4)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+28], v220, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+29], v221, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+30], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+31], v223, a[%[ab]:%[ab]+3]\n\t"
+
+#define CL8_B_LAST_TEXT \
+  "s_waitcnt lgkmcnt(2)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+24], v216, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+25], v217, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+26], v218, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+27], v219, a[%[ab]:%[ab]+3]\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+28], v220, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+29], v221, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+30], v222, a[%[ab]:%[ab]+3]\n\t" \
+  "v_mfma_f32_16x16x4_f32 a[%[ab]:%[ab]+3], a[%[rb]+31], v223, a[%[ab]:%[ab]+3]\n\t"
+#define CL8_LOADS_TEXT(L0, L1, L2, L3, L4, L5, L6, L7) L0 L1 L2 L3 L4 L5 L6 L7
+#define CL8_EXPAND(M, ...) M(__VA_ARGS__)
+__device__ __forceinline__ void cl8_b_prologue() {      // B fragments of groups 0, 1 of a layer's first unit
+  CL_ASM(8, "ds_read2st64_b32 v[208:209], v207 offset0:0 offset1:1\n\t"
+               "ds_read2st64_b32 v[210:211], v207 offset0:2 offset1:3\n\t"
+               "ds_read2st64_b32 v[212:213], v207 offset0:4 offset1:5\n\t"
+               "ds_read2st64_b32 v[214:215], v207 offset0:6 offset1:7"
+         ::: "memory");
 }
-template <int AB, int RB, int NWAIT>
-__device__ __forceinline__ void cl8_unit_a0(uint32_t xb) {          // ... when no further chunk exists
-  CL_ASM(8, "s_waitcnt vmcnt(%3)\n\t"
-               "ds_read2st64_b32 v[216:217], %0 offset0:8 offset1:9\n\t"
-               "ds_read2st64_b32 v[218:219], %0 offset0:10 offset1:11\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+0], v208, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+1], v209, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+2], v210, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+3], v211, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[220:221], %0 offset0:12 offset1:13\n\t"
-               "ds_read2st64_b32 v[222:223], %0 offset0:14 offset1:15\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+4], v212, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+5], v213, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+6], v214, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+7], v215, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[208:209], %0 offset0:16 offset1:17\n\t"
-               "ds_read2st64_b32 v[210:211], %0 offset0:18 offset1:19\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+8], v216, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+9], v217, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+10], v218, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+11], v219, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[212:213], %0 offset0:20 offset1:21\n\t"
-               "ds_read2st64_b32 v[214:215], %0 offset0:22 offset1:23\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+12], v220, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+13], v221, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+14], v222, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+15], v223, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[216:217], %0 offset0:24 offset1:25\n\t"
-               "ds_read2st64_b32 v[218:219], %0 offset0:26 offset1:27\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+16], v208, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+17], v209, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+18], v210, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+19], v211, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[220:221], %0 offset0:28 offset1:29\n\t"
-               "ds_read2st64_b32 v[222:223], %0 offset0:30 offset1:31\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+20], v212, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+21], v213, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+22], v214, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+23], v215, a[%1:%1+3]"
-         ::"v"(xb), "n"(AB), "n"(RB), "n"(NWAIT > 63 ? 63 : NWAIT) : "memory");
+// AB: accumulator block, RB: ring slot of this unit's chunk, NWAIT: requests younger than it, NRB: ring slot of the chunk requested,
+// UO = 32 x unit, S16: the requested chunk belongs to the 256-row layer (16 KiB between its requests)
+template <int AB, int RB, int NWAIT, int NRB, int UO, bool S16>
+__device__ __forceinline__ void cl8_unit_a(const char* b0) {
+  const char* b1 = b0 + (S16 ? 16384 : 131072);
+  if constexpr (S16) CL_ASM(8, CL8_EXPAND(CL8_A_TEXT, CL8_LOADS16) ::[b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [ab] "n"(AB), [rb] "n"(RB), [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [nrb] "n"(NRB), [uo] "n"(UO) : "memory");
+  else CL_ASM(8, CL8_EXPAND(CL8_A_TEXT, CL8_LOADS32) ::[b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [ab] "n"(AB), [rb] "n"(RB), [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [nrb] "n"(NRB), [uo] "n"(UO) : "memory");
 }
-template <int NRB>
-__device__ __forceinline__ void cl8_unit_loads(uint32_t voff, const char* const (&p)[8]) {     // a wave without rows in this layer: the requests only
-  CL_ASM(8, "s_nop 4\n\t"
-               "global_load_dwordx4 a[%9+0:%9+3], %0, %1\n\t"
-               "global_load_dwordx4 a[%9+4:%9+7], %0, %2\n\t"
-               "global_load_dwordx4 a[%9+8:%9+11], %0, %3\n\t"
-               "global_load_dwordx4 a[%9+12:%9+15], %0, %4\n\t"
-               "global_load_dwordx4 a[%9+16:%9+19], %0, %5\n\t"
-               "global_load_dwordx4 a[%9+20:%9+23], %0, %6\n\t"
-               "global_load_dwordx4 a[%9+24:%9+27], %0, %7\n\t"
-               "global_load_dwordx4 a[%9+28:%9+31], %0, %8"
-         ::"v"(voff), "s"(cl_uni(p[0])), "s"(cl_uni(p[1])), "s"(cl_uni(p[2])), "s"(cl_uni(p[3])), "s"(cl_uni(p[4])), "s"(cl_uni(p[5])), "s"(cl_uni(p[6])),
-           "s"(cl_uni(p[7])), "n"(NRB) : "memory");
+template <int AB, int RB, int NWAIT, int UO>
+__device__ __forceinline__ void cl8_unit_a0() {          // ... when no further chunk exists
+  CL_ASM(8, CL8_A0_TEXT ::[ab] "n"(AB), [rb] "n"(RB), [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [uo] "n"(UO) : "memory");
 }
-template <int AB, int RB, bool NEXT>
-__device__ __forceinline__ void cl8_unit_b(uint32_t xb) {
-  if constexpr (NEXT) {
-    CL_ASM(8, "ds_read2st64_b32 v[208:209], %0 offset0:32 offset1:33\n\t"
-               "ds_read2st64_b32 v[210:211], %0 offset0:34 offset1:35\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+24], v216, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+25], v217, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+26], v218, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+27], v219, a[%1:%1+3]\n\t"
-               "ds_read2st64_b32 v[212:213], %0 offset0:36 offset1:37\n\t"
-               "ds_read2st64_b32 v[214:215], %0 offset0:38 offset1:39\n\t"
-               "s_waitcnt lgkmcnt(4)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+28], v220, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+29], v221, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+30], v222, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+31], v223, a[%1:%1+3]"
-           ::"v"(xb), "n"(AB), "n"(RB) : "memory");
-  } else {
-    CL_ASM(8, "s_waitcnt lgkmcnt(2)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+24], v216, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+25], v217, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+26], v218, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+27], v219, a[%1:%1+3]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+28], v220, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+29], v221, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+30], v222, a[%1:%1+3]\n\t"
-               "v_mfma_f32_16x16x4_f32 a[%1:%1+3], a[%2+31], v223, a[%1:%1+3]"
-           ::"v"(xb), "n"(AB), "n"(RB) : "memory");
-  }
+// ... with the staging of the next input unit inside (landing slot LAND, NWS requests younger than its granules; own: bit e set = the
+// wave's entry e holds the member's own rows -- neither checked nor stored: exec = 0 around its instructions; so0 = LDS offset of the
+// wave's first row block of the unit, the second one is 4 KiB further). Returns nonzero when a tag did not match (the caller then
+// re-requests the unit until it is there: cl_stage_unit). exec is all ones here (every branch around the tile is wave-uniform).
+struct Cl8Stage { uint32_t tag, so0, own; };
+template <int AB, int RB, int NWAIT, int NRB, int UO, bool S16, int NWS, int LAND>
+__device__ __forceinline__ uint64_t cl8_unit_as(const char* b0, const Cl8Stage& st) {
+  const char* b1 = b0 + (S16 ? 16384 : 131072);
+  uint64_t flag;
+  if constexpr (S16) CL_ASM(8, CL8_EXPAND(CL8_AS_TEXT, CL8_LOADS16) : [flag] "=&s"(flag) : [b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [ab] "n"(AB), [rb] "n"(RB),
+                               [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [nrb] "n"(NRB), [uo] "n"(UO), [nws] "n"(NWS > 63 ? 63 : NWS), [land] "n"(LAND), [tag] "s"(st.tag),
+                               [own] "s"(st.own), [so0] "s"(st.so0) : "memory", "vcc", "scc");
+  else CL_ASM(8, CL8_EXPAND(CL8_AS_TEXT, CL8_LOADS32) : [flag] "=&s"(flag) : [b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [ab] "n"(AB), [rb] "n"(RB),
+                 [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [nrb] "n"(NRB), [uo] "n"(UO), [nws] "n"(NWS > 63 ? 63 : NWS), [land] "n"(LAND), [tag] "s"(st.tag),
+                 [own] "s"(st.own), [so0] "s"(st.so0) : "memory", "vcc", "scc");
+  return flag;
+}
+template <int AB, int RB, int NWAIT, int UO, int NWS, int LAND>
+__device__ __forceinline__ uint64_t cl8_unit_a0s(const Cl8Stage& st) {
+  uint64_t flag;
+  CL_ASM(8, CL8_A0S_TEXT : [flag] "=&s"(flag) : [ab] "n"(AB), [rb] "n"(RB), [nw] "n"(NWAIT > 63 ? 63 : NWAIT), [uo] "n"(UO), [nws] "n"(NWS > 63 ? 63 : NWS),
+            [land] "n"(LAND), [tag] "s"(st.tag), [own] "s"(st.own), [so0] "s"(st.so0) : "memory", "vcc", "scc");
+  return flag;
+}
+template <int NRB, bool S16>
+__device__ __forceinline__ void cl8_unit_loads(const char* b0) {     // a wave without rows in this layer: the requests only
+  const char* b1 = b0 + (S16 ? 16384 : 131072);
+  if constexpr (S16) CL_ASM(8, "s_nop 4\n\t" CL8_EXPAND(CL8_LOADS_TEXT, CL8_LOADS16) ::[b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [nrb] "n"(NRB) : "memory");
+  else CL_ASM(8, "s_nop 4\n\t" CL8_EXPAND(CL8_LOADS_TEXT, CL8_LOADS32) ::[b0] "s"(cl_uni(b0)), [b1] "s"(cl_uni(b1)), [nrb] "n"(NRB) : "memory");
+}
+template <int AB, int RB, bool NEXT, int UO>
+__device__ __forceinline__ void cl8_unit_b() {
+  if constexpr (NEXT) CL_ASM(8, CL8_B_NEXT_TEXT ::[ab] "n"(AB), [rb] "n"(RB), [uo] "n"(UO) : "memory");
+  else CL_ASM(8, CL8_B_LAST_TEXT ::[ab] "n"(AB), [rb] "n"(RB) : "memory");
 }
 
-// the eight request bases of chunk C of a K x O layer (see cl_load_chunk)
-template <int K, int O, int CL, int C>
-__device__ __forceinline__ void cl_chunk_ptrs(const float* __restrict__ Wf, int member, int wave, const char* (&p)[8]) {
-  using Ge = ClGeom<K, O, CL>;
-  const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1)) * Ge::NBL;
-  const char* wp = reinterpret_cast<const char*>(Wf) + (size_t)rb0 * 1024;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = wp + ((size_t)(C * Ge::G + i / Ge::NBL) * Ge::RBT + (i % Ge::NBL)) * 1024;
+
+// request base of chunk C of a K x O layer for this wave, 8 members (one row block per wave; see cl_load_chunk): request i of the chunk is
+// base + i x RBT KiB
+template <int K, int O, int C>
+__device__ __forceinline__ const char* cl8_chunk_base(const float* __restrict__ Wf, int member, int wave) {
+  using Ge = ClGeom<K, O, 8>;
+  static_assert(Ge::NBL == 1 && (Ge::RBT == 32 || Ge::RBT == 16), "512- or 256-row layers");
+  const int rb0 = member * Ge::PER + (wave & (Ge::ACT - 1));
+  return reinterpret_cast<const char*>(Wf) + ((size_t)rb0 + (size_t)(C * 8) * Ge::RBT) * 1024;
 }
 
 // start values of a layer's accumulators (this wave's rows of the bias / latent-constant vector) straight into accumulator set P
@@ -1491,10 +1716,9 @@ __device__ __forceinline__ void cl_request_unit(const char* slot, int wave, int 
 // members' rows to X (the own rows were written at write-back) and ORs their ReLU bits into the mask blocks (lead member, KEEP).
 // The caller adds the barrier. own rows of the producing layer: row blocks [own_lo, own_lo + own_n).
 template <int CL, int U, int NWAIT>
-__device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CL& S, int tid, bool keep, int layer_of_data,
-                                              int wr_log) {
+__device__ __forceinline__ void cl_stage_unit(const char* slot, uint32_t tag, int own_lo, int own_n, Smem16CL& S, int tid, int wave, bool keep,
+                                              int layer_of_data, int wr_log) {
   constexpr int LAND = ClRegs<CL>::LAND0 + 16 * (U & 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lw = tid & 63, kq = lw >> 4, j = lw & 15;
   cl_wait_vm<NWAIT>();
   // own rows of the producing layer (wave-uniform: a wave's two entries are whole row blocks): neither checked nor copied
@@ -1544,9 +1768,10 @@ constexpr int cl_issued(int GB, int TOT, int upto) {
 // sequence is requested: of this layer, of the next one (KN x ON, WfNext) or of the one after it (KN2 x ON2, WfNext2).
 // REQ_OUT: request the output slot afterwards (false for a member that leaves after its last slice store).
 // Returns false when this member gave up (S.fail set; nothing of its requests is in flight any more).
+// keep (ReLU bits into S.mk): bit 0 = of the rows staged from the other members, bit 1 = of the own rows at write-back.
 template <int LAYER, int K, int O, int CL, int GB, int TOT, int KN, int ON, int KN2, int ON2, bool FIRST, bool REQ_OUT>
 __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const float* __restrict__ WfNext, const float* __restrict__ WfNext2,
-                                         const float* __restrict__ initNext, Smem16CLX& S, const Xchg& xc, char* xbase, int member, bool keep) {
+                                         const float* __restrict__ initNext, Smem16CLX& S, const Xchg& xc, char* xbase, int member, int keep) {
   using Ge = ClGeom<K, O, CL>;
   using GeN = ClGeom<(KN > 0 ? KN : 128), (KN > 0 ? ON : 64 * CL), CL>;
   using GeN2 = ClGeom<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 64 * CL), CL>;
@@ -1556,8 +1781,8 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   constexpr int ACC = ClRegs<CL>::ACC0 + 4 * ClRegs<CL>::NBLM * (LAYER & 1);
   constexpr int layer = LAYER;
   static_assert(FIRST || (NG % 8 == 0 && PERIN >= 1), "staging units of 8 k-groups");
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = cl_tid();
+  const int wave = cl_wave(tid);
   const int lane = tid & 63, kq = lane >> 4, j = lane & 15;
   float* X = S.X;
   const char* slot_in = xbase + ((layer - 1 + xc.par) & 1) * XSLOT_BYTES;
@@ -1566,7 +1791,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   constexpr int wr_in = (LAYER - 1 == 3) ? 6 : 7;
   const int rb0 = member * PER + wave * NBL;
   if constexpr (NUIN > 0) {   // the first 128 input rows (the only exposed hand-off of the layer); everything requested earlier has landed with them
-    cl_stage_unit<CL, 0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+    cl_stage_unit<CL, 0, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, wave, (keep & 1) != 0, layer - 1, wr_in);
     // (units 1 and 2 before this layer's first weight request: the counts below rely on it)
     if constexpr (NUIN > 1) cl_request_unit<CL, 1>(slot_in, wave, lane);
     if constexpr (NUIN > 2) cl_request_unit<CL, 2>(slot_in, wave, lane);
@@ -1575,11 +1800,11 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
     DISTR_XTS(4 * (layer - 1) + 3);
   }
   if constexpr (CL == 8) {
-    // hand-scheduled units (cl8_unit_a / _b): a weight chunk = a unit (G = 8), one row block per wave
+    // hand-scheduled units (cl8_unit_a / _as / _b): a weight chunk = a unit (G = 8), one row block per wave
     static_assert(G == 8 && NBL == 1 && NG % 8 == 0, "8 members: one 16-row block per wave, a chunk per unit");
     constexpr int NU = NG / 8;
-    const uint32_t xb0 = lds_off(X) + (uint32_t)lane * 4u, voff = (uint32_t)lane * 16u;
-    if (wave < ACT) cl8_b_prologue(xb0);
+    const bool act = (ACT == 4) || wave < ACT;       // (a scalar branch costs what the MFMA before it hides: none where every wave has rows)
+    if (act) cl8_b_prologue();
     static_for<NU>([&](auto u_) {
       constexpr int u = decltype(u_)::value;
       constexpr int t = u + CL_AHEAD;
@@ -1589,31 +1814,61 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
       // (first layer: requested before lin0, like the start values, which are the youngest request there)
       constexpr int NWAIT = (FIRST && u == 0) ? 0 : (u >= CL_AHEAD) ? 8 * (((GB + u - 1 + CL_AHEAD < TOT) ? 1 : 0) + ((GB + u - 2 + CL_AHEAD < TOT) ? 1 : 0)) +
                                                                         ((NUIN == 4 && u - 3 <= 0 && 0 <= u - 1) ? 4 : 0) : 63;
-      const uint32_t xb = xb0 + (uint32_t)u * 8192u;
-      if constexpr (GB + t < TOT) {
-        const char* p[8];
-        if constexpr (t < NCH) cl_chunk_ptrs<K, O, 8, t>(Wf, member, wave, p);
-        else if constexpr (t - NCH < NCHN) cl_chunk_ptrs<(KN > 0 ? KN : 128), (KN > 0 ? ON : 512), 8, t - NCH>(WfNext, member, wave, p);
-        else cl_chunk_ptrs<(KN2 > 0 ? KN2 : 128), (KN2 > 0 ? ON2 : 512), 8, t - NCH - NCHN>(WfNext2, member, wave, p);
-        if (wave < ACT) cl8_unit_a<ACC, RB, NWAIT, NRB>(xb, voff, p);
-        else cl8_unit_loads<NRB>(voff, p);
-      } else {
-        if (wave < ACT) cl8_unit_a0<ACC, RB, NWAIT>(xb);
-      }
+      constexpr bool HAS = GB + t < TOT;                      // a chunk to request: of this layer, the next one or the one after it
+      constexpr int KT = (t < NCH) ? K : (t - NCH < NCHN) ? (KN > 0 ? KN : 128) : (KN2 > 0 ? KN2 : 128);
+      constexpr int OT = (t < NCH) ? O : (t - NCH < NCHN) ? (KN > 0 ? ON : 512) : (KN2 > 0 ? ON2 : 512);
+      constexpr int CT = (t < NCH) ? t : (t - NCH < NCHN) ? t - NCH : t - NCH - NCHN;
+      constexpr bool S16 = OT == 256;
+      const char* b0 = nullptr;
+      if constexpr (HAS) b0 = cl8_chunk_base<KT, OT, CT>((t < NCH) ? Wf : (t - NCH < NCHN) ? WfNext : WfNext2, member, wave);
       if constexpr (NUIN > 1 && u + 1 < NU) {     // the next unit: in LDS before statement B reads the B fragments of its first groups
         constexpr int un = u + 1;
         // younger than unit un's requests: unit 1: unit 2's + the weight chunks requested in units 0..u; unit 2: unit 3's (requested
         // behind the staging of unit 1) + the chunks of units 0..u; unit 3: the chunks requested in units 1..u
         constexpr int NW = (un == 1) ? ((NUIN > 2 ? 4 : 0) + 8 * cl_issued(GB, TOT, u)) : (un == 2) ? ((NUIN > 3 ? 4 : 0) + 8 * cl_issued(GB, TOT, u))
                                      : 8 * (cl_issued(GB, TOT, u) - cl_issued(GB, TOT, 0));
-        cl_stage_unit<CL, un, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+        constexpr int LAND = ClRegs<8>::LAND0 + 16 * (un & 1);
+        if (act) {
+          // staged inside the statement (this unit's chunk requests are older than the wait in there, like in the separate form)
+          const int blk = un * 8 + wave;
+          const bool own0 = (unsigned)(blk - member * PERIN) < (unsigned)PERIN, own1 = (unsigned)(blk + 4 - member * PERIN) < (unsigned)PERIN;
+          Cl8Stage st;
+          // ("s" operands must be provably wave-uniform: see cl_uni)
+          st.tag = __builtin_amdgcn_readfirstlane(tag_in); st.so0 = __builtin_amdgcn_readfirstlane((uint32_t)blk * 1024u);
+          st.own = __builtin_amdgcn_readfirstlane((own0 ? 1u : 0u) | (own1 ? 2u : 0u));
+          uint64_t bad;
+          if constexpr (HAS) bad = cl8_unit_as<ACC, RB, NWAIT, NRB, 32 * u, S16, NW, LAND>(b0, st);
+          else bad = cl8_unit_a0s<ACC, RB, NWAIT, 32 * u, NW, LAND>(st);
+          if (bad) {          // a granule was not there yet: re-request until it is (bounded), store again
+            cl_stage_unit<CL, un, 0>(slot_in, tag_in, member * PERIN, PERIN, S, tid, wave, (keep & 1) != 0, layer - 1, wr_in);
+          } else if (keep & 1) {  // lead member: the ReLU bits of the staged rows
+            if (!own0) mask_nibble_put(S, layer - 1, blk, wr_in, kq, j, cl_land_nibble<CL, LAND, 0>());
+            if (!own1) mask_nibble_put(S, layer - 1, blk + 4, wr_in, kq, j, cl_land_nibble<CL, LAND, 1>());
+          }
+        } else {
+          if constexpr (HAS) cl8_unit_loads<NRB, S16>(b0);
+          cl_stage_unit<CL, un, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, wave, (keep & 1) != 0, layer - 1, wr_in);
+        }
         if constexpr (un == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
         // lin4's input: rows 253..255 carry xyz, over the (staged or own) zeros of lin3's padded rows -- written by the wave that staged
         // that row block (wave 3: row block 15), behind its own copy in program order (another wave would race with it)
         if (K == 256 && un == NUIN - 1 && wave == 3 && lane < 48) X[253 * 16 + lane] = S.xyz[lane];
         __syncthreads();
+      } else {
+        if (act) {
+          if constexpr (HAS) cl8_unit_a<ACC, RB, NWAIT, NRB, 32 * u, S16>(b0);
+          else cl8_unit_a0<ACC, RB, NWAIT, 32 * u>();
+        } else {
+          if constexpr (HAS) cl8_unit_loads<NRB, S16>(b0);
+        }
       }
-      if (wave < ACT) cl8_unit_b<ACC, RB, (u + 1 < NU)>(xb);
+#ifdef DISTR_XTS_UNITS      // diagnostics build: stamps around the statements of layer 2's units (profiles/tools: gpu_diag_cluster.py prints them)
+      if (LAYER == 2) DISTR_XTS(42 + 2 * u);
+#endif
+      if (act) cl8_unit_b<ACC, RB, (u + 1 < NU), 32 * u>();
+#ifdef DISTR_XTS_UNITS
+      if (LAYER == 2) DISTR_XTS(43 + 2 * u);
+#endif
     });
   } else {
   const float* xb = X + lane;
@@ -1653,7 +1908,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
           constexpr int CS1 = 6 / G;
           constexpr int NW = (u == 1) ? ((NUIN > 2 ? 4 : 0) + 8 * cl_issued(GB, TOT, c)) : (u == 2) ? ((NUIN > 3 ? 4 : 0) + 8 * cl_issued(GB, TOT, c))
                                       : 8 * (cl_issued(GB, TOT, c) - cl_issued(GB, TOT, CS1));
-          cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, keep, layer - 1, wr_in);
+          cl_stage_unit<CL, u, NW>(slot_in, tag_in, member * PERIN, PERIN, S, tid, wave, (keep & 1) != 0, layer - 1, wr_in);
           if constexpr (u == 1 && NUIN > 3) cl_request_unit<CL, 3>(slot_in, wave, lane);
           // lin4's input: rows 253..255 carry xyz, over the (staged or own) zeros of lin3's padded rows -- written by the wave that staged
           // that row block (wave 3: row block 15), behind its own copy in program order (another wave would race with it)
@@ -1695,7 +1950,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
       g0[0] = v[0]; g0[2] = v[1]; g1[0] = v[2]; g1[2] = v[3];
       cl_st((uint32_t)lane * 16u, p, g0, sc1);
       cl_st((uint32_t)lane * 16u, p + 1024, g1, sc1);
-      if (keep) mask_nibble_put(S, layer, rb0 + ob, (LAYER == 3) ? 6 : 7, kq, j, mask_nibble_of(v));
+      if (keep & 2) mask_nibble_put(S, layer, rb0 + ob, (LAYER == 3) ? 6 : 7, kq, j, mask_nibble_of(v));
     });
   }
   if (REQ_OUT) cl_request_unit<CL, 0>(slot_out, wave, lane);
@@ -1708,14 +1963,17 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
 // workgroup) means this member gave up (cluster not assembled in time / a unit timed out): the lead member's caller then
 // evaluates the tile with mlp_forward16 (S.xyz is untouched), the other members simply leave.
 // ALL_LIN8 (sticky tiles): every member computes lin8 from its own copy of h7 and returns the pre-tanh value (all members then
-// mirror the march update in registers, no broadcast needed). assemble = false: the members are known to be resident (a later
+// mirror the march update in registers, no broadcast needed). MASK_OWN (with KEEP): EVERY member records the ReLU bits of the rows it
+// computes itself (its accumulators at write-back, its quarter-of-a-wave share of lin0) in its own S.mk -- in the mask-block format the four
+// row blocks of a member are exactly one 32-bit word per layer and half (two members share a word for the 256-row lin3) -- and nobody
+// extracts bits from staged rows: the lead member's per-unit bit extraction made it the last to publish in every layer. assemble = false: the members are known to be resident (a later
 // march step of the same launch), no arrival / go handshake (S.sc1 keeps the first step's verdict).
-template <int CL, bool KEEP, bool ALL_LIN8 = false>
+template <int CL, bool KEEP, bool ALL_LIN8 = false, bool MASK_OWN = false>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
                                                   const float* __restrict__ c4, Smem16CLX& S, const Xchg& xc, int cluster, int member,
                                                   bool assemble = true) {
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = cl_tid();
+  const int wave = cl_wave(tid);
   const int lane = tid & 63;
   const int kq = lane >> 4;
   const int ray = tid & 15;
@@ -1741,7 +1999,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   cl_load_chunk<512, 512, CL, 2, 2>(D16.Wf[1], member, wave, lane);
   cl_load_start<512, 512, CL, 1>(D.bias[1], member, wave, kq);
   X[tid] = (tid < 48) ? S.xyz[tid] : 0.f;
-  if (KEEP && lead) {   // the rays' mask blocks are OR-ed together nibble by nibble (mask_nibble_or)
+  if (KEEP && (lead || MASK_OWN)) {   // the rays' mask blocks are OR-ed together nibble by nibble (mask_nibble_or)
     uint4* z = reinterpret_cast<uint4*>(&S.mk[0][0]);
     z[tid] = make_uint4(0u, 0u, 0u, 0u);
     z[tid + NTHREADS] = make_uint4(0u, 0u, 0u, 0u);
@@ -1755,9 +2013,11 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     CL_ASM(CL, "" ::: "memory");
     __syncthreads();
     (void)writeback16<8, false>(X, acc, wave * 128, lane);
-    if (KEEP && lead) {
+    if (KEEP && (lead || MASK_OWN)) {
 #pragma unroll
-      for (int ob = 0; ob < 8; ++ob) mask_nibble_put(S, 0, wave * 8 + ob, 7, kq, ray, mask_nibble_of(acc[ob]));
+      for (int ob = 0; ob < 8; ++ob) {     // (MASK_OWN: the member's share of lin0 = the row blocks it owns in every 512-row layer)
+        if (!MASK_OWN || ((wave * 8 + ob) >> 2) == member) mask_nibble_put(S, 0, wave * 8 + ob, 7, kq, ray, mask_nibble_of(acc[ob]));
+      }
     }
     __syncthreads();
   }
@@ -1770,7 +2030,9 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
   static_assert(N1 >= CL_AHEAD, "the initial requests cover lin1's first chunks");
   constexpr int G1 = 0, G2 = G1 + N1, G3 = G2 + N1, G4 = G3 + N3, G5 = G4 + N4, G6 = G5 + N1, G7 = G6 + N1, GT = G7 + N1;
-  const bool kp = KEEP && lead;
+  const int kp = !KEEP ? 0 : MASK_OWN ? 2 : (lead ? 3 : 0);
+  // (behind lin0, whose compiler-generated loop may use any register: from here to the end of lin7 only the statements name these)
+  if constexpr (CL == 8) cl8_set_fixed(lds_off(X) + (uint32_t)lane * 4u, lds_off(X) + (uint32_t)((4 * kq * 16 + ray) * 4), (uint32_t)lane * 16u);
   if (!layer_cl<1, 512, 512, CL, G1, GT, 512, 512, 512, 256, true, true>(D16.Wf[1], D16.Wf[2], D16.Wf[3], D.bias[2], S, xc, xbase, member, kp)) return 0.f;
   if (!layer_cl<2, 512, 512, CL, G2, GT, 512, 256, 256, 512, false, true>(D16.Wf[2], D16.Wf[3], D16.Wf[4], D.bias[3], S, xc, xbase, member, kp)) return 0.f;
   if (!layer_cl<3, 512, 256, CL, G3, GT, 256, 512, 512, 512, false, true>(D16.Wf[3], D16.Wf[4], D16.Wf[5], c4, S, xc, xbase, member, kp)) return 0.f;
@@ -1778,7 +2040,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   if (!layer_cl<5, 512, 512, CL, G5, GT, 512, 512, 512, 512, false, true>(D16.Wf[5], D16.Wf[6], D16.Wf[7], D.bias[6], S, xc, xbase, member, kp)) return 0.f;
   if (!layer_cl<6, 512, 512, CL, G6, GT, 512, 512, 0, 0, false, true>(D16.Wf[6], D16.Wf[7], nullptr, D.bias[7], S, xc, xbase, member, kp)) return 0.f;
   if (!lead && !ALL_LIN8) {
-    (void)layer_cl<7, 512, 512, CL, G7, GT, 0, 0, 0, 0, false, false>(D16.Wf[7], nullptr, nullptr, nullptr, S, xc, xbase, member, false);
+    (void)layer_cl<7, 512, 512, CL, G7, GT, 0, 0, 0, 0, false, false>(D16.Wf[7], nullptr, nullptr, nullptr, S, xc, xbase, member, 0);
     return 0.f;                          // (the slice stores complete before the wave ends)
   }
   if (!layer_cl<7, 512, 512, CL, G7, GT, 0, 0, 0, 0, false, true>(D16.Wf[7], nullptr, nullptr, nullptr, S, xc, xbase, member, kp)) return 0.f;
@@ -1786,13 +2048,13 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     const char* slot7 = xbase + ((7 + xc.par) & 1) * XSLOT_BYTES;
     const uint32_t tag7 = (xc.epoch << 3) | 7u;
     constexpr int PER7 = 32 / CL;
-    cl_stage_unit<CL, 0, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<CL, 0, 0>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
     cl_request_unit<CL, 1>(slot7, wave, lane);
     cl_request_unit<CL, 2>(slot7, wave, lane);
-    cl_stage_unit<CL, 1, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<CL, 1, 4>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
     cl_request_unit<CL, 3>(slot7, wave, lane);
-    cl_stage_unit<CL, 2, 4>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
-    cl_stage_unit<CL, 3, 0>(slot7, tag7, member * PER7, PER7, S, tid, KEEP && lead, 7, 7);
+    cl_stage_unit<CL, 2, 4>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
+    cl_stage_unit<CL, 3, 0>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
     __syncthreads();
     if (S.fail) { cl_wait_vm<0>(); return 0.f; }
   }

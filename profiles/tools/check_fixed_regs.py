@@ -1,5 +1,5 @@
 """The cluster tile (csrc/distr_mlp.hpp) keeps its weight ring, accumulators and granule landing zone in FIXED registers that only its
-asm statements name (a[96:255] at most, v[224:255]); every statement lists them as clobbered so that the compiler keeps nothing there
+asm statements name (a[96:255] at most, v[224:255]; with 8 members also v[202:223]: B fragments and per-lane constants); every statement lists them as clobbered so that the compiler keeps nothing there
 across them. This checks the generated code: inside the span of the cluster code (first .. last asm statement that names a fixed
 register) no COMPILER-generated instruction may name one of them.
 
@@ -32,6 +32,8 @@ def main():
         k = bisect.bisect_right(mf_idx, i) - 1
         base = mf[max(k, 0)][1]
         return {0xf8: 120, 0xfc: 120, 0xf0: 112, 0xe0: 96}.get(base & ~7 if base >= 0xf8 else base & ~15, a_lo)
+    def v_limit(i):      # 8 members: v[202:255] (B fragments v[208:223], per-lane constants v[202:207]); else the landing zone only
+        return 202 if a_limit(i) == 120 else v_lo
     WIN = 300          # a compiler instruction is "inside cluster code" when fixed-register statements lie within WIN lines on both sides
     in_asm = False
     hits = []
@@ -54,7 +56,7 @@ def main():
         for m in re.finditer(r'\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]', l.split(';')[0]):
             f = m.group(1) or m.group(3)
             top = int(m.group(2)) if m.group(2) else int(m.group(5))
-            if (f == 'a' and top >= al) or (f == 'v' and top >= v_lo):
+            if (f == 'a' and top >= al) or (f == 'v' and top >= v_limit(i)):
                 hits.append((i, l))
                 break
     print('%s: cluster code spans lines %d..%d; compiler instructions naming a%d+ / v%d+ inside it: %d' % (key, lo, hi, a_lo, v_lo, len(hits)))

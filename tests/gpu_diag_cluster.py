@@ -35,3 +35,8 @@ for l in range(1, 8):
     prev = d
 print('total to lin8 start: %.2f us' % ((ts[32] - t0) / 100.0))
 print('shader clock between the first and the last stamp: %.2f GHz (%.0f cycles in %.2f us)' % ((ts[41] - ts[40]) / ((ts[32] - ts[0]) * 10.0) , ts[41] - ts[40], (ts[32] - ts[0]) / 100.0))
+if ts[42] > 0:     # a -DDISTR_XTS_UNITS build: layer 2, per unit: end of statement A (+ staging of the next unit), end of statement B
+    p = ts[7]
+    for u in range(4):
+        print('layer 2 unit %d: A (+ staging, barrier) %.2f | B %.2f us' % (u, (ts[42 + 2 * u] - p) / 100.0, (ts[43 + 2 * u] - ts[42 + 2 * u]) / 100.0))
+        p = ts[43 + 2 * u]

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--out', default=None)
     ap.add_argument('--arith', default='f32')
+    ap.add_argument('--no-save', action='store_true', help='forward only: no ReLU masks saved for the backward (distr_render_cfg.save_for_backward = 0)')
     args = ap.parse_args()
     import ctypes as C
     import bench
@@ -46,6 +47,8 @@ def main():
     K = fixture.make_intrinsic(H, W)
     R, T = bench.view_camera(fixture, args.view)
     cfg = binding.make_cfg((H, W), K, march_step=args.march_step, buffer_size=3, ratio=1.5, marcher=args.marcher, use_depth2normal=True, arith=args.arith)
+    if args.no_save:
+        cfg.save_for_backward = 0
     dev = eng.device
     P = H * W
     fwd_bytes, _ = eng.ctx.workspace_bytes(cfg)
