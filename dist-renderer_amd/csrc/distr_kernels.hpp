@@ -764,6 +764,42 @@ __global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_march(
   (void)march_tile<MODE, RB, KEEP, ARITH>(A, D, S, (int)blockIdx.x, (int)gridDim.x, A.which, A.origin_tile);
 }
 
+// KEEP, cluster tile of CL members: this member's share of the rays' mask blocks. Every member recorded the ReLU bits of the rows IT
+// computed in its S.mk (mlp_forward16_cl, MASK_OWN; zero elsewhere). In store_mask_chunk's format the bits of 64 consecutive rows of a
+// 512-row layer are one 32-bit word per half h -- word 32 (g / 2) + 2 layer + (g & 1) + 16 h for row group g = 0..7 -- and a member owns
+// 8 / CL whole groups; for lin3 (256 rows) four row blocks are word 32 w + 6 + 16 h (w = 0..3, the words 32 w + 7 + 16 h stay zero): a
+// member of 4 or 2 owns whole words, two members of 8 share one (16 bits each). Thread (ray, layer, h) stores the member's words: the
+// members together write every byte of the 512-byte block, nobody gathers. mb[ray] = index of the ray's block, < 0: none.
+template <int CL>
+__device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long long* mb, const Smem16CL& S, int member, int tid) {
+  const int j = tid >> 4, q = tid & 15;
+  const long long b = mb[j];
+  if (b < 0) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.mk[j][0]);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(mstore + (size_t)b * 32);
+  const int layer = q >> 1, h = q & 1;
+  if (layer != 3) {
+    constexpr int GPM = 8 / CL;
+#pragma unroll
+    for (int gi = 0; gi < GPM; ++gi) {
+      const int g = member * GPM + gi, wi = 32 * (g >> 1) + 2 * layer + (g & 1) + 16 * h;
+      dst[wi] = src[wi];
+    }
+  } else if constexpr (CL == 8) {
+    const int wi = 32 * (member >> 1) + 6 + 16 * h;
+    reinterpret_cast<uint16_t*>(dst + wi)[member & 1] = reinterpret_cast<const uint16_t*>(src + wi)[member & 1];
+    if (member & 1) dst[wi + 1] = 0u;
+  } else {
+    constexpr int WPM = 4 / CL;
+#pragma unroll
+    for (int wq = 0; wq < WPM; ++wq) {
+      const int wi = 32 * (member * WPM + wq) + 6 + 16 * h;
+      dst[wi] = src[wi];
+      dst[wi + 1] = 0u;
+    }
+  }
+}
+
 // Sticky tail tile (renderer.py:528-567 from the point where few rays are left): once ALL live rays of a step fit the cluster
 // tiles of one launch (<= 32 tiles of 16 rays, 8 compute units each), every tile marches ITS 16 rays through all remaining steps
 // inside that launch -- no compaction, no launch boundary, no device-wide barrier: tiles never exchange anything. The ray state
@@ -901,23 +937,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       if (tid < TILE) S.mb[tid] = mblock;
       __syncthreads();
       if (clustered) {
-        // every member holds the ReLU bits of the rows IT computed (S.mk, zero elsewhere): per layer and half (h) one 32-bit word of the
-        // ray's mask block -- word 32 (member / 2) + 2 layer + (member & 1) + 16 h: the member's four row blocks are its four bytes -- except
-        // for lin3 (256 rows): members 2 w and 2 w + 1 own the two 16-bit halves of word 32 w + 6 + 16 h, word 32 w + 7 + 16 h stays zero.
-        // Thread (ray, layer, h) stores the member's word: the eight members together write the whole 512-byte block, nobody gathers.
-        const int j = tid >> 4, q = tid & 15;
-        const long long b = S.mb[j];
-        if (b >= 0) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(&S.mk[j][0]);
-          uint32_t* dst = reinterpret_cast<uint32_t*>(V.mstore + (size_t)b * 32);
-          const int layer = q >> 1, wi = 32 * (member >> 1) + 2 * layer + 16 * (q & 1);
-          if (layer != 3) {
-            dst[wi + (member & 1)] = src[wi + (member & 1)];
-          } else {
-            reinterpret_cast<uint16_t*>(dst + wi)[member & 1] = reinterpret_cast<const uint16_t*>(src + wi)[member & 1];
-            if (member & 1) dst[wi + 1] = 0u;
-          }
-        }
+        store_own_mask_words<8>(V.mstore, S.mb, S, member, tid);    // every member: its own words of the rays' blocks
       } else {
         store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
       }
@@ -1048,14 +1068,19 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
   float pre;
   bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
+  bool helper = false;                  // a member of a cluster tile other than the lead (KEEP: it stores its words of the mask blocks, nothing else)
   if (MODE != MODE_EVAL && cl > 1) {
     if constexpr (MODE != MODE_EVAL) {
-      if (cl == 8) pre = mlp_forward16_cl<8, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-      else if (cl == 4) pre = mlp_forward16_cl<4, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-      else pre = mlp_forward16_cl<2, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+      // KEEP: every member evaluates lin8 too (ALL_LIN8) and records the ReLU bits of its own rows (MASK_OWN): it then knows where the rays'
+      // mask blocks go and stores its words of them itself -- the lead member does not extract bits from staged rows (that made it the
+      // last to publish in every layer). Without KEEP the other members leave after their last slice.
+      if (cl == 8) pre = mlp_forward16_cl<8, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+      else if (cl == 4) pre = mlp_forward16_cl<4, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
+      else pre = mlp_forward16_cl<2, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
     } else pre = 0.f;
-    if (member != cl_lead(cl)) return;   // only the lead member runs the epilogue
+    helper = member != cl_lead(cl);      // only the lead member runs the epilogue; with KEEP the others store their mask words
     clustered = S.fail == 0;
+    if (helper && (!KEEP || !clustered)) return;
     if (!clustered) {
       // the cluster did not assemble (compute units held by other streams / ranks) or a barrier timed out: the lead member
       // evaluates the tile on its own -- identical values; counted in the render stats (cluster_fallbacks)
@@ -1070,7 +1095,18 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   long long mblock = -1;
   if (tid < 64) {
     const float s = tanh_spec(pre);
-    if (origin) {
+    if (helper) {      // where the mask blocks go, nothing else (the lead member writes the step's results)
+      if (origin) {
+        if (tid == 0) mblock = V.morigin;
+      } else if (MODE == MODE_COARSE) {
+        if (valid) mblock = V.mfine + moff_sel(V, A.lvl) + (long long)((size_t)A.step * level_sel(V, A.lvl).n + id);
+      } else if (MODE == MODE_FINE) {
+        if (valid) {
+          const int slot = topk_slot_pre(V, st, s);
+          if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+        }
+      }
+    } else if (origin) {
       if (tid == 0) { V.C->f_origin = s; V.C->origin_done = 1; mblock = V.morigin; }
     } else if (MODE == MODE_EVAL) {
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
@@ -1105,15 +1141,10 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
   if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
-    if (clustered) {   // the lead member assembled the rays' mask blocks in LDS (mask_nibble_or)
-      const int j = tid >> 4, q = tid & 15;
-      const long long b = S.mb[j];
-      if (b >= 0) {
-        const uint4* src = reinterpret_cast<const uint4*>(&S.mk[j][0]);
-        uint4* dst = V.mstore + (size_t)b * 32;
-        dst[q] = src[q];
-        dst[q + 16] = src[q + 16];
-      }
+    if (clustered) {   // every member: its own words of the rays' blocks
+      if (cl == 8) store_own_mask_words<8>(V.mstore, S.mb, S, member, tid);
+      else if (cl == 4) store_own_mask_words<4>(V.mstore, S.mb, S, member, tid);
+      else store_own_mask_words<2>(V.mstore, S.mb, S, member, tid);
     } else {
       store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     }

@@ -2016,7 +2016,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     if (KEEP && (lead || MASK_OWN)) {
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob) {     // (MASK_OWN: the member's share of lin0 = the row blocks it owns in every 512-row layer)
-        if (!MASK_OWN || ((wave * 8 + ob) >> 2) == member) mask_nibble_put(S, 0, wave * 8 + ob, 7, kq, ray, mask_nibble_of(acc[ob]));
+        if (!MASK_OWN || (wave * 8 + ob) / (32 / CL) == member) mask_nibble_put(S, 0, wave * 8 + ob, 7, kq, ray, mask_nibble_of(acc[ob]));
       }
     }
     __syncthreads();

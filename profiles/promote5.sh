@@ -18,5 +18,11 @@ grep '^{' $F/bench_c5_n2_gloo.json > $P/${R}_bench_c5_n2_one_gpu_gloo.json
 for k in 2 4 8; do cp $F/r05_plan_check_c5_n$k.md $P/${R}_plan_check_c5_n$k.md; done
 # the timed GPU test run: summary line, slowest tests, wall clock
 ( grep -E "passed|failed" $F/pytest_gpu.log | tail -1; grep -E "^real" $F/pytest_gpu.log; echo; grep -E "^[0-9.]+s (call|setup)" $F/pytest_gpu.log ) > $P/${R}_pytest_gpu_durations.log
+( echo "# Soak run on one MI355X, final tree of round 5 (not part of the timed pytest -m gpu; profiles/run_round5.sh):"
+  echo "#   DISTR_TEST_RANDOM_CONFIGS=96 DISTR_TEST_STRESS_ITERS=400 python -m pytest tests/test_gpu_parity.py -q -k \"random_configs or oversubscription or many_streams or cluster_fallback\""
+  grep -E "passed|failed|^real" $F/soak.log
+  echo "#   DISTR_XCHG_SC1=1 DISTR_TEST_STRESS_ITERS=200 ... -k \"oversubscription or cluster_tiles_bit\"   (write-through slice stores forced: the mixed-XCD path)"
+  grep -E "passed|failed|^real" $F/soak_sc1.log ) > $P/${R}_soak.log
+cp $F/steps_137_100_nosave.md $P/${R}_steps_137_100_nosave.md
 python $P/make_traffic.py $P/$R > /dev/null
 ls -la $P | grep " ${R}_" | wc -l

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5 evidence (run from the repo root THROUGH gpurun; everything lands in <out>/, which gpurun merges back; promote4.sh copies what
+# Round 5 evidence (run from the repo root THROUGH gpurun; everything lands in <out>/, which gpurun merges back; promote5.sh copies what
 # is kept into profiles/). Round 5 changed the cluster tiles of the exact-f32 march (pipelined granule hand-off): the same set as round 4
 # (timed pytest -m gpu, bench lines, rocprofv3 kernel trace + the four separate PMC passes, per-launch step tables, single-view loops)
 # plus the cluster phase stamps and the C5 partition emulation.
@@ -47,4 +47,9 @@ for b in cluster_exchange2 mfma_chain_agpr; do [ -x profiles/ubench/$b ] && time
 DISTR_DIST_BACKEND=gloo python bench.py --workload c5 --gpus 2 --steps 2 --warmup 1 > "$OUT/bench_c5_n2_gloo.json" 2> "$OUT/bench_c5_n2_gloo.err"
 python profiles/plan_check_c5.py "$OUT" > "$OUT/plan_check_c5.log" 2>&1
 python tests/gpu_diag_batch.py 137 8 recursive 2>&1 | grep -v "amdgpu.ids\|Warning\|warn\|Consider\|return Variable" > "$OUT/batch_round.log"
+# soak (not part of the timed pytest -m gpu): 96 seeded random renderer configurations HIP vs oracle, the 8-stream oversubscription stress at 400
+# iterations, many streams, forced cluster fallback; then the stress with write-through slice stores forced (the mixed-XCD path)
+( time DISTR_TEST_RANDOM_CONFIGS=96 DISTR_TEST_STRESS_ITERS=400 python -m pytest tests/test_gpu_parity.py -q -k "random_configs or oversubscription or many_streams or cluster_fallback" ) > "$OUT/soak.log" 2>&1
+( time DISTR_XCHG_SC1=1 DISTR_TEST_STRESS_ITERS=200 python -m pytest tests/test_gpu_parity.py -q -k "oversubscription or cluster_tiles_bit" ) > "$OUT/soak_sc1.log" 2>&1
+python tests/gpu_diag_steps.py --size 137 --march-step 100 --no-save --out "$OUT/steps_137_100_nosave.md" > /dev/null 2>&1
 ls -la "$OUT" | tail -40
