@@ -20,6 +20,15 @@ def rows(path):
     return out
 
 
+def run_digest(pre):
+    """csrc digest of the library the PMC passes ran on: the bench line of the SAME run (profiles/rNN_bench.json, written on the GPU box by the
+    script that also made the passes) carries distr.binding.source_digest() of the box's tree; without that file: this tree's."""
+    try:
+        return json.load(open(pre + '_bench.json'))['roofline']['csrc_sha256']
+    except (OSError, KeyError, ValueError):
+        return __import__('distr.binding', fromlist=['source_digest']).source_digest()
+
+
 def main():
     pre = sys.argv[1]
     f, w, mf, l2 = (rows('%s_pmc_%s.md' % (pre, k)) for k in ('fetch', 'write', 'mfma', 'l2'))
@@ -39,8 +48,8 @@ def main():
                             'section); the weight fragments are buffer_load_dwordx4',
         'bytes_per_launch': int(round((2.0 * fetch + write) * 1024.0 / n)),
         # the sources the profiled libdistr.so was built from (distr.binding.source_digest): bench.py quotes bytes_per_launch only while
-        # csrc/ still has this digest -- run this script in the same tree state as the PMC passes
-        'csrc_sha256': __import__('distr.binding', fromlist=['source_digest']).source_digest(),
+        # csrc/ still has this digest
+        'csrc_sha256': run_digest(pre),
         'mfma_busy': {'k_step': round(busy('k_step'), 3), 'k_march_coarse': round(busy('k_march'), 3),
                       'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), profiles/%s_pmc_mfma.md; k_step covers all 44 '
                              'full-resolution steps of a forward including the latency-bound tail' % name},
