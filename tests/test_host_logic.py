@@ -726,3 +726,18 @@ def test_multi_view_pair_schedule_matches_reference_golden(monkeypatch):
         om.optimize_multi_view(None, None, code, torch.optim.SGD([code], lr=0.0), [None] * n, [None] * n, {}, num_views_per_round=v, num_iters=2,
                                sep_dist=sep, test_step=1000, distributed=False)
         assert rounds == g['pairs_%d_%d_%d' % (n, v, sep)].tolist(), (n, v, sep)
+
+
+def test_generated_kernel_text_matches_its_generators():
+    """The two hand-scheduled instruction streams in csrc/ are GENERATED text kept in the tree: distr_dense_asm.hpp (the 64-ray tile's
+    k-loop) is the output of gen_dense_asm.py, the CL8_*_TEXT macro block of distr_mlp.hpp (the 8-member cluster tile's unit statements)
+    the output of gen_cl8_units.py. Editing one side without the other must fail here."""
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, 'dist-renderer_amd', 'csrc')
+    out = subprocess.run([sys.executable, os.path.join(csrc, 'gen_dense_asm.py')], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout == open(os.path.join(csrc, 'distr_dense_asm.hpp')).read()
+    chk = subprocess.run([sys.executable, os.path.join(csrc, 'gen_cl8_units.py'), '--check', os.path.join(csrc, 'distr_mlp.hpp')],
+                         capture_output=True, text=True, timeout=120)
+    assert chk.returncode == 0, chk.stdout + chk.stderr
