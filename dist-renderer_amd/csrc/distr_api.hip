@@ -529,7 +529,10 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
   // DIAGNOSTICS ONLY (values are wrong): every 512 x 512 layer of the 16-ray / cluster tiles reads lin1's fragments, so that their weight
   // stream (2 MB instead of 6.3 MB) stays in one XCD's 4 MiB L2 -- separates "waiting for weights" from "issuing instructions" in the tail
-  if (D16 && getenv("DISTR_DEBUG_ALIAS_WEIGHTS")) for (int l : {2, 5, 6, 7}) D16->Wf[l] = D16->Wf[1];
+  if (D16 && getenv("DISTR_DEBUG_ALIAS_WEIGHTS")) {
+    fprintf(stderr, "distr: DISTR_DEBUG_ALIAS_WEIGHTS is set -- the 16-ray / cluster tiles compute with the WRONG weights (timing diagnostics only)\n");
+    for (int l : {2, 5, 6, 7}) D16->Wf[l] = D16->Wf[1];
+  }
   if (B6) {   // split-bf16 planes of lin1..lin7 for the opt-in arithmetic mode (distr_mlp_eval_bf16x6): 9.4 MB, own allocation
     std::vector<uint16_t> hb;
     size_t offb[8] = {0}, offbt[8] = {0};

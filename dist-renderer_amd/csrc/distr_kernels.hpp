@@ -805,7 +805,8 @@ __device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long l
 // inside that launch -- no compaction, no launch boundary, no device-wide barrier: tiles never exchange anything. The ray state
 // (march depth, bounds, selected-row keys) lives in registers of wave 0; after the layer-7 exchange every member holds h7, so
 // every member computes lin8 and mirrors the depth update and the live test itself (identical arithmetic, nothing to
-// broadcast); only the lead member writes to memory. Finished rays stay in the tile as dead lanes; the tile ends when none is
+// broadcast); only the lead member writes the step's results (depths, selected rows, counters) -- with saved masks every member stores
+// its own words of the rays' mask blocks (store_own_mask_words). Finished rays stay in the tile as dead lanes; the tile ends when none is
 // live. A ray's arithmetic is exactly the per-step one (same points, same k-ordered chains) -> bit-identical outputs. The step
 // launches the host still issues find empty live lists and exit in a few microseconds. A tile whose cluster does not assemble
 // (compute units held by another stream) is evaluated by its lead member alone and hands its rays back to the next step's live

@@ -1250,8 +1250,8 @@ __device__ __forceinline__ void cl8_set_fixed(uint32_t xb0, uint32_t xs0, uint32
                     CL8_LDW(4, "v202", "%[b1]"), CL8_LDW(5, "v203", "%[b1]"), CL8_LDW(6, "v204", "%[b1]"), CL8_LDW(7, "v205", "%[b1]")
 #define CL8_LOADS16 CL8_LDW(0, "v202", "%[b0]"), CL8_LDW(1, "v202", "%[b1]"), CL8_LDW(2, "v203", "%[b0]"), CL8_LDW(3, "v203", "%[b1]"), \
                     CL8_LDW(4, "v204", "%[b0]"), CL8_LDW(5, "v204", "%[b1]"), CL8_LDW(6, "v205", "%[b0]"), CL8_LDW(7, "v205", "%[b1]")
-// (generated by a script from the schedule above: B buffers rotate 208 / 212 / 216 / 220, requests behind the first two MFMAs of groups 0..3,
-// the staging block behind MFMAs 17 and 19, its verdict behind 21)
+// (generated: gen_cl8_units.py prints this block, `--check distr_mlp.hpp` compares it (tests/test_host_logic.py). B buffers rotate 208 / 212 /
+// 216 / 220, requests behind the first two MFMAs of groups 0..3, the staging block behind MFMAs 17..19, its verdict behind 20..22)
 #define CL8_A_TEXT(CL8_L0, CL8_L1, CL8_L2, CL8_L3, CL8_L4, CL8_L5, CL8_L6, CL8_L7) \
   "s_nop 4\n\t" \
   "s_waitcnt vmcnt(%[nw])\n\t" \
@@ -1625,8 +1625,8 @@ __device__ __forceinline__ void cl_load_start(const float* __restrict__ init, in
 // take part: the lead then evaluates the tile alone, the others leave. *sc1 (LDS, valid when the cluster assembled) = 1: the
 // members sit on more than one XCD, slices must be stored write-through.
 // The LEAD member of a cluster (it coordinates the assembly, runs the tile's epilogue -- march update, selected rows, mask blocks --
-// and evaluates the tile alone if the cluster breaks up) is its LAST member, not its first: everything only the lead does (the ReLU
-// bits of every staged unit, the epilogue of a sticky step) delays ITS slice, and a layer's k-loop consumes the slices in member
+// and evaluates the tile alone if the cluster breaks up) is its LAST member, not its first: everything only the lead does (the
+// epilogue of a step; before the own-row masks also the ReLU bits of every staged unit) delays ITS slice, and a layer's k-loop consumes the slices in member
 // order -- the last member's rows are needed ~1.5 us after the first member's, so up to that much lead-only work is hidden, while
 // the same work on member 0 stalls every member at the start of every layer.
 __device__ __forceinline__ constexpr int cl_lead(int cl) { return cl - 1; }
@@ -1670,8 +1670,8 @@ __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_
   __syncthreads();
 }
 
-// KEEP, lead member: the ReLU bits of 4 consecutive rows (row0 = multiple of 4) of ray jj, taken from the REGISTERS that hold the
-// values anyway (own slice at write-back, the other members' slices on their way into LDS), go into the ray's mask block as one
+// KEEP: the ReLU bits of 4 consecutive rows (row0 = multiple of 4) of ray jj, taken from the REGISTERS that hold the values anyway
+// (own slice at write-back; in the lead-gathers form, keep bit 0, also the other members' slices on their way into LDS), go into the ray's mask block as one
 // nibble with an LDS atomic-or (S.mk is zeroed at the start of the tile). Format of store_mask_chunk: chunk (w, h), word
 // layer*4 + ob, bit r <-> row w*WR + 32*ob + (r&3) + 8*(r>>2) + 4*h, WR = 1 << wr_log = rows per wave of the 32x32 tiles (128; 64
 // for lin3, whose words ob = 2, 3 stay zero). (Re-reading the finished layer from LDS cost 2 us per layer on the lead member.)
@@ -1958,11 +1958,11 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
   return true;
 }
 
-// Cluster forward. Every member returns after its last contribution; member 0 returns the pre-tanh value (ray = tid & 15)
-// and, with KEEP, has the rays' mask blocks in S.mk. Members != 0 return 0. On return S.fail != 0 (uniform over the
+// Cluster forward. Every member returns after its last contribution; the lead member returns the pre-tanh value (ray = tid & 15)
+// and, with KEEP and without MASK_OWN, has the rays' mask blocks in S.mk. The other members return 0 (unless ALL_LIN8). On return S.fail != 0 (uniform over the
 // workgroup) means this member gave up (cluster not assembled in time / a unit timed out): the lead member's caller then
 // evaluates the tile with mlp_forward16 (S.xyz is untouched), the other members simply leave.
-// ALL_LIN8 (sticky tiles): every member computes lin8 from its own copy of h7 and returns the pre-tanh value (all members then
+// ALL_LIN8 (sticky tiles; every cluster tile with saved masks): every member computes lin8 from its own copy of h7 and returns the pre-tanh value (all members then
 // mirror the march update in registers, no broadcast needed). MASK_OWN (with KEEP): EVERY member records the ReLU bits of the rows it
 // computes itself (its accumulators at write-back, its quarter-of-a-wave share of lin0) in its own S.mk -- in the mask-block format the four
 // row blocks of a member are exactly one 32-bit word per layer and half (two members share a word for the 256-row lin3) -- and nobody
