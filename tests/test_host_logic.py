@@ -741,3 +741,49 @@ def test_generated_kernel_text_matches_its_generators():
     chk = subprocess.run([sys.executable, os.path.join(csrc, 'gen_cl8_units.py'), '--check', os.path.join(csrc, 'distr_mlp.hpp')],
                          capture_output=True, text=True, timeout=120)
     assert chk.returncode == 0, chk.stdout + chk.stderr
+
+
+def test_cluster_members_own_disjoint_words_of_a_mask_block():
+    """The arithmetic behind csrc/distr_kernels.hpp::store_own_mask_words (round 5): in store_mask_chunk's format (restated from
+    distr_mlp.hpp::mask_nibble_put: 16-row block rb of `layer`, rows 4 kq .. 4 kq + 3 -> 32-bit word (idxu >> 1) + 16 (kq & 1) of the ray's
+    128-word block, bits [shift, shift + 4), idxu = 64 w + 4 layer + ob) the rows a member of a cluster of CL computes are, per layer and
+    half h, whole words -- except lin3 (256 rows) with 8 members, where two members share a word, 16 bits each. The words the members
+    store (plus the zero words of lin3) cover all 128 words of the block exactly once, for CL = 8, 4, 2."""
+    def put(layer, rb, wr_log, kq):
+        R = 16 * rb
+        w, ob = R >> wr_log, (R & ((1 << wr_log) - 1)) >> 5
+        idxu = 64 * w + 4 * layer + ob
+        return (idxu >> 1) + 16 * (kq & 1), 8 * (rb & 1) + 16 * (idxu & 1) + 4 * (kq >> 1)
+
+    for CL in (8, 4, 2):
+        written = {}                                   # (word, first bit, bits) -> member, as store_own_mask_words stores them
+        for m in range(CL):
+            for layer in range(8):
+                for h in (0, 1):
+                    if layer != 3:
+                        for gi in range(8 // CL):
+                            g = m * (8 // CL) + gi
+                            written[(32 * (g >> 1) + 2 * layer + (g & 1) + 16 * h, 0, 32)] = m
+                    elif CL == 8:
+                        wi = 32 * (m >> 1) + 6 + 16 * h
+                        written[(wi, 16 * (m & 1), 16)] = m
+                        if m & 1:
+                            written[(wi + 1, 0, 32)] = m
+                    else:
+                        for wq in range(4 // CL):
+                            wi = 32 * (m * (4 // CL) + wq) + 6 + 16 * h
+                            written[(wi, 0, 32)] = m
+                            written[(wi + 1, 0, 32)] = m
+        bits = np.zeros((128, 32), np.int32)
+        for (word, lo, n), m in written.items():
+            bits[word, lo:lo + n] += 1
+        assert (bits == 1).all(), CL                    # every bit of the 512-byte block stored exactly once
+        # the bits of every row land in a piece stored by the member that computes the row
+        for layer in range(8):
+            nblk, wr_log = (16, 6) if layer == 3 else (32, 7)
+            for rb in range(nblk):
+                owner = rb // (nblk // CL)
+                for kq in range(4):
+                    word, shift = put(layer, rb, wr_log, kq)
+                    piece = [k for k in written if k[0] == word and k[1] <= shift < k[1] + k[2]]
+                    assert len(piece) == 1 and written[piece[0]] == owner, (CL, layer, rb, kq)
