@@ -165,6 +165,120 @@ def cpu_baseline_torch(fixture, Ws, bs, latent, march_step, marcher, budget_s=70
             'c1_64x64_20steps': {'rays_per_s': 64 * 64 / t_c1, 'seconds': t_c1}}
 
 
+SMALL_RENDERS = (('c2_256x256_50', 256, 50), ('c1_64x64_20', 64, 20), ('drivers_137x137_100', 137, 100))
+
+
+def small_renders(eng, functions, binding, fixture, latent_np, dev, marcher, steps=10, warmup=4):
+    """extra.small_renders (N = 1, outside the headline's timed region, same protocol: warm-up, then K steps of fwd + dense loss + bwd
+    between synchronisations): the small-render regime on the driver's clock -- BASELINE configs C2 (256^2 / 50 steps) and C1 (64^2 / 20)
+    and 137^2 / 100 steps, the size the reference's own drivers run (run_single_shape.py:110-117). Per entry: ms per step, rays/s,
+    forward-only ms, and the march kernels' fraction of the f32-MFMA peak from one bracketed forward (roofline protocol)."""
+    out = {}
+    R, T = view_camera(fixture, 0)
+    for name, size, march in SMALL_RENDERS:
+        K = fixture.make_intrinsic(size, size)
+        cfg = binding.make_cfg((size, size), K, march_step=march, buffer_size=BUFFER_SIZE, ratio=RATIO, marcher=marcher, use_depth2normal=True)
+        lat = torch.from_numpy(np.asarray(latent_np, np.float32)).to(dev).requires_grad_(True)
+        Rt = torch.from_numpy(R).to(dev).requires_grad_(True)
+        Tt = torch.from_numpy(T).to(dev).requires_grad_(True)
+        rs = np.random.RandomState(5)
+        wd, wq, wn = (torch.from_numpy(rs.rand(*sh).astype(np.float32)).to(dev) for sh in ((size, size), (size, size), (size, size, 3)))
+
+        def one(backward=True):
+            z, mask, q, depth, normal = functions.render_call(eng, cfg, lat, Rt, Tt)
+            if not backward:
+                return
+            mb = mask.reshape(size, size).bool()
+            L = torch.where(mb, depth * wd, torch.zeros_like(depth)).sum() + (q.reshape(size, size) * wq).sum() + (normal * wn).sum()
+            lat.grad = Rt.grad = Tt.grad = None
+            L.backward()
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        with torch.no_grad():
+            one(False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one(False)
+            torch.cuda.synchronize()
+            fwd = (time.perf_counter() - t0) / steps
+        # one bracketed forward through the raw C ABI on a workspace of its own (the counters live in the workspace)
+        import ctypes as C
+        p = binding.ptr
+        P = size * size
+        ws = torch.empty(eng.ctx.workspace_bytes(cfg)[0], dtype=torch.uint8, device=dev)
+        o = [torch.empty(P, device=dev), torch.empty(P, dtype=torch.uint8, device=dev), torch.empty(P, device=dev), torch.empty(P, device=dev),
+             torch.empty(3 * P, device=dev)]
+        args_ = (eng.ctx.h, C.byref(cfg), p(lat.detach().reshape(-1).contiguous()), p(Rt.detach().reshape(-1).contiguous()), p(Tt.detach().contiguous()),
+                 p(o[0]), p(o[1]), p(o[2]), p(o[3]), p(o[4]), p(ws), ws.numel(), eng.ctx.stream())
+        eng.ctx.check(eng.ctx.L.distr_render_forward(*args_))
+        eng.ctx.profile_enable(True)
+        eng.ctx.check(eng.ctx.L.distr_render_forward(*args_))
+        launches, kernel_ms = eng.ctx.profile_read()
+        eng.ctx.profile_enable(False)
+        st = eng.ctx.render_stats(cfg, ws)
+        tf = FLOP_PER_EVAL * st['num_point_evals'] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        out[name] = {'size': size, 'march_steps': march, 'ms_per_step': 1e3 * el, 'rays_per_s': size * size / el, 'forward_only_ms': 1e3 * fwd,
+                     'march_launches': int(launches), 'march_kernel_ms': kernel_ms, 'march_tflops': tf, 'march_frac_of_peak': tf / PEAK_F32_MFMA_TFLOPS,
+                     'decoder_evals': st['num_point_evals'], 'tail_from': st['tail_from'], 'tail_steals': st['tail_steals'],
+                     'cluster_fallbacks': st['cluster_fallbacks'], 'steps': steps, 'warmup': warmup}
+    return out
+
+
+# measured on one MI355X (profiles/r03_view_balance.md, r05_plan_check_c5_n8.md): what --plan-only predicts from without a GPU
+VIEW_MS_512 = (52.60, 54.28, 51.20, 50.40, 48.14, 46.74, 49.78, 58.94)     # one 512^2 / 50-step view of the C4 camera circle, fwd + loss + bwd
+C5_IMAGE_MS = 202.4                                                          # one 1024^2 / 100-step image of C5 (810 ms for the four as one batch)
+C5_LOWER_HALF = 1.048                                                        # a row of the lower image half costs this x the mean row (upper: 0.952)
+
+
+def plan_only(args):
+    """`bench.py --gpus N --plan-only [--workload c5]`: the partition an N-rank run starts from (before any in-run calibration) and the
+    load it predicts for every rank, as ONE JSON line -- no GPU, no process group. The prediction is a static model fitted to
+    single-GPU measurements (constants above): a first multi-GPU run that scales badly is read against it -- one rank's `local_ms`
+    (config.per_rank of the real line) far above its prediction is a straggler, all of them above it is the node."""
+    from distr import parallel
+    n = args.gpus
+    c5 = args.workload == 'c5'
+    size = 1024 if c5 else 512
+    parts, pred = [], []
+    if c5:
+        for r in range(n):
+            pieces = parallel.shard_rows(4, size, r, n)
+            parts.append([[img, 0, r0, r1] for (img, r0, r1) in pieces])
+            ms = 0.0
+            for (img, r0, r1) in pieces:
+                up = max(0, min(r1, size // 2) - r0)
+                lo = (r1 - r0) - up
+                ms += C5_IMAGE_MS * ((2.0 - C5_LOWER_HALF) * up + C5_LOWER_HALF * lo) / size
+                ms += 0.0 if (r0, r1) == (0, size) else ROW_BAND_FIXED * C5_IMAGE_MS
+            pred.append(ms)
+        t1 = 4 * C5_IMAGE_MS
+        eff = (t1 / n) / max(pred)
+    else:
+        for r in range(n):
+            views = parallel.shard_views(n, r, n)
+            parts.append([[0, (v + args.view_offset) % 8, 0, size] for v in views])
+            pred.append(sum(VIEW_MS_512[(v + args.view_offset) % 8] for v in views))
+        eff = VIEW_MS_512[args.view_offset % 8] / max(pred)
+    line = {'plan_only': True, 'workload': args.workload, 'n_gpus': n, 'scaling': 'strong' if c5 else 'weak',
+            'partition': parts, 'partition_note': 'per rank: [shape, view, first row, end row] of every piece it renders per step',
+            'predicted_ms_per_rank': pred, 'predicted_slowest_ms': max(pred), 'predicted_mean_ms': sum(pred) / n,
+            'predicted_efficiency_vs_n1': eff,
+            'cost_model': 'static, from single-GPU measurements (profiles/r03_view_balance.md, profiles/r05_plan_check_c5_n8.md): '
+                          + ('rows of the lower image half x %.3f, +%.0f %% of an image per band that is not a whole image' % (C5_LOWER_HALF, 100 * ROW_BAND_FIXED)
+                             if c5 else 'per-view step time of the C4 camera circle'),
+            'in_run_rebalancing': ('cost-weighted row cut from the rendered masks + measured loads, up to %d rounds, best measured cut kept' % ROW_FEEDBACK_ROUNDS)
+                                  if c5 else 'slow views hand 4-row-aligned bands to fast ranks (parallel.balance_views), value switches only beyond a %.0f %% margin' % (100 * BALANCE_MARGIN)}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-execute this very command line under torch.distributed.run with N ranks on
     this node (one per GPU), a free rendezvous port on 127.0.0.1, and the IPC mode RCCL needs. Returns the launcher's exit code."""
@@ -222,7 +336,12 @@ def main():
     ap.add_argument('--workload', default='c3', choices=['c3', 'c5'],
                     help='c3 (default, the headline metric): one 512x512 view per GPU, weak scaling; '
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
+    ap.add_argument('--plan-only', action='store_true',
+                    help='print the partition of an N-rank run and the per-rank load a static cost model predicts for it (one JSON line; no GPU, no ranks)')
+    ap.add_argument('--no-small-renders', action='store_true', help='skip extra.small_renders (C2, C1 and 137^2 / 100 steps timed beside the headline at N = 1)')
     args = ap.parse_args()
+    if args.plan_only:
+        sys.exit(plan_only(args))
     if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         if os.environ.get('DISTR_BENCH_SPAWNED'):
             raise SystemExit('bench.py: spawned rank without RANK / WORLD_SIZE in its environment')
@@ -696,6 +815,13 @@ def main():
         except Exception:
             traffic = None
     rccl_info = collective_info(world, local)           # (collective: every rank takes part in the all-gather)
+    partition = None
+    if world > 1:
+        partition = [None] * world
+        torch.distributed.all_gather_object(partition, [list(it) for it in items])
+    small = None
+    if world == 1 and not args.no_small_renders and not c5 and not args.items and args.arith == 'f32' and (H, MARCH_STEP) == (512, 50):
+        small = small_renders(eng, functions, binding, fixture, latent_np, dev, args.marcher)
     if rank == 0:
         evals = stats['num_point_evals'] * ROOF_STEPS
         flops = FLOP_PER_EVAL * evals
@@ -747,8 +873,13 @@ def main():
                 m = split_modes[mode]
                 m.update(value=rays / m.pop('elapsed_s'), unit='rays/s', speedup_vs_exact_f32=(elapsed / args.steps) / (m['ms_per_step'] * 1e-3), note=notes[mode])
                 out[key] = m
+        if small is not None:
+            out['extra'] = {'small_renders': small,
+                            'small_renders_note': 'not part of `value`: the same fwd + dense loss + bwd step at BASELINE configs C2 / C1 and at the size the '
+                                                  "reference's drivers run, timed after the headline with the same protocol (warm-up, K steps between synchronisations)"}
         if world > 1:
             c = out['config']
+            c['partition'] = partition
             c['serial_check'] = serial_check
             c['per_rank'] = diag
             c['scaling_measurement'] = bool(rccl_info.get('one_gpu_per_rank'))       # false on test rigs whose ranks time-share one GPU over gloo

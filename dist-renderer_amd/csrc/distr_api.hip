@@ -1,5 +1,6 @@
 // distr_api.hip -- host side of libdistr.so: C ABI (include/distr.h), weight-fragment packer, workspace carving,
-// kernel launch sequences. Built with: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared.
+// kernel launch sequences. Built with: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC (-c, next to the distr_inst.hip
+// groups; distr.binding.build_library links them into libdistr.so).
 // No device allocation / synchronisation happens inside forward/backward (caller-owned workspaces, caller's stream).
 #include <hip/hip_runtime.h>
 
@@ -12,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "distr_kernels.hpp"
+#include "distr_inst.hpp"      // distr_kernels.hpp + the big template kernels as extern templates (their code: distr_inst.hip, per group)
 #include "distr_losses.hpp"
 #include "distr_mlp_b6.hpp"
 
@@ -53,6 +54,24 @@ struct distr_ctx {
   int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
   bool sticky = true;           // DISTR_STICKY=0: cluster tiles never keep their rays across march steps (sticky_tile16)
   int xchg_sc1 = 0;             // DISTR_XCHG_SC1=1 (tests): write-through slice stores even for clusters on one XCD (the mixed-XCD path)
+  // Persistent tail launch (k_tail): the full-resolution steps from `tail_from` on run inside one launch. tail_from is a HOST decision
+  // taken without synchronising: the step at which the PREVIOUS render of the same configuration first had at most tail_rays live rays
+  // (k_finalize writes it to a host-mapped word, read here whenever the next render is enqueued: stale is fine, k_tail is correct for any
+  // count); no hint yet (a configuration's first render): no tail launch. tail_rays sits just above the 496 rays at which a step's tiles
+  // turn sticky: a step inside k_tail costs a few microseconds MORE than a launch of its own (claim + release / acquire fences against a
+  // launch boundary, profiles/r06_tail_steps.md), what the tail launch saves is every launch the host would issue behind the last live
+  // ray -- so it takes over right where the sticky tiles would.
+  bool tail = true;             // DISTR_TAIL=0: one launch per step to the end (rounds 1-5)
+  int tail_px = 0;              // DISTR_TAIL_PX: renders of at most this many pixels start the tail launch at step 0 (0: hint only)
+  int tail_rays = 640;          // DISTR_TAIL_RAYS
+  int tail_force = -1;          // DISTR_TAIL_FROM=n (tests): tail_from = n for every render of the recursive marchers
+  int tail_absent = 0;          // DISTR_TAIL_TEST_ABSENT=n (tests): the first n workgroups of the tail launch leave at once (never resident)
+  struct TailHint { int32_t key[10]; bool used = false; uint64_t last_use = 0; };
+  static constexpr int NHINT = 16;
+  TailHint hints[NHINT];
+  int32_t* hint_host = nullptr; // NHINT host-mapped words (hipHostMalloc): -1 = nothing written yet
+  int32_t* hint_dev = nullptr;
+  bool hint_failed = false;
 };
 
 namespace {
@@ -276,7 +295,7 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
 // stream (no stale word or tag may equal a future one) and counting restarts at 1.
 inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl, int test_abort, int min_cl, uint32_t epochs = 1, bool sticky = false,
                       int force_sc1 = 0) {
-  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1, force_sc1};
+  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1, force_sc1, 0};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
   if (r) {
     if (r->epoch > 0x0fffffffu - epochs - 1) {
@@ -288,6 +307,42 @@ inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl,
     r->epoch += epochs;
   }
   return x;
+}
+
+// Slot of this render configuration in the tail-hint table (least recently used entry replaced; its word restarts at -1 = no hint).
+// Null when the host-mapped words cannot be had (allocation failed once, or the stream is capturing: no allocation inside a capture).
+int32_t* tail_hint_slot(distr_ctx* ctx, const distr_render_cfg& c, int nviews, bool capturing, int32_t** dev_word) {
+  *dev_word = nullptr;
+  if (ctx->hint_failed) return nullptr;
+  if (!ctx->hint_host) {
+    if (capturing) return nullptr;
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, distr_ctx::NHINT * sizeof(int32_t), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h) (void)hipHostFree(h);
+      ctx->hint_failed = true;
+      return nullptr;
+    }
+    ctx->hint_host = (int32_t*)h; ctx->hint_dev = (int32_t*)d;
+    for (int i = 0; i < distr_ctx::NHINT; ++i) ctx->hint_host[i] = -1;
+  }
+  const int32_t key[10] = {c.H, c.W, c.row0, c.rows, c.march_step, c.coarse_steps[0], c.coarse_steps[1], c.marcher, c.buffer_size, nviews};
+  static uint64_t clock = 0;
+  int lru = 0;
+  for (int i = 0; i < distr_ctx::NHINT; ++i) {
+    auto& h = ctx->hints[i];
+    if (h.used && memcmp(h.key, key, sizeof(key)) == 0) { h.last_use = ++clock; *dev_word = ctx->hint_dev + i; return ctx->hint_host + i; }
+    if (!h.used) { lru = i; break; }
+    if (h.last_use < ctx->hints[lru].last_use) lru = i;
+  }
+  auto& h = ctx->hints[lru];
+  if (h.used && capturing) return nullptr;      // (re-using a slot resets its word from the host: not while a capture records device writes to it)
+  memcpy(h.key, key, sizeof(key));
+  h.used = true; h.last_use = ++clock;
+  __atomic_store_n(ctx->hint_host + lru, -1, __ATOMIC_RELAXED);
+  *dev_word = ctx->hint_dev + lru;
+  return ctx->hint_host + lru;
 }
 
 inline int band_rows(const distr_render_cfg& c) { return c.rows > 0 ? c.rows : c.H; }
@@ -338,6 +393,8 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
   V.tk_s = cv.take<float>(bs * P); V.tk_zb = cv.take<float>(bs * P); V.tk_za = cv.take<float>(bs * P);
   V.tk_src = cv.take<int32_t>(bs * P);
   V.tk_slot = cv.take<int32_t>(bs * P);
+  V.tclaim = cv.take<int32_t>(P / 16 + 2);
+  V.tail_from = V.fine_steps;
   V.zdepth_s = cv.take<float>(P); V.depth_pre = cv.take<float>(P); V.nrm_t = cv.take<float>(3 * P);
   V.mask_s = cv.take<uint8_t>(P);
   V.nlist = cv.take<int32_t>(P); V.n_sdf = cv.take<float>(P); V.n_g = cv.take<float>(3 * P);
@@ -390,7 +447,7 @@ struct MarchTimer {  // optional hipEvent bracket around the march kernel launch
 
 extern "C" {
 
-const char* distr_version(void) { return "distr 0.4 (ABI 4; gfx950, f32 MFMA)"; }
+const char* distr_version(void) { return "distr 0.5 (ABI 5; gfx950, f32 MFMA)"; }
 
 uint32_t distr_abi_version(void) { return DISTR_ABI_VERSION; }
 
@@ -414,6 +471,11 @@ int distr_create_abi(distr_ctx** out, int hip_device, uint32_t abi_version) {
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   if (const char* e = getenv("DISTR_STICKY")) ctx->sticky = atoi(e) != 0;
   if (const char* e = getenv("DISTR_XCHG_SC1")) ctx->xchg_sc1 = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_TAIL")) ctx->tail = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_TAIL_PX")) ctx->tail_px = atoi(e);
+  if (const char* e = getenv("DISTR_TAIL_RAYS")) ctx->tail_rays = atoi(e);
+  if (const char* e = getenv("DISTR_TAIL_FROM")) ctx->tail_force = atoi(e);
+  if (const char* e = getenv("DISTR_TAIL_TEST_ABSENT")) ctx->tail_absent = atoi(e);
   {
     // invariants of the tile-size split (fine_split and the host-side grid sizes rely on them): multiples of 64,
     // 64 <= t16 <= t32, and t16 + t32 below one full round (16384 rays) so that "remainder" ranges never reach a round
@@ -444,6 +506,7 @@ void distr_destroy(distr_ctx* ctx) {
   if (ctx->dec_buf_color) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_color); }
   if (ctx->dec_buf_b6) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->dec_buf_b6); }
   for (auto& r : ctx->xr) { if (r.buf) (void)hipFree(r.buf); if (r.flags) (void)hipFree(r.flags); }
+  if (ctx->hint_host) (void)hipHostFree(ctx->hint_host);
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   delete ctx;
 }
@@ -705,6 +768,24 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
   const unsigned NV = (unsigned)nviews;
   auto gridv = [&](int64_t n) { return dim3((unsigned)((n + 255) / 256), NV); };   // (blocks of 256, view)
 
+  // persistent tail launch: from which full-resolution step on (see distr_ctx::tail)
+  int32_t* hint_dev = nullptr;
+  if (cfg->marcher != DISTR_MARCH_TRIVIAL && cfg->arith == DISTR_ARITH_F32 && ctx->tail && !cfg->concurrent && ctx->tail16_threshold > 0) {
+    bool capturing = false;
+    {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+      else capturing = cs != hipStreamCaptureStatusNone;
+    }
+    int32_t* hint = tail_hint_slot(ctx, *cfg, nviews, capturing, &hint_dev);
+    if (ctx->tail_force >= 0) V.tail_from = std::min(ctx->tail_force, V.fine_steps);
+    else if ((int64_t)nviews * P <= ctx->tail_px) V.tail_from = 0;
+    else if (hint) {
+      const int32_t h = __atomic_load_n(hint, __ATOMIC_RELAXED);
+      if (h >= 0 && h + 2 <= V.fine_steps) V.tail_from = h;      // (nothing to gain from a tail of one step)
+    }
+  }
+
   hipLaunchKernelGGL(k_prep, dim3(4, NV), dim3(256), 0, s, V, D, latent, lat_stride, R, T, vf);
   LAUNCH_CHECK("k_prep");
   for (int l = 0; l < V.nlev; ++l) {
@@ -782,6 +863,18 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
   for (int st = 0; st < V.fine_steps; ++st) {
     A.lvl = 0; A.step = st;
     timer.begin();
+    if (st == V.tail_from) {
+      // every remaining step inside this launch (k_tail): 256 workgroups, one per compute unit
+      A.origin_tile = 1;
+      A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky, ctx->xchg_sc1);
+      A.xc.t_go = TAIL_T_GO;
+      A.tail_absent = ctx->tail_absent;
+      if (V.save_masks) hipLaunchKernelGGL((k_tail<true>), dim3(256), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+      else hipLaunchKernelGGL((k_tail<false>), dim3(256), dim3(NTHREADS), 0, s, A, D, ctx->D16);
+      timer.end();
+      LAUNCH_CHECK("k_tail");
+      break;
+    }
     if (!recursive) {
       // 'trivial': every in-sphere ray, every step, on 64-ray tiles
       A.origin_tile = (st == 0) ? 1 : 0;
@@ -831,7 +924,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
     timer.end();
     LAUNCH_CHECK("k_step");
   }
-  hipLaunchKernelGGL(k_finalize, gridv(P), dim3(256), 0, s, V, zdepth, mask, min_sdf, depth);
+  hipLaunchKernelGGL(k_finalize, gridv(P), dim3(256), 0, s, V, zdepth, mask, min_sdf, depth, hint_dev, (int32_t)ctx->tail_rays);
   LAUNCH_CHECK("k_finalize");
   if (cfg->want_normal) {
     if (cfg->use_depth2normal) {
@@ -1180,13 +1273,15 @@ int distr_get_render_stats(distr_ctx* ctx, const distr_render_cfg* cfg, const vo
   for (int l = 1; l < V.nlev; ++l) { ev += (int64_t)V.lv[l].steps * C->cnt_level[l]; launches += V.lv[l].steps; }
   if (cfg->marcher == DISTR_MARCH_TRIVIAL) ev += (int64_t)V.fine_steps * C->cnt_level[0];
   else for (int t = 0; t < V.fine_steps; ++t) ev += C->cnt_live[t] + C->cnt_sticky[t];
-  launches += V.fine_steps;
+  launches += (C->tail_from < V.fine_steps) ? C->tail_from + 1 : V.fine_steps;     // (steps from tail_from on share one launch: k_tail)
   out->num_point_evals = ev;
   out->num_march_launches = launches;
   out->num_valid = C->cnt_valid;
   out->num_grad_samples = C->cnt_samples;
   out->cluster_fallbacks = C->xchg_err;
   out->f16_overflows = C->f16_overflow;
+  out->tail_from = C->tail_from;
+  out->tail_steals = C->tail_steals;
   return DISTR_OK;
 }
 

@@ -43,6 +43,13 @@ struct Consts {
   int32_t cnt_live[MAX_STEPS + 2];  // live rays entering fine step t (compacted list of that step's launch)
   int32_t cnt_sticky[MAX_STEPS + 2]; // rays evaluated at fine step t by sticky tiles (no list: sticky_tile16); statistics only
   int32_t f16_overflow;   // split-f16 arithmetic (cfg.arith = 2): decoder evaluations whose value left the f16 range (non-finite result)
+  // persistent tail kernel (k_tail): fine steps [tail_from, fine_steps) run inside ONE launch (tail_from = fine_steps: no tail launch).
+    int32_t tail_from;
+  int32_t tail_steals;    // tiles a workgroup other than their owner evaluated after waiting too long (owner not resident); statistics
+  // tail_sync[2k] = virtual tiles of step tail_from + k evaluated with their stores complete (view 0's only: the step barrier);
+  // tail_sync[2k + 1] = THIS view's live rays entering step tail_from + k + 1 (= cnt_live of that step, kept next to the barrier word so
+  // that one 8-byte load answers both "is the step over" and "how many rays does the next one have")
+  alignas(8) int32_t tail_sync[2 * (MAX_STEPS + 2)];
 };
 
 struct LevelView {
@@ -69,6 +76,8 @@ struct View {
   float *tk_s, *tk_zb, *tk_za;   // [bs][P] selected rows: sdf, depth before, depth after (pyramid) / marching depth after
   int32_t* tk_src;               // [bs][P] row source (see src_* helpers) or -1 for a padded row
   int32_t* tk_slot;              // [bs][P] physical ReLU-mask slot (0..bs) of the entry
+  int32_t* tclaim;               // [P/16 + 2] k_tail: claim word of the view's 16-ray tiles (last step index + 1 somebody took the tile at)
+  int32_t tail_from;             // first full-resolution step of the persistent tail launch (host decision; = fine_steps: none)
   // ReLU masks saved for the backward pass: one 512-byte block (8 layers x 512 bits) per kept row.
   //   block = px*(bs+1) + slot                      rows of the full-resolution march
   //   block = mfine + moff[lvl] + step*n_lvl + ray  rows of the coarse pyramid levels
@@ -106,7 +115,7 @@ __device__ __forceinline__ View view_at(const View& V0, int b) {
   }
   adv(V.live[0], d); adv(V.live[1], d);
   adv(V.m, d); adv(V.init_now, d); adv(V.maxbound, d); adv(V.minabs, d); adv(V.first_sdf, d);
-  adv(V.tk_s, d); adv(V.tk_zb, d); adv(V.tk_za, d); adv(V.tk_src, d); adv(V.tk_slot, d);
+  adv(V.tk_s, d); adv(V.tk_zb, d); adv(V.tk_za, d); adv(V.tk_src, d); adv(V.tk_slot, d); adv(V.tclaim, d);
   adv(V.mstore, d);
   adv(V.zdepth_s, d); adv(V.depth_pre, d); adv(V.nrm_t, d); adv(V.mask_s, d);
   adv(V.nlist, d); adv(V.n_sdf, d); adv(V.n_g, d);
@@ -222,16 +231,35 @@ __device__ __forceinline__ CamRegs load_cam(const Consts* C) {
   return k;
 }
 
-// wave-level stream compaction: appends `id` of flagged lanes to list, one atomic per wavefront
-__device__ __forceinline__ void wave_append(bool flag, int32_t id, int32_t* list, int32_t* counter) {
+// XC = true: write-through stores (sc1: nothing stays dirty in this XCD's L2) and L1-bypassing loads -- the fence-free hand-off form of
+// MI355X_MICROARCH.md ("sc1 stores AND sc1 loads"). Measured for the per-ray march state inside the persistent tail launch (k_tail) and NOT
+// used there: every step got slower than with plain accesses + one release / acquire fence per tile (137 x 137 / 100 steps: 7.94 against
+// 7.46 ms) -- a write-through store is acknowledged by memory, not by the L2, and the cluster tile's counted vmcnt waits of the next
+// layers queue up behind it. Kept for the one place that needs it: the mask words a HELPER member of a cluster stores (nobody releases
+// those, store_own_mask_words). XC = false: plain accesses.
+template <bool XC, class T>
+__device__ __forceinline__ T ld_x(const T* p) {
+  if constexpr (XC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool XC, class T>
+__device__ __forceinline__ void st_x(T* p, T v) {
+  if constexpr (XC) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// wave-level stream compaction: appends `id` of flagged lanes to list, one atomic per wavefront (counter2: a second counter that gets
+// the same increment -- k_tail keeps the next step's count next to the step's barrier word)
+template <bool XC = false>
+__device__ __forceinline__ void wave_append(bool flag, int32_t id, int32_t* list, int32_t* counter, int32_t* counter2 = nullptr) {
   const unsigned long long ball = __ballot(flag);
   if (ball == 0ull) return;
   const int lane = threadIdx.x & 63;
   const int n = __popcll(ball);
   int base = 0;
-  if (lane == 0) base = atomicAdd(counter, n);
+  if (lane == 0) { base = atomicAdd(counter, n); if (counter2) atomicAdd(counter2, n); }
   base = __shfl(base, 0);
-  if (flag) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = id;
+  if (flag) st_x<XC>(list + base + __popcll(ball & ((1ull << lane) - 1ull)), id);
 }
 
 // block-level stream compaction for the full-image setup kernels (256 threads): one atomic per BLOCK -- with one per
@@ -264,7 +292,7 @@ struct ViewFlags { uint8_t f[DISTR_MAX_VIEWS]; };   // VF_* of every view of the
 
 // grid (4, nviews): camera constants, latent constants c0 / c4 and counter reset of every view of the batch; view b reads
 // latent + b * lat_stride (lat_stride = 0: one shape code shared by all views), R + 9 b, T + 3 b
-__global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float* __restrict__ latent0, int64_t lat_stride,
+DISTR_GLOBAL void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float* __restrict__ latent0, int64_t lat_stride,
                                               const float* __restrict__ R0, const float* __restrict__ T0, ViewFlags vf) {
   const int vb = blockIdx.y;
   Consts* C = view_at(V0, vb).C;
@@ -283,7 +311,7 @@ __global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float
   if (blockIdx.x == 0) {
     const int t = threadIdx.x;
     C->latent[t] = latent[t];
-    for (int i = t; i < MAX_STEPS + 2; i += 256) { C->cnt_live[i] = 0; C->cnt_sticky[i] = 0; }
+    for (int i = t; i < MAX_STEPS + 2; i += 256) { C->cnt_live[i] = 0; C->cnt_sticky[i] = 0; C->tail_sync[2 * i] = 0; C->tail_sync[2 * i + 1] = 0; }
     for (int i = t; i < PSTRIDE; i += 256) C->red[i] = 0.f;
     if (t < 12) C->cam_acc[t] = 0.f;
     if (t < 3) { C->maxinit_bits[t] = 0u; C->cnt_level[t] = 0; }
@@ -302,13 +330,15 @@ __global__ void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const float
       C->origin_done = 0;
       C->xchg_err = 0;
       C->f16_overflow = 0;
+      C->tail_from = V0.tail_from;
+      C->tail_steals = 0;
       C->cnt_valid = 0; C->cnt_normal = 0; C->cnt_samples = 0; C->pad_coef = 0.f;
     }
   }
 }
 
 // latent constants only (decode_sdf / decode_sdf_gradient entry points)
-__global__ void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, DecoderDev D, const float* __restrict__ latent) {
+DISTR_GLOBAL void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, DecoderDev D, const float* __restrict__ latent) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int o = gid & 511;
   const float* Wt = (gid < 512) ? D.W0lat_t : D.W4lat_t;
@@ -321,7 +351,7 @@ __global__ void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/, D
 // ------------------------------------------------------------------------------------------ ray setup
 // get_intersections_with_unit_spheres (renderer.py:254-273) for one pyramid level; coarse masks are the OR of the
 // 2x2 children (maxpool_valid_mask_with_index / torch_scatter.scatter_max, renderer.py:668-680).
-__global__ void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
+DISTR_GLOBAL void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
   const View V = view_at(V0, blockIdx.y);
   const LevelView L = level_sel(V, lvl);
   Consts* C = V.C;
@@ -357,7 +387,7 @@ __global__ void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
 
 // row band: the fill depth of rays that miss the sphere is the maximum over the FULL image's level grid
 // (renderer.py:268-270), not over the band -> one cheap pass over all of the level's pixel centres
-__global__ void __launch_bounds__(256) k_maxinit_full(View V0, int lvl) {
+DISTR_GLOBAL void __launch_bounds__(256) k_maxinit_full(View V0, int lvl) {
   const View V = view_at(V0, blockIdx.y);
   const LevelView L = level_sel(V, lvl);
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -373,7 +403,7 @@ __global__ void __launch_bounds__(256) k_maxinit_full(View V0, int lvl) {
 }
 
 // start depth of a coarse level: unit-sphere entry (coarsest) or the parent's last marched depth (renderer.py:766-769)
-__global__ void __launch_bounds__(256) k_coarse_init(View V0, int lvl) {
+DISTR_GLOBAL void __launch_bounds__(256) k_coarse_init(View V0, int lvl) {
   const View V = view_at(V0, blockIdx.y);
   const LevelView L = level_sel(V, lvl);
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -434,21 +464,30 @@ struct RayPre {
   int32_t sl[MAX_BS];    // their mask slots
 };
 
+// Per-ray arrays are addressed as (uniform base + k * P)[u] with an UNSIGNED 32-bit pixel index: the row base is scalar arithmetic and the
+// access takes the "SGPR base + 32-bit VGPR offset" form. Written as base[k * P + px] with a 64-bit P the whole sum is 64-bit VECTOR
+// arithmetic on a VGPR copy of the base -- inside the step loop of a sticky tile those copies were hoisted, kept across the decoder
+// evaluation and spilled: scratch reloads with a vmcnt(0) each in the lead member's epilogue, the critical path of every sticky step.
+template <class T>
+__device__ __forceinline__ T* ray_row(T* base, int k, int32_t P) { return base + (size_t)k * (size_t)P; }
+
+template <bool XC = false>
 __device__ __forceinline__ void raypre_load(const View& V, int px, RayPre& st) {
-  const size_t P = (size_t)V.P;
+  const uint32_t u = (uint32_t)px;
   const int bs = V.cfg.buffer_size;
-  st.m = V.m[px]; st.init_now = V.init_now[px]; st.maxbound = V.maxbound[px]; st.minabs = V.minabs[px];
+  st.m = ld_x<XC>(V.m + u); st.init_now = V.init_now[u]; st.maxbound = V.maxbound[u]; st.minabs = ld_x<XC>(V.minabs + u);   // (init_now / maxbound: written once, by k_fine_init)
 #pragma unroll
   for (int k = 0; k < MAX_BS; ++k) {
-    st.ks[k] = (k < bs) ? V.tk_s[k * P + px] : 0.f;
-    st.sl[k] = (k < bs) ? V.tk_slot[k * P + px] : 0;
+    st.ks[k] = (k < bs) ? ld_x<XC>(ray_row(V.tk_s, k, V.P) + u) : 0.f;
+    st.sl[k] = (k < bs) ? ld_x<XC>(ray_row(V.tk_slot, k, V.P) + u) : 0;
   }
 }
 
 // topk_insert with the keys / slots already in registers (same result, same memory image)
+template <bool XC = false>
 __device__ __forceinline__ int topk_insert_pre(const View& V, const RayPre& st, int px, float s, float zb, float za, int32_t src) {
   const int bs = V.cfg.buffer_size;
-  const size_t P = (size_t)V.P;
+  const uint32_t u = (uint32_t)px;
   const float key = fabsf(s);
   int pos = bs;
   bool open = true;
@@ -464,18 +503,24 @@ __device__ __forceinline__ int topk_insert_pre(const View& V, const RayPre& st, 
 #pragma unroll
   for (int k = MAX_BS - 1; k >= 1; --k) {
     if (k < bs && k > pos) {
-      V.tk_s[k * P + px] = st.ks[k - 1];
-      V.tk_slot[k * P + px] = st.sl[k - 1];
-      V.tk_zb[k * P + px] = V.tk_zb[(k - 1) * P + px];
-      V.tk_za[k * P + px] = V.tk_za[(k - 1) * P + px];
-      V.tk_src[k * P + px] = V.tk_src[(k - 1) * P + px];
+      st_x<XC>(ray_row(V.tk_s, k, V.P) + u, st.ks[k - 1]);
+      st_x<XC>(ray_row(V.tk_slot, k, V.P) + u, st.sl[k - 1]);
+      st_x<XC>(ray_row(V.tk_zb, k, V.P) + u, ld_x<XC>(ray_row(V.tk_zb, k - 1, V.P) + u));
+      st_x<XC>(ray_row(V.tk_za, k, V.P) + u, ld_x<XC>(ray_row(V.tk_za, k - 1, V.P) + u));
+      st_x<XC>(ray_row(V.tk_src, k, V.P) + u, ld_x<XC>(ray_row(V.tk_src, k - 1, V.P) + u));
     }
   }
-  V.tk_s[pos * P + px] = s;
-  V.tk_zb[pos * P + px] = zb;
-  V.tk_za[pos * P + px] = za;
-  V.tk_src[pos * P + px] = src;
-  V.tk_slot[pos * P + px] = free_slot;
+  // (the new row's place is data: one of bs unrolled, uniformly based stores)
+#pragma unroll
+  for (int k = 0; k < MAX_BS; ++k) {
+    if (k < bs && k == pos) {
+      st_x<XC>(ray_row(V.tk_s, k, V.P) + u, s);
+      st_x<XC>(ray_row(V.tk_zb, k, V.P) + u, zb);
+      st_x<XC>(ray_row(V.tk_za, k, V.P) + u, za);
+      st_x<XC>(ray_row(V.tk_src, k, V.P) + u, src);
+      st_x<XC>(ray_row(V.tk_slot, k, V.P) + u, (int32_t)free_slot);
+    }
+  }
   return free_slot;
 }
 
@@ -498,12 +543,13 @@ __device__ __forceinline__ int topk_slot_pre(const View& V, const RayPre& st, fl
 }
 
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
-__global__ void __launch_bounds__(256) k_fine_init(View V0) {
+DISTR_GLOBAL void __launch_bounds__(256) k_fine_init(View V0) {
   const View V = view_at(V0, blockIdx.y);
   const LevelView& L0 = V.lv[0];
   Consts* C = V.C;
   const int px = blockIdx.x * 256 + threadIdx.x;
   bool live = false;
+  if (px < V.P / 16 + 2) V.tclaim[px] = 0;
   if (px < V.P && L0.valid[px]) {
     const CamRegs cam = load_cam(C);
     float cx, cy;
@@ -600,6 +646,7 @@ struct MarchArgs {
   Xchg xc;                   // 16-ray launches: exchange region of the cluster tiles (buf == null: single-workgroup tiles only)
   DecoderB6 B6;              // split-bf16 weight planes (kernels instantiated with ARITH = 1, distr_render_cfg.arith)
   DecoderH3 H3;              // split-f16 weight planes (ARITH = 2)
+  int32_t tail_absent;       // tests (DISTR_TAIL_TEST_ABSENT=n): workgroups 0 .. n-1 of k_tail leave at once, as if they never became resident
 };
 
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
@@ -728,13 +775,13 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
         bool stay = false;
         if (valid) {
           const float mn = st.m + clampf(s, -cd, cd) * ratio;
-          V.m[id] = mn;
+          V.m[(uint32_t)id] = mn;
           const float za = mn + st.init_now;
           const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
           if (slot >= 0) mblock = (int64_t)id * (V.cfg.buffer_size + 1) + slot;
           const float a = fabsf(s);
-          if (a < st.minabs) V.minabs[id] = a;
-          if (A.step == 0) V.first_sdf[id] = s;
+          if (a < st.minabs) V.minabs[(uint32_t)id] = a;
+          if (A.step == 0) V.first_sdf[(uint32_t)id] = s;
           stay = (za < st.maxbound) && (a >= V.cfg.threshold);
         }
         if (V.cfg.marcher != DISTR_MARCH_TRIVIAL)
@@ -770,7 +817,15 @@ __global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_march(
 // 8 / CL whole groups; for lin3 (256 rows) four row blocks are word 32 w + 6 + 16 h (w = 0..3, the words 32 w + 7 + 16 h stay zero): a
 // member of 4 or 2 owns whole words, two members of 8 share one (16 bits each). Thread (ray, layer, h) stores the member's words: the
 // members together write every byte of the 512-byte block, nobody gathers. mb[ray] = index of the ray's block, < 0: none.
-template <int CL>
+// WT (k_tail): write-through stores. Inside the persistent tail launch the same block can be rewritten a few steps later by a workgroup on
+// ANOTHER XCD (the row was evicted, its slot reused); a helper member's plain stores are released by nobody before that (only a tile's lead
+// member releases, k_tail), and a line left dirty in this XCD's L2 could be written back over the newer one. Write-through leaves none.
+template <bool WT, class T>
+__device__ __forceinline__ void st_mask(T* p, T v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <int CL, bool WT = false>
 __device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long long* mb, const Smem16CL& S, int member, int tid) {
   const int j = tid >> 4, q = tid & 15;
   const long long b = mb[j];
@@ -783,19 +838,19 @@ __device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long l
 #pragma unroll
     for (int gi = 0; gi < GPM; ++gi) {
       const int g = member * GPM + gi, wi = 32 * (g >> 1) + 2 * layer + (g & 1) + 16 * h;
-      dst[wi] = src[wi];
+      st_mask<WT>(dst + wi, src[wi]);
     }
   } else if constexpr (CL == 8) {
     const int wi = 32 * (member >> 1) + 6 + 16 * h;
-    reinterpret_cast<uint16_t*>(dst + wi)[member & 1] = reinterpret_cast<const uint16_t*>(src + wi)[member & 1];
-    if (member & 1) dst[wi + 1] = 0u;
+    st_mask<WT>(reinterpret_cast<uint16_t*>(dst + wi) + (member & 1), reinterpret_cast<const uint16_t*>(src + wi)[member & 1]);
+    if (member & 1) st_mask<WT>(dst + wi + 1, 0u);
   } else {
     constexpr int WPM = 4 / CL;
 #pragma unroll
     for (int wq = 0; wq < WPM; ++wq) {
       const int wi = 32 * (member * WPM + wq) + 6 + 16 * h;
-      dst[wi] = src[wi];
-      dst[wi + 1] = 0u;
+      st_mask<WT>(dst + wi, src[wi]);
+      st_mask<WT>(dst + wi + 1, 0u);
     }
   }
 }
@@ -811,38 +866,42 @@ __device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long l
 // launches the host still issues find empty live lists and exit in a few microseconds. A tile whose cluster does not assemble
 // (compute units held by another stream) is evaluated by its lead member alone and hands its rays back to the next step's live
 // list; if a barrier times out later, the lead member finishes the tile alone on the single-workgroup path.
-template <bool KEEP>
-__device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CLX& S, const View& V,
-                                              int tile, int member, int64_t base, int64_t count) {
+// TAIL (k_tail: no launch follows): a tile whose cluster does not assemble is marched to the END by its lead member alone (no list to hand
+// the rays back to); solo0: evaluated alone from the first step (a workgroup that took the tile over from a lead that is not resident).
+template <bool KEEP, bool TAIL = false>
+__device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CLX& S, int vb,
+                                              int tile, int member, int64_t base, int64_t count, int step0, const Xchg& xc, bool solo0 = false, int32_t lost = 0) {
   constexpr int TILE = 16;
   const int tid = threadIdx.x;
   const bool lead = member == cl_lead(8);
-  const int32_t* list = live_sel(V, A.step);
+  const View V = view_at(A.V, vb);         // (setup and the per-step sample points; the epilogue of a step takes its own, see there)
+  const int32_t* list = live_sel(V, step0);
   const float* c0 = V.C->c0;
   const float* c4 = V.C->c4;
   int32_t id = -1;
   bool live = false;
   float m = 0.f, init_now = 0.f, maxbound = 0.f, minabs = 0.f;      // march state of this lane's ray, in registers across steps
   if (tid < TILE && base + tid < count) {
-    id = list[base + tid];
+    id = ld_x<false>(list + base + tid);
     live = true;
     RayPre st;
-    raypre_load(V, id, st);
+    raypre_load<false>(V, id, st);
     m = st.m; init_now = st.init_now; maxbound = st.maxbound; minabs = st.minabs;
 #pragma unroll
     for (int k = 0; k < MAX_BS; ++k) { S.sk[k][tid] = st.ks[k]; S.ssl[k][tid] = st.sl[k]; }   // selected-row keys / slots: LDS between steps
   }
   const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
-  bool solo = false;                  // the cluster broke up: the lead member finishes the tile alone
-  for (int step = A.step, k = 0;; ++step, ++k) {
+  bool solo = solo0;                  // the cluster broke up: the lead member finishes the tile alone
+  for (int step = step0, k = 0;; ++step, ++k) {
     if (tid < TILE) {
       float p[3] = {0.f, 0.f, 0.f};
       if (live) {        // (the ray direction is recomputed from the pixel id every step, like the per-step kernels do: ~40 flops
-        const CamRegs cam = load_cam(V.C);     // against three registers held across the decoder evaluation)
+        const View& Vp = kernarg_ref<MarchArgs>(0).V;      // against three registers held across the decoder evaluation); camera constants re-read per step
+        const CamRegs cam = load_cam(view_at(Vp, vb).C);
         float cx, cy;
-        level_center(V.lv[0], id, cx, cy);
-        const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-        make_point(V.cfg.M, cam.c, g.d, init_now + m, p);
+        level_center(Vp.lv[0], id, cx, cy);
+        const RayGeo g = make_ray(Vp.cfg.K_inv, cam.R, cx, cy);
+        make_point(Vp.cfg.M, cam.c, g.d, init_now + m, p);
       }
       S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
     }
@@ -856,20 +915,33 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
     int zero;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     if (!solo) {
-      Xchg xs = A.xc;
-      xs.epoch = A.xc.epoch + (uint32_t)k;          // one epoch per march step (the host reserved them: Xchg::epochs)
-      xs.par = k & 1;                                // alternate the exchange slots: layer 1 of step k+1 must not reuse layer 7's
-      pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0);
+      Xchg xs = xc;
+      xs.epoch = xc.epoch + (uint32_t)k;          // one epoch per march step (the host reserved them: Xchg::epochs)
+      xs.par = (xc.par + k) & 1;                   // alternate the exchange slots: layer 1 of step k+1 must not reuse layer 7's
+      pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0, (TAIL && k == 0) ? lost : 0);
       clustered = S.fail == 0;
       if (!clustered) {
         if (!lead) return;
+        if (TAIL && k == 0) {   // the lead's claim had been lost (it told its members to leave): the tile belongs to somebody else
+          if (tid == 0) S.cont = lost;
+          __syncthreads();
+          if (S.cont) return;
+        }
         solo = true;
         if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
         __syncthreads();
       }
     }
     if (solo) pre = mlp_forward16<KEEP>(D, D16, c0 + zero, c4 + zero, S, nib);
+    if (TAIL && solo0 && k == 0) {     // taken over: only if the claim was won (known by now: the atomic was issued before the evaluation)
+      if (tid == 0) S.cont = lost;
+      __syncthreads();
+      if (S.cont) return;
+    }
 
+    // the epilogue's view of the workspace, from kernel arguments re-read HERE (kernarg_ref; MarchArgs is the first argument of every kernel that holds 16-ray tiles): the ray-state pointers are then not alive
+    // across the decoder evaluation (hoisted out of the step loop they were: AGPR / scratch copies reloaded in the lead member's epilogue)
+    const View Ve = view_at(kernarg_ref<MarchArgs>(0).V, vb);
     long long mblock = -1;
     if (tid < 64) {
       const float s = tanh_spec(pre);            // (lane l holds ray l & 15)
@@ -884,18 +956,18 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
           // (the ray's row addresses are recomputed from id + an opaque zero every step: hoisted out of the step loop they would be ~40
           // 64-bit values alive across the decoder evaluation)
           const int32_t id_ = id + zero;
-          if (lead) V.m[id_] = mn;
+          if (lead) Ve.m[(uint32_t)id_] = mn;
           RayPre st;                   // this step's view of the selected rows (only the keys and slots are read)
           st.m = m; st.init_now = init_now; st.maxbound = maxbound; st.minabs = minabs;
 #pragma unroll
           for (int k = 0; k < MAX_BS; ++k) { st.ks[k] = S.sk[k][tid]; st.sl[k] = S.ssl[k][tid]; }
           // only the lead writes the selected rows; every member mirrors the insertion on its LDS copy of the keys / slots: the slot says
           // where this step's mask block goes, and every member stores its own words of it (mlp_forward16_cl, MASK_OWN)
-          const int slot = lead ? topk_insert_pre(V, st, id_, s, zd, V.pyramid ? za : mn, id_) : topk_slot_pre(V, st, s);
+          const int slot = lead ? topk_insert_pre<false>(Ve, st, id_, s, zd, Ve.pyramid ? za : mn, id_) : topk_slot_pre(Ve, st, s);
           if (slot >= 0) {
-            mblock = (long long)id_ * (V.cfg.buffer_size + 1) + slot;
+            mblock = (long long)id_ * (Ve.cfg.buffer_size + 1) + slot;
             // the same insertion on the LDS copy: rows behind the new one move down, the new row takes its place
-            const int bs = V.cfg.buffer_size;
+            const int bs = Ve.cfg.buffer_size;
             int pos = bs;
             bool open = true;
 #pragma unroll
@@ -912,41 +984,211 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
             }
           }
           if (lead) {
-            if (a < minabs) V.minabs[id_] = a;
-            if (step == 0) V.first_sdf[id_] = s;
+            if (a < minabs) Ve.minabs[(uint32_t)id_] = a;
+            if (step == 0) Ve.first_sdf[(uint32_t)id_] = s;
           }
         }
         if (a < minabs) minabs = a;
         m = mn;
-        stay = (za < maxbound) && (a >= V.cfg.threshold);
+        stay = (za < maxbound) && (a >= Ve.cfg.threshold);
       }
-      if (solo && k == 0) {
+      if (!TAIL && solo && k == 0) {
         // the cluster never assembled (its compute units are held by another stream / rank): this tile does NOT turn sticky -- the
         // lead member evaluated the step alone and hands the surviving rays to the next step's live list like a per-step tile
         // (marching 16 rays to the end on ONE compute unit would cost twice a cluster step, every step)
-        wave_append(tid < TILE && stay, id, live_sel(V, step + 1), &V.C->cnt_live[step + 1]);
+        wave_append(tid < TILE && stay, id, live_sel(Ve, step + 1), &Ve.C->cnt_live[step + 1]);
         stay = false;
       }
       live = stay;
       const unsigned long long now = __ballot(tid < TILE && live);
       if (tid == 0) {
         S.cont = now != 0ull;
-        if (lead && k > 0) atomicAdd(&V.C->cnt_sticky[step], __popcll(was));   // (step A.step itself is counted in cnt_live)
+        if (lead && k > 0) atomicAdd(&Ve.C->cnt_sticky[step], __popcll(was));   // (the tile's first step is counted in cnt_live)
       }
     }
     if (KEEP && (lead || clustered)) {
       if (tid < TILE) S.mb[tid] = mblock;
       __syncthreads();
       if (clustered) {
-        store_own_mask_words<8>(V.mstore, S.mb, S, member, tid);    // every member: its own words of the rays' blocks
+        store_own_mask_words<8, false>(Ve.mstore, S.mb, S, member, tid);    // every member: its own words of the rays' blocks
       } else {
-        store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+        store_masks16<false>(Ve.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
       }
     }
     __syncthreads();                   // S.cont visible; this step's LDS reads are done before the next step's points land
-    if (!S.cont || step + 1 >= V.fine_steps) break;
+    if (!S.cont || step + 1 >= Ve.fine_steps) break;
   }
 }
+
+// One 16-ray tile of a launch (or of a step of the persistent tail launch), everything about it decided by the caller:
+struct Tile16 {
+  int tile, member, cl, vb;     // virtual tile index, member index within its cluster of cl workgroups (cl = 1: single workgroup), view
+  bool origin;                  // the tile evaluates f(0,0,0) of view vb
+  bool sticky;                  // MODE_FINE: the tile keeps its rays to the end of the march (sticky_tile16)
+  bool solo;                    // sticky tile evaluated by one workgroup from its first step (k_tail: taken over from an absent lead)
+  int64_t base, count;          // the tile's rays: list[base .. min(base + 16, count))
+  int32_t lost;                 // k_tail, lane 0 of the owner: != 0 when its claim on the tile failed (the claiming atomic is issued before the
+                                // evaluation and looked at before anything is written or a cluster gets its `go`)
+  int32_t* count2;              // k_tail: second counter of the rays that stay live (Consts::tail_sync), else null
+  int32_t step;                 // MODE_FINE / MODE_COARSE: the march step (of the level) this tile evaluates (a launch: MarchArgs::step)
+};
+
+// TAIL (k_tail): write-through mask stores of the cluster members (store_own_mask_words), sticky tiles never hand rays back.
+template <int MODE, bool KEEP, class SM, bool TAIL = false>
+__device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, SM& S, const Tile16& t, const Xchg& xc) {
+  constexpr int TILE = 16;
+  const View& V0 = A.V;
+  const int tid = threadIdx.x;
+  const int tile = t.tile, member = t.member, cl = t.cl;
+  const bool origin = t.origin;
+  const int64_t base = t.base, count = t.count;
+  const View V = view_at(V0, t.vb);
+  if constexpr (MODE == MODE_FINE) {
+    if (t.sticky && !origin) {
+      sticky_tile16<KEEP, TAIL>(A, D, D16, S, t.vb, tile, member, base, count, t.step, xc, t.solo, t.lost);
+      return;
+    }
+  }
+  if (origin && V.C->origin_done) return;   // f(origin) was evaluated by an earlier launch (the one that turned sticky)
+  const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, t.step) : nullptr;
+
+  int32_t id = -1;
+  float zd = 0.f;
+  bool valid = false;
+  RayPre st;
+  if (tid < TILE) {
+    float p[3] = {0.f, 0.f, 0.f};
+    const int64_t r = base + tid;
+    valid = !origin && r < count;
+    if (valid) {
+      if (MODE == MODE_EVAL) {
+        id = (int32_t)r;
+        p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
+      } else {
+        id = ld_x<false>(list + r);
+        const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
+        const CamRegs cam = load_cam(V.C);
+        float cx, cy;
+        level_center(L, id, cx, cy);
+        const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
+        if (MODE == MODE_FINE) { raypre_load<false>(V, id, st); zd = st.init_now + st.m; }
+        else zd = L.cinit[id] + L.cm[id];
+        make_point(V.cfg.M, cam.c, g.d, zd, p);
+      }
+    }
+    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
+  }
+  __syncthreads();
+
+  uint32_t nib[8];
+  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
+  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
+  float pre;
+  bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
+  bool helper = false;                  // a member of a cluster tile other than the lead (KEEP: it stores its words of the mask blocks, nothing else)
+  if (MODE != MODE_EVAL && cl > 1) {
+    if constexpr (MODE != MODE_EVAL) {
+      // KEEP: every member evaluates lin8 too (ALL_LIN8) and records the ReLU bits of its own rows (MASK_OWN): it then knows where the rays'
+      // mask blocks go and stores its words of them itself -- the lead member does not extract bits from staged rows (that made it the
+      // last to publish in every layer). Without KEEP the other members leave after their last slice.
+      const int32_t lost = TAIL ? t.lost : 0;     // (lead member, lane 0: its claim failed -> the cluster is told to leave)
+      if (cl == 8) pre = mlp_forward16_cl<8, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, xc, tile, member, true, lost);
+      else if (cl == 4) pre = mlp_forward16_cl<4, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, xc, tile, member, true, lost);
+      else pre = mlp_forward16_cl<2, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, xc, tile, member, true, lost);
+    } else pre = 0.f;
+    helper = member != cl_lead(cl);      // only the lead member runs the epilogue; with KEEP the others store their mask words
+    clustered = S.fail == 0;
+    if (helper && (!KEEP || !clustered)) return;
+    if (!clustered) {
+      if constexpr (TAIL) {      // ... or its lead's claim had been lost: the tile is somebody else's
+        if (tid == 0) S.cont = t.lost;
+        __syncthreads();
+        if (S.cont) return;
+      }
+      // the cluster did not assemble (compute units held by other streams / ranks) or a barrier timed out: the lead member
+      // evaluates the tile on its own -- identical values; counted in the render stats (cluster_fallbacks)
+      if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
+      __syncthreads();
+      pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+    }
+  } else {
+    pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+    if constexpr (TAIL) {        // the claim (issued before the evaluation) must have been won before anything is written
+      if (tid == 0) S.cont = t.lost;
+      __syncthreads();
+      if (S.cont) return;
+    }
+  }
+
+  long long mblock = -1;
+  if (tid < 64) {
+    const float s = tanh_spec(pre);
+    // the persistent tail launch reads the ray's state AGAIN here instead of carrying twenty registers per lane across the evaluation
+    // (inside its step loop they end up in scratch); its per-step tiles are not where its time goes (k_tail takes over at the sticky regime)
+    RayPre st_again;
+    if constexpr (TAIL && MODE == MODE_FINE) {
+      st_again.m = 0.f; st_again.init_now = 0.f; st_again.maxbound = 0.f; st_again.minabs = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAX_BS; ++k) { st_again.ks[k] = 0.f; st_again.sl[k] = 0; }
+      if (valid) raypre_load<false>(V, id, st_again);
+    }
+    const RayPre& sr = (TAIL && MODE == MODE_FINE) ? st_again : st;
+    if (helper) {      // where the mask blocks go, nothing else (the lead member writes the step's results)
+      if (origin) {
+        if (tid == 0) mblock = V.morigin;
+      } else if (MODE == MODE_COARSE) {
+        if (valid) mblock = V.mfine + moff_sel(V, A.lvl) + (long long)((size_t)t.step * level_sel(V, A.lvl).n + id);
+      } else if (MODE == MODE_FINE) {
+        if (valid) {
+          const int slot = topk_slot_pre(V, sr, s);
+          if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+        }
+      }
+    } else if (origin) {
+      if (tid == 0) { V.C->f_origin = s; V.C->origin_done = 1; mblock = V.morigin; }
+    } else if (MODE == MODE_EVAL) {
+      if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
+    } else if (MODE == MODE_COARSE) {
+      if (valid) {
+        const LevelView L = level_sel(V, A.lvl);
+        const float mn = L.cm[id] + clampf(s, -V.cfg.clamp_dist, V.cfg.clamp_dist) * V.cfg.ratio;
+        L.cm[id] = mn;
+        const size_t o = (size_t)t.step * L.n + id;
+        L.rs[o] = s;
+        L.rzb[o] = zd;
+        L.rza[o] = mn + L.cinit[id];
+        mblock = V.mfine + moff_sel(V, A.lvl) + (long long)o;
+      }
+    } else {
+      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+      bool stay = false;
+      if (valid) {
+        const float mn = sr.m + clampf(s, -cd, cd) * ratio;
+        V.m[(uint32_t)id] = mn;
+        const float za = mn + sr.init_now;
+        const int slot = topk_insert_pre<false>(V, sr, id, s, zd, V.pyramid ? za : mn, id);
+        if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+        const float a = fabsf(s);
+        if (a < sr.minabs) V.minabs[(uint32_t)id] = a;
+        if (t.step == 0) V.first_sdf[(uint32_t)id] = s;
+        stay = (za < sr.maxbound) && (a >= V.cfg.threshold);
+      }
+      wave_append<false>(stay, id, live_sel(V, t.step + 1), &V.C->cnt_live[t.step + 1], TAIL ? t.count2 : nullptr);
+    }
+  }
+  if (KEEP && MODE != MODE_EVAL) {
+    if (tid < TILE) S.mb[tid] = mblock;
+    __syncthreads();
+    if (clustered) {   // every member: its own words of the rays' blocks
+      if (cl == 8) store_own_mask_words<8, TAIL>(V.mstore, S.mb, S, member, tid);
+      else if (cl == 4) store_own_mask_words<4, TAIL>(V.mstore, S.mb, S, member, tid);
+      else store_own_mask_words<2, TAIL>(V.mstore, S.mb, S, member, tid);
+    } else {
+      store_masks16<false>(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+    }
+  }
+}
+
 
 // The same march step on 16-ray tiles (v_mfma_f32_16x16x4_f32), for the live-ray tail: see distr_mlp.hpp::Smem16.
 // MODE_FINE (recursive marchers), MODE_COARSE (pyramid levels of small images) and MODE_EVAL.
@@ -1026,130 +1268,10 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
       if (base >= count) return;       // padding behind the view's last ray (all members of a cluster agree)
     }
   }
-  const View V = view_at(V0, vb);
-  if constexpr (MODE == MODE_FINE) {
-    if (sticky_launch && !origin) {
-      sticky_tile16<KEEP>(A, D, D16, S, V, tile, member, base, count);
-      return;
-    }
-  }
-  if (origin && V.C->origin_done) return;   // f(origin) was evaluated by an earlier launch (the one that turned sticky)
-  const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, A.step) : nullptr;
-
-  int32_t id = -1;
-  float zd = 0.f;
-  bool valid = false;
-  RayPre st;
-  if (tid < TILE) {
-    float p[3] = {0.f, 0.f, 0.f};
-    const int64_t r = base + tid;
-    valid = !origin && r < count;
-    if (valid) {
-      if (MODE == MODE_EVAL) {
-        id = (int32_t)r;
-        p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
-      } else {
-        id = list[r];
-        const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
-        const CamRegs cam = load_cam(V.C);
-        float cx, cy;
-        level_center(L, id, cx, cy);
-        const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-        if (MODE == MODE_FINE) { raypre_load(V, id, st); zd = st.init_now + st.m; }
-        else zd = L.cinit[id] + L.cm[id];
-        make_point(V.cfg.M, cam.c, g.d, zd, p);
-      }
-    }
-    S.xyz[tid] = p[0]; S.xyz[TILE + tid] = p[1]; S.xyz[2 * TILE + tid] = p[2];
-  }
-  __syncthreads();
-
-  uint32_t nib[8];
-  const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
-  const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
-  float pre;
-  bool clustered = false;               // the tile's value (and, KEEP, its mask blocks in S.mk) came from the cluster path
-  bool helper = false;                  // a member of a cluster tile other than the lead (KEEP: it stores its words of the mask blocks, nothing else)
-  if (MODE != MODE_EVAL && cl > 1) {
-    if constexpr (MODE != MODE_EVAL) {
-      // KEEP: every member evaluates lin8 too (ALL_LIN8) and records the ReLU bits of its own rows (MASK_OWN): it then knows where the rays'
-      // mask blocks go and stores its words of them itself -- the lead member does not extract bits from staged rows (that made it the
-      // last to publish in every layer). Without KEEP the other members leave after their last slice.
-      if (cl == 8) pre = mlp_forward16_cl<8, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-      else if (cl == 4) pre = mlp_forward16_cl<4, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-      else pre = mlp_forward16_cl<2, KEEP, KEEP, KEEP>(D, D16, c0, c4, S, A.xc, tile, member);
-    } else pre = 0.f;
-    helper = member != cl_lead(cl);      // only the lead member runs the epilogue; with KEEP the others store their mask words
-    clustered = S.fail == 0;
-    if (helper && (!KEEP || !clustered)) return;
-    if (!clustered) {
-      // the cluster did not assemble (compute units held by other streams / ranks) or a barrier timed out: the lead member
-      // evaluates the tile on its own -- identical values; counted in the render stats (cluster_fallbacks)
-      if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
-      __syncthreads();
-      pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
-    }
-  } else {
-    pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
-  }
-
-  long long mblock = -1;
-  if (tid < 64) {
-    const float s = tanh_spec(pre);
-    if (helper) {      // where the mask blocks go, nothing else (the lead member writes the step's results)
-      if (origin) {
-        if (tid == 0) mblock = V.morigin;
-      } else if (MODE == MODE_COARSE) {
-        if (valid) mblock = V.mfine + moff_sel(V, A.lvl) + (long long)((size_t)A.step * level_sel(V, A.lvl).n + id);
-      } else if (MODE == MODE_FINE) {
-        if (valid) {
-          const int slot = topk_slot_pre(V, st, s);
-          if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
-        }
-      }
-    } else if (origin) {
-      if (tid == 0) { V.C->f_origin = s; V.C->origin_done = 1; mblock = V.morigin; }
-    } else if (MODE == MODE_EVAL) {
-      if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
-    } else if (MODE == MODE_COARSE) {
-      if (valid) {
-        const LevelView L = level_sel(V, A.lvl);
-        const float mn = L.cm[id] + clampf(s, -V.cfg.clamp_dist, V.cfg.clamp_dist) * V.cfg.ratio;
-        L.cm[id] = mn;
-        const size_t o = (size_t)A.step * L.n + id;
-        L.rs[o] = s;
-        L.rzb[o] = zd;
-        L.rza[o] = mn + L.cinit[id];
-        mblock = V.mfine + moff_sel(V, A.lvl) + (long long)o;
-      }
-    } else {
-      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
-      bool stay = false;
-      if (valid) {
-        const float mn = st.m + clampf(s, -cd, cd) * ratio;
-        V.m[id] = mn;
-        const float za = mn + st.init_now;
-        const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);
-        if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
-        const float a = fabsf(s);
-        if (a < st.minabs) V.minabs[id] = a;
-        if (A.step == 0) V.first_sdf[id] = s;
-        stay = (za < st.maxbound) && (a >= V.cfg.threshold);
-      }
-      wave_append(stay, id, live_sel(V, A.step + 1), &V.C->cnt_live[A.step + 1]);
-    }
-  }
-  if (KEEP && MODE != MODE_EVAL) {
-    if (tid < TILE) S.mb[tid] = mblock;
-    __syncthreads();
-    if (clustered) {   // every member: its own words of the rays' blocks
-      if (cl == 8) store_own_mask_words<8>(V.mstore, S.mb, S, member, tid);
-      else if (cl == 4) store_own_mask_words<4>(V.mstore, S.mb, S, member, tid);
-      else store_own_mask_words<2>(V.mstore, S.mb, S, member, tid);
-    } else {
-      store_masks16(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
-    }
-  }
+  Tile16 t;
+  t.tile = tile; t.member = member; t.cl = cl; t.vb = vb; t.origin = origin; t.sticky = sticky_launch; t.solo = false; t.base = base; t.count = count;
+  t.lost = 0; t.count2 = nullptr; t.step = A.step;
+  tile16_run<MODE, KEEP, SM>(A, D, D16, S, t, A.xc);
 }
 
 // (MODE_EVAL: point lists of any length on single-workgroup tiles, two per CU; MODE_COARSE: at most 256 tiles, cluster tiles among
@@ -1158,6 +1280,239 @@ template <int MODE, bool KEEP>
 __global__ void __launch_bounds__(256, (MODE == MODE_EVAL) ? 2 : 1) k_march16(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
   __shared__ typename std::conditional<MODE == MODE_EVAL, Smem16CL, Smem16CLX>::type S;
   march_tile16<MODE, KEEP>(A, D, D16, S, (int)blockIdx.x, A.origin_tile);
+}
+
+
+// ------------------------------------------------------------------------------------------ persistent tail launch
+// k_tail: the full-resolution steps [tail_from, fine_steps) of the recursive marchers inside ONE launch of 256 workgroups (one per
+// compute unit), for the regime where a step is one 16-ray-tile latency or less (small images from their first step, every image
+// once few rays are left): a launch per step costs more than the step's hand-over needs there, and every launch the host issues after
+// the last ray has finished (it cannot know) is pure waste -- 72 of the 94 full-resolution launches of a 137 x 137 / 100-step render
+// (renderer.py:528-567 breaks out of its loop there; it synchronises the host every step to know).
+// Per step every workgroup derives the SAME plan from the device-side live counts (tail_plan): the step's rays on 16-ray tiles --
+// cluster tiles of 8 / 4 / 2 workgroups while at most 32 / 64 / 128 tiles are left, single-workgroup tiles in rounds of 256 above
+// that -- and, once everything fits 32 cluster tiles, sticky tiles that march their rays to the end (sticky_tile16); then the launch
+// is over. A ray's arithmetic is exactly the per-step launches' one: bit-identical renders (tests: tail on / off).
+// Step barrier WITHOUT a co-residency assumption (the hardware promises none: another stream or process may hold compute units, and
+// two spinning launches could starve each other for ever): a tile is OWNED through a claim word (atomicMax with the step's tag), its
+// owner evaluates it, releases its stores (one agent-scope release fence per tile; every workgroup takes one acquire fence per step) and
+// counts it in tail_sync[2 step]; a step is complete when the count equals the number of tiles. Tiles are handed out statically (workgroup b: tiles b, b + 256, ...; clusters as in march_tile16, the lead member
+// claims), but a workgroup that has waited TAIL_T_STEAL for a step takes over every tile nobody has claimed and evaluates it alone --
+// so the launch finishes with ANY subset of its workgroups resident, and a lead that arrives late finds its tile taken and moves on.
+constexpr long long TAIL_T_STEAL = 400 * 100;     // 400 us (100 MHz ticks): several tile latencies
+constexpr int32_t TAIL_T_GO = 150 * 100;          // a cluster member waits this long for its lead's verdict (workgroups start a step together)
+
+__device__ __forceinline__ int32_t vload_fresh(const int32_t* p0, int64_t stride, int B) {   // vload past the L1 (counters other workgroups of THIS launch wrote)
+  if (B <= 1) return __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int lane = threadIdx.x & 63;
+  return (lane < B) ? __hip_atomic_load(reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p0) + (int64_t)lane * stride), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT) : 0;
+}
+
+struct TailPlan {
+  int32_t c, incl;     // this lane's view: live rays, inclusive prefix of the counts padded to 16 (vprefix)
+  int64_t ntiles;      // 16-ray tiles of the step over all views
+  int norigin;         // + one tile per view for f(0,0,0) on the launch's first step
+  int cl;              // workgroups per tile
+  bool sticky;         // the tiles keep their rays to the end of the march
+};
+
+// plan of a step from the views' live counts (c: this lane's view, vload layout)
+__device__ __forceinline__ TailPlan tail_plan(const MarchArgs& A, const Xchg& xc, int32_t c, int step, bool first) {
+  const View& V0 = A.V;
+  const int B = V0.nviews;
+  TailPlan P;
+  P.c = c;
+  P.incl = vprefix(P.c, B, 16);
+  P.ntiles = vtotal(P.incl, B) / 16;
+  P.norigin = first ? B : 0;
+  const int64_t need = P.ntiles + P.norigin;
+  P.sticky = xc.buf && xc.sticky && xc.max_cl >= 8 && step + 1 < V0.fine_steps && P.ntiles > 0 && need <= 32;
+  P.cl = 1;
+  if (xc.buf) P.cl = (need <= 32 && xc.max_cl >= 8) ? 8 : (need <= 64 && xc.max_cl >= 4) ? 4 : (need <= 128 && xc.min_cl <= 2) ? 2 : 1;
+  return P;
+}
+
+// { tiles counted, rays entering the next step } of tail step k as ONE 8-byte word (Consts::tail_sync is 8-byte aligned)
+__device__ __forceinline__ unsigned long long tail_sync_load(const Consts* C, int k) {
+  return __hip_atomic_load(static_cast<const unsigned long long*>(__builtin_assume_aligned(&C->tail_sync[2 * k], 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// claim word of virtual tile vt: the views' tclaim arrays (P / 16 + 2 words each) taken as one array over the batch
+__device__ __forceinline__ int32_t* tail_claim_word(const View& V0, int64_t vt) {
+  const int64_t ch = V0.P / 16 + 2;
+  return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(V0.tclaim) + (vt / ch) * V0.vstride) + (vt % ch);
+}
+
+// Evaluates virtual tile vt of step T0 + k as member `member` of a cluster of cl workgroups (cl = 1: alone). The lead member (or the
+// single workgroup) claims the tile -- the atomic is ISSUED here and its answer looked at inside the tile, before a cluster gets its `go`
+// and before anything is written (tile16_run, Tile16::lost): a round trip to the claim word is not paid in front of every tile -- and
+// counts the tile in tail_sync when its stores are complete.
+template <bool KEEP>
+__device__ __forceinline__ void tail_slot(const MarchArgs& A, const DecoderDev& D, const DecoderDev16& D16, Smem16CLX& S, int32_t* ctl, const TailPlan& P,
+                                          const Xchg& xc, int64_t vt, int k, int cl, int member, bool sticky, bool steal) {
+  const View& V0 = A.V;
+  const int tid = threadIdx.x;
+  const bool lead = member == cl_lead(cl);
+  Tile16 t;
+  t.tile = (int)vt; t.member = member; t.cl = cl; t.vb = 0; t.base = 0; t.count = 0; t.lost = 0; t.step = A.step + k;
+  t.origin = vt >= P.ntiles;
+  t.sticky = sticky; t.solo = sticky && cl == 1;
+  if (t.solo) t.member = cl_lead(8);          // (sticky_tile16 is written for 8 members: alone = as their lead)
+  if (steal) {
+    // a scan for abandoned tiles looks before it claims (hundreds of failing atomics per scan would be the slow part of it), and only
+    // touches a tile it can have: most are taken
+    if (tid == 0) {
+      int32_t* w = tail_claim_word(V0, vt);
+      const bool got = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1 && atomicMax(w, k + 1) < k + 1;
+      if (got) atomicAdd(&V0.C->tail_steals, 1);
+      ctl[0] = got ? 1 : 0;
+    }
+    __syncthreads();
+    const bool got = ctl[0] != 0;
+    __syncthreads();
+    if (!got) return;
+  } else if (lead && tid == 0) {
+    t.lost = (atomicMax(tail_claim_word(V0, vt), k + 1) < k + 1) ? 0 : 1;
+  }
+  if (t.origin) {
+    t.vb = (int)(vt - P.ntiles);
+  } else {
+    int64_t start;
+    int32_t cnt;
+    vfind(P.c, P.incl, V0.nviews, 16, vt * 16, t.vb, start, cnt);
+    t.base = vt * 16 - start;
+    t.count = cnt;
+  }
+  // second counter of the rays that stay live: the count word next to the step's barrier word, in the tile's view
+  t.count2 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(&V0.C->tail_sync[2 * k + 1]) + (int64_t)t.vb * V0.vstride);
+  tile16_run<MODE_FINE, KEEP, Smem16CLX, true>(A, D, D16, S, t, xc);
+  __syncthreads();                // the tile's stores are issued; its LDS is free for the next tile
+  if (lead && !sticky && tid == 0 && !t.lost) {
+    // release the tile's results (ray state, next step's list entries: plain stores) to the other XCDs, THEN count the tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(&V0.C->tail_sync[2 * k], 1);
+  }
+}
+
+template <bool KEEP>
+__global__ void __launch_bounds__(256, 1) k_tail(MarchArgs A, DecoderDev D, DecoderDev16 D16) {
+  __shared__ Smem16CLX S;
+  __shared__ int32_t ctl[4];
+  const View& V0 = A.V;
+  const int tid = threadIdx.x, bidx = (int)blockIdx.x, nwg = (int)gridDim.x;
+  const int T0 = A.step, B = V0.nviews;
+  if (bidx < A.tail_absent) return;      // (tests: the others must take over this workgroup's tiles)
+  int32_t c_next = vload(&V0.C->cnt_live[T0], V0.vstride, B);        // (written by earlier launches)
+  bool behind = true;
+  for (int k = 0; T0 + k < V0.fine_steps; ++k) {
+    // a zero the optimiser cannot see through, added to the tile / member index of every tile: the weight-stream addresses of the decoder
+    // evaluation then depend on the iteration and are NOT hoisted out of the step loop (hoisted they stay live next to the weight ring:
+    // scratch; the same device as in sticky_tile16)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    // (the kernel's arguments stay where they are: a modified COPY of MarchArgs would be hundreds of scalars loaded at the top of every
+    // iteration and kept alive across the tile)
+    Xchg xc = A.xc;
+    xc.epoch = A.xc.epoch + (uint32_t)k;
+    xc.epochs = A.xc.epochs - (uint32_t)k;
+    xc.par = k & 1;            // alternate the exchange slots between steps (as sticky tiles do): layer 1 of step k + 1 never lands on step k's h7
+    const TailPlan P = tail_plan(A, xc, c_next, T0 + k, k == 0);
+    const int64_t slots = P.ntiles + P.norigin;
+    if (slots == 0) break;     // no live ray left (every workgroup reads the same count)
+    if (behind && !P.sticky) {
+      // A workgroup that starts late (its compute unit was held by somebody else) must not evaluate tiles of steps that are long over
+      // (it would find out only afterwards: the claim is looked at behind the evaluation): until it has seen ONE incomplete step it peeks.
+      if (tid == 0) {
+        const unsigned long long v = tail_sync_load(V0.C, k);
+        ctl[1] = ((int32_t)(uint32_t)v >= (int32_t)slots) ? 1 : 0;
+        ctl[2] = (int32_t)(uint32_t)(v >> 32);
+      }
+      __syncthreads();
+      const bool over = ctl[1] != 0;
+      const int32_t cn = ctl[2];
+      __syncthreads();
+      if (over) {
+        c_next = (B > 1) ? vload_fresh(&V0.C->tail_sync[2 * k + 1], V0.vstride, B) : cn;
+        continue;
+      }
+      behind = false;
+      if (k > 0) {               // (it skipped steps without taking their acquire fences)
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+      }
+    }
+    // This workgroup's jobs of the step, ONE call site for all of them (the tile code is large): first its own tile(s) -- cluster tiles as
+    // in march_tile16 (members = workgroups with equal index mod 8: one XCD), single-workgroup tiles b, b + 256, ... --, then the wait for
+    // the step (sticky step: for every tile to have an owner), and from a wait that took too long a scan over all tiles for abandoned ones.
+    enum { OWN = 0, WAIT = 1, SCAN = 2 };
+    int mode = OWN;
+    int64_t cur = bidx, scan = 0;
+    int member = 0;
+    if (P.cl > 1) {
+      const int gq = bidx / (8 * P.cl), r = bidx % (8 * P.cl);
+      cur = gq * 8 + (r & 7);
+      member = r >> 3;
+    }
+    const long long t_step = (long long)wall_clock64();
+    for (;;) {
+      if (mode == OWN && cur >= slots) mode = WAIT;
+      if (mode == WAIT) {
+        int32_t state = 0;     // 1: the step is complete, 2: waited too long
+        if (P.sticky) {
+          // The tiles march to the end inside their workgroups: nothing to wait for -- but no tile may stay without an owner. Everybody (own tile
+          // done, or none) watches the claim words until all are taken; after TAIL_T_STEAL an unclaimed tile's lead member is not coming.
+          int32_t v = k + 1;
+          if (tid < slots) v = __hip_atomic_load(tail_claim_word(V0, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool open = __syncthreads_or(tid < 64 && v < k + 1) != 0;
+          state = !open ? 1 : ((long long)wall_clock64() - t_step > TAIL_T_STEAL) ? 2 : 0;
+          if (state == 0) __builtin_amdgcn_s_sleep(32);
+          state = __builtin_amdgcn_readfirstlane(state);
+        } else {
+          if (tid == 0) {
+            // ONE 8-byte load per poll: { tiles counted, rays entering the next step } -- when the first says "all", the second is final (a
+            // tile's count atomics are complete before it is counted)
+            const long long t0 = (long long)wall_clock64();
+            int32_t st;
+            for (;;) {
+              const unsigned long long v = tail_sync_load(V0.C, k);
+              if ((int32_t)(uint32_t)v >= (int32_t)slots) { st = 1; ctl[2] = (int32_t)(uint32_t)(v >> 32); break; }
+              if ((long long)wall_clock64() - t0 > TAIL_T_STEAL) { st = 2; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+            ctl[1] = st;
+          }
+          __syncthreads();
+          state = ctl[1];
+          c_next = ctl[2];
+          __syncthreads();
+        }
+        if (state == 1) break;
+        if (state == 0) continue;
+        mode = SCAN; scan = 0;
+      }
+      if (mode == SCAN && scan >= slots) {      // every tile has been offered to this workgroup: all of them have an owner now
+        if (P.sticky) break;
+        mode = WAIT;
+        continue;
+      }
+      const int64_t vt = (mode == OWN) ? cur : (bidx + scan) % slots;
+      const int cl = (mode == OWN) ? P.cl : 1;
+      // the tile reads the kernel's arguments through references taken HERE (kernarg_ref): none of them is loaded in front of the step
+      // loop and carried across every tile
+      constexpr size_t OFF_D = (sizeof(MarchArgs) + alignof(DecoderDev) - 1) / alignof(DecoderDev) * alignof(DecoderDev);
+      constexpr size_t OFF_D16 = (OFF_D + sizeof(DecoderDev) + alignof(DecoderDev16) - 1) / alignof(DecoderDev16) * alignof(DecoderDev16);
+      tail_slot<KEEP>(kernarg_ref<MarchArgs>(0), kernarg_ref<DecoderDev>(OFF_D), kernarg_ref<DecoderDev16>(OFF_D16), S, ctl, P, xc, vt + zero, k, cl,
+                      ((mode == OWN) ? member : 0) + zero, P.sticky && vt < P.ntiles, mode == SCAN);
+      if (mode == OWN) cur = (P.cl > 1) ? slots : cur + nwg;
+      else ++scan;
+    }
+    if (P.sticky) return;      // (the sticky tiles have marched their rays to the end)
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE acquire per workgroup, then plain loads of what the step wrote
+    __syncthreads();
+    if (B > 1) c_next = vload_fresh(&V0.C->tail_sync[2 * k + 1], V0.vstride, B);      // a batch: every view's own count word
+  }
 }
 
 // One full-resolution march step of the recursive marchers in ONE launch: the three tile sizes of the split (fine_range)
@@ -1193,7 +1548,7 @@ __global__ void __launch_bounds__(256, 1) k_step(MarchArgs A, DecoderDev D, Deco
 // decode_color (core/utils/decoder_utils.py:94-112) for the surface points of SDFRenderer_color.render_color
 // (core/sdfrenderer/renderer_rgb.py:20-38): the same fused tile on the colour decoder's weights (latent = shape code |
 // colour code, folded into c0 / c4), lin8 with three rows, tanh on each. Forward only.
-__global__ void __launch_bounds__(256, 1) k_color(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
+DISTR_GLOBAL void __launch_bounds__(256, 1) k_color(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
                                                   float* __restrict__ rgb, DecoderDev D) {
   constexpr int RB = 2, TILE = 64;
   __shared__ Smem<RB> S;
@@ -1223,7 +1578,7 @@ __global__ void __launch_bounds__(256, 1) k_color(const float* __restrict__ xyz,
 // Backward of decode_color (decoder_utils.py:94-112 differentiated by autograd in the reference): recompute the colour decoder's
 // forward for a tile of 64 points keeping the ReLU masks, d8_c = g_rgb_c * (1 - rgb_c^2), dX chain with the 3-row lin8, per-tile
 // delta sums for the [shape | colour] code gradient, d rgb / d xyz per point.
-__global__ void __launch_bounds__(256, 1) k_color_bwd(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
+DISTR_GLOBAL void __launch_bounds__(256, 1) k_color_bwd(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4,
                                                       const float* __restrict__ g_rgb, float* __restrict__ g_xyz, float* __restrict__ partial,
                                                       DecoderDev D) {
   constexpr int RB = 2, TILE = 64;
@@ -1293,7 +1648,25 @@ __global__ void __launch_bounds__(256, (RB == 1) ? 2 : 1) k_debug_layer(const fl
 
 // ------------------------------------------------------------------------------------------ finalize
 // render_depth's output assembly (renderer.py:859-878) + depth = Zdepth*calib (renderer.py:967-969)
-__global__ void __launch_bounds__(256) k_finalize(View V0, float* zdepth, uint8_t* mask, float* min_sdf, float* depth) {
+// hint_out (host-mapped word, may be null): the first full-resolution step of THIS render that had at most tail_rays live rays over all
+// views (fine_steps: none) -- where the next render of the same configuration lets the persistent tail launch take over (k_tail; the
+// host reads the word without synchronising: a stale or missing value costs time, never rays).
+DISTR_GLOBAL void __launch_bounds__(256) k_finalize(View V0, float* zdepth, uint8_t* mask, float* min_sdf, float* depth, int32_t* hint_out, int32_t tail_rays) {
+  if (hint_out && blockIdx.x == 0 && blockIdx.y == 0 && V0.cfg.marcher != DISTR_MARCH_TRIVIAL) {
+    __shared__ int32_t s_first;
+    if (threadIdx.x == 0) s_first = V0.fine_steps;
+    __syncthreads();
+    for (int t = threadIdx.x; t < V0.fine_steps; t += 256) {
+      int64_t tot = 0;
+      for (int b = 0; b < V0.nviews; ++b) {
+        const Consts* Cb = reinterpret_cast<const Consts*>(reinterpret_cast<const char*>(V0.C) + (int64_t)b * V0.vstride);
+        tot += Cb->cnt_live[t] + Cb->cnt_sticky[t];
+      }
+      if (tot <= tail_rays) { atomicMin(&s_first, t); break; }     // (a thread's steps ascend: its first hit is its smallest)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(hint_out, s_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const View V = view_at(V0, blockIdx.y);
   {
     const size_t o = (size_t)blockIdx.y * V.P;         // outputs of a batch: [nviews][P]
@@ -1368,7 +1741,7 @@ __device__ __forceinline__ bool d2n_row_inner(const View& V, int y) {
 }
 
 // depth2normal (core/utils/render_utils.py:9-43) incl. its in-place zeroing of the background depth
-__global__ void __launch_bounds__(256) k_depth2normal(View V0, float* depth, float* normal) {
+DISTR_GLOBAL void __launch_bounds__(256) k_depth2normal(View V0, float* depth, float* normal) {
   const View V = view_at(V0, blockIdx.y);
   if (depth) depth += (size_t)blockIdx.y * V.P;
   if (normal) normal += (size_t)blockIdx.y * V.P * 3;
@@ -1613,7 +1986,7 @@ __global__ void __launch_bounds__(256, (RB == 1 && ARITH == 0) ? 2 : 1) k_bwd(Bw
 // ------------------------------------------------------------------------------------------ normals (autograd path)
 // render_normal (renderer.py:880-910) epilogue: n = normalize(3 * grad f) (torch-1.1 grad_outputs quirk,
 // decoder_utils.py:84), t = M n; render(): out = flipx(R t) (renderer.py:977-980)
-__global__ void __launch_bounds__(256) k_normal_finish(View V0, float* normal_hw3, float* normal_3xP, int write_nrm_t) {
+DISTR_GLOBAL void __launch_bounds__(256) k_normal_finish(View V0, float* normal_hw3, float* normal_3xP, int write_nrm_t) {
   const View V = view_at(V0, blockIdx.y);
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= V.C->cnt_normal) return;
@@ -1650,7 +2023,7 @@ __global__ void __launch_bounds__(256) k_normal_finish(View V0, float* normal_hw
 }
 
 // valid-pixel list of every view from a caller-provided mask [nviews][P] (render_normal)
-__global__ void __launch_bounds__(256) k_mask_list(View V0, const uint8_t* mask) {
+DISTR_GLOBAL void __launch_bounds__(256) k_mask_list(View V0, const uint8_t* mask) {
   const View V = view_at(V0, blockIdx.y);
   const int px = blockIdx.x * 256 + threadIdx.x;
   wave_append(px < V.P && mask[(size_t)blockIdx.y * V.P + px] != 0, px, V.nlist, &V.C->cnt_normal);
@@ -1843,7 +2216,7 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V0, const float* g_zdepth
 }
 
 // exclusive scan of the per-block sample counts, ordered sum of the per-block partials, pad sample (one block)
-__global__ void __launch_bounds__(256) k_bwd_scan(View V0, BwdWs W0, int nblk) {   // one block per view
+DISTR_GLOBAL void __launch_bounds__(256) k_bwd_scan(View V0, BwdWs W0, int nblk) {   // one block per view
   const View V = view_at(V0, blockIdx.x);
   const BwdWs Wv = bws_at(W0, blockIdx.x);
   const BwdBlocks B = Wv.BB;
@@ -1890,7 +2263,7 @@ __global__ void __launch_bounds__(256) k_bwd_scan(View V0, BwdWs W0, int nblk) {
 }
 
 // column sums of the tile partials over one chunk of tiles -> chunk_part[chunk][col] (fixed order, no atomics)
-__global__ void __launch_bounds__(256) k_bwd_reduce(View V0, BwdWs W0, int chunk, int tile) {   // grid (columns, chunks, nviews)
+DISTR_GLOBAL void __launch_bounds__(256) k_bwd_reduce(View V0, BwdWs W0, int chunk, int tile) {   // grid (columns, chunks, nviews)
   const View V = view_at(V0, blockIdx.z);
   const BwdWs Wv = bws_at(W0, blockIdx.z);
   const float* partial = Wv.partial;
@@ -1906,7 +2279,7 @@ __global__ void __launch_bounds__(256) k_bwd_reduce(View V0, BwdWs W0, int chunk
 }
 
 // decode_sdf backward (explicit points): ordered column sums of the tile partials, then g_latent as in k_bwd_final
-__global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial, int ntiles, DecoderDev D, float* g_latent) {
+DISTR_GLOBAL void __launch_bounds__(256) k_points_latent_grad(const float* partial, int ntiles, DecoderDev D, float* g_latent) {
   __shared__ float red[2 * HID];
   for (int col = threadIdx.x; col < 2 * HID; col += 256) {
     float s = 0.f;
@@ -1924,7 +2297,7 @@ __global__ void __launch_bounds__(256) k_points_latent_grad(const float* partial
 }
 
 // g_latent = W0lat^T sum(delta0) + W4lat^T sum(delta4); camera chain cam_pos = -R^T T (renderer.py:180-188)
-__global__ void __launch_bounds__(256) k_bwd_final(View V0, DecoderDev D, BwdWs W0, int nchunks_max, int chunk, int tile,
+DISTR_GLOBAL void __launch_bounds__(256) k_bwd_final(View V0, DecoderDev D, BwdWs W0, int nchunks_max, int chunk, int tile,
                                                    float* g_latent, float* g_R, float* g_T) {   // one block per view; outputs [nviews][256 | 9 | 3]
   const View V = view_at(V0, blockIdx.x);
   const float* chunk_part = bws_at(W0, blockIdx.x).chunk_part;

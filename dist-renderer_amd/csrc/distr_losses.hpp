@@ -37,7 +37,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* lds /*[4*NV]*/)
 }
 
 // ordered sum of [nblk][nv] partials -> out[nv] (one block; thread k owns column k)
-__global__ void __launch_bounds__(64) k_sum_partials(const float* __restrict__ partial, int nblk, int nv, float* __restrict__ out) {
+DISTR_GLOBAL void __launch_bounds__(64) k_sum_partials(const float* __restrict__ partial, int nblk, int nv, float* __restrict__ out) {
   const int k = threadIdx.x;
   if (k >= nv) return;
   float acc = 0.f;
@@ -94,7 +94,7 @@ __device__ __forceinline__ SinglePix single_terms(const SingleLossArgs& A, int i
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_single_loss_partial(SingleLossArgs A, float* __restrict__ partial /*[nblk][8]*/) {
+DISTR_GLOBAL void __launch_bounds__(256) k_single_loss_partial(SingleLossArgs A, float* __restrict__ partial /*[nblk][8]*/) {
   __shared__ float lds[32];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float v[8];
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) k_single_loss_partial(SingleLossArgs A, f
 }
 
 // sums[0..3], counts[4..7] -> losses[k] = mean over the term's pixel set, 0 for an empty set (loss_utils.py:82-84 etc.)
-__global__ void __launch_bounds__(64) k_single_loss_final(const float* __restrict__ partial, int nblk, float* __restrict__ out /*[8]: losses[4], counts[4]*/) {
+DISTR_GLOBAL void __launch_bounds__(64) k_single_loss_final(const float* __restrict__ partial, int nblk, float* __restrict__ out /*[8]: losses[4], counts[4]*/) {
   __shared__ float s[8];
   const int k = threadIdx.x;
   if (k < 8) {
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64) k_single_loss_final(const float* __restric
 }
 
 // upstream gradients g[4] of the four means -> gradients of depth / normal / min_sdf images
-__global__ void __launch_bounds__(256) k_single_loss_bwd(SingleLossArgs A, const float* __restrict__ lc /*[8] losses, counts*/,
+DISTR_GLOBAL void __launch_bounds__(256) k_single_loss_bwd(SingleLossArgs A, const float* __restrict__ lc /*[8] losses, counts*/,
                                                          const float* __restrict__ g /*[4]*/, float* __restrict__ g_depth,
                                                          float* __restrict__ g_normal, float* __restrict__ g_min_sdf) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -256,7 +256,7 @@ __device__ __forceinline__ void load_cam_pair(const WarpArgs& A, float* R1, floa
 
 // forward: per pixel keep flag, the two colour images (detached visualisation outputs), and per-block partials of
 // { sum |c1 - c2|, #kept, #valid(view 1) }
-__global__ void __launch_bounds__(256) k_warp_fwd(WarpArgs A, uint8_t* __restrict__ keep, float* __restrict__ color1,
+DISTR_GLOBAL void __launch_bounds__(256) k_warp_fwd(WarpArgs A, uint8_t* __restrict__ keep, float* __restrict__ color1,
                                                   float* __restrict__ color2, float* __restrict__ partial /*[nblk][3]*/) {
   __shared__ float lds[12];
   const int P = A.H * A.W;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_warp_fwd(WarpArgs A, uint8_t* __restric
 
 // out[0] = loss_color = mean |c1 - c2| over kept pixels x 3 channels (NaN for an empty kept set, as torch.mean of an
 // empty tensor; 0 when view 1 has no valid pixel, renderer_warp.py:111-113), out[1] = #kept, out[2] = #valid
-__global__ void __launch_bounds__(64) k_warp_final(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+DISTR_GLOBAL void __launch_bounds__(64) k_warp_final(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
   __shared__ float s[3];
   const int k = threadIdx.x;
   if (k < 3) {
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(64) k_warp_final(const float* __restrict__ par
 }
 
 // backward: g_loss (device scalar) -> g_z1[P] and per-block partials of the camera gradients [R1 9 | T1 3 | R2 9 | T2 3]
-__global__ void __launch_bounds__(256) k_warp_bwd(WarpArgs A, const float* __restrict__ fwd /*[3] loss, kept, valid*/,
+DISTR_GLOBAL void __launch_bounds__(256) k_warp_bwd(WarpArgs A, const float* __restrict__ fwd /*[3] loss, kept, valid*/,
                                                   const float* __restrict__ g_loss, float* __restrict__ g_z1,
                                                   float* __restrict__ partial /*[nblk][24]*/) {
   __shared__ float lds[96];

@@ -31,6 +31,27 @@
 
 namespace distr {
 
+// Non-template kernels: defined once, by the translation unit that launches them (distr_api.hip). The translation units that only hold
+// explicit instantiations of the big template kernels (distr_inst_*.hip, compiled in parallel) define DISTR_GLOBAL as `static __global__`:
+// what they do not use is not emitted there.
+#ifndef DISTR_GLOBAL
+#define DISTR_GLOBAL __global__
+#endif
+
+// A reference to a kernel argument that the optimiser cannot see through (taken from the kernarg segment pointer, NOT from the address of
+// the parameter: that would force a private copy of it): loads through it are still scalar loads from the constant
+// address space, but they depend on THIS statement and are not hoisted above it. Inside a loop that runs a decoder evaluation per
+// iteration (a sticky tile's march steps, the step loop of the persistent tail launch) loop-invariant kernel arguments are otherwise
+// loaded once in front of the loop and kept alive across every evaluation -- dozens of 64-bit pointers next to the 512-register tile:
+// parked in AGPRs, copied to VGPR pairs, spilled to scratch and reloaded (each reload a vmcnt(0)) on the critical path of every step.
+template <class T>
+__device__ __forceinline__ const T& kernarg_ref(size_t offset) {     // the kernel argument of type T at byte `offset` of the kernarg segment
+  typedef const char __attribute__((address_space(4)))* cptr;
+  cptr p = (cptr)__builtin_amdgcn_kernarg_segment_ptr() + offset;
+  asm volatile("" : "+s"(p));
+  return *(const T*)(uintptr_t)p;
+}
+
 constexpr int HID = 512;
 constexpr int LAT = 256;
 constexpr int NTHREADS = 256;
@@ -933,6 +954,8 @@ __device__ __forceinline__ float mlp_forward16(const DecoderDev& D, const Decode
 
 // Stores the ray's mask chunks in the common per-ray format (store_mask_chunk): the 16-bit word of 32-row block ob and
 // half h is  nib(kq=h, 2ob) | nib(kq=2+h, 2ob)<<4 | nib(kq=h, 2ob+1)<<8 | nib(kq=2+h, 2ob+1)<<12.
+// XC (k_tail): write-through stores (distr_kernels.hpp, st_x: the block may be rewritten a few steps later from another XCD)
+template <bool XC = false>
 __device__ __forceinline__ void store_masks16(uint4* mstore, const long long* mb /*[16] LDS*/, const uint32_t (&nib)[8], int wave,
                                               int lane) {
   uint32_t partner[8];
@@ -957,7 +980,14 @@ __device__ __forceinline__ void store_masks16(uint4* mstore, const long long* mb
   }
   uint4* dst = mstore + (size_t)b * 32 + (wave * 2 + kq) * 4;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) dst[v] = make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]);
+  for (int v = 0; v < 4; ++v) {
+    const uint4 val = make_uint4(q[4 * v], q[4 * v + 1], q[4 * v + 2], q[4 * v + 3]);
+    if constexpr (XC) {
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t vv = {val.x, val.y, val.z, val.w};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst + v), "v"(vv) : "memory");     // (s_nop: the store reads its data registers after issue)
+    } else dst[v] = val;
+  }
 }
 
 // =====================================================================================================================
@@ -995,6 +1025,8 @@ struct Xchg {
   int32_t sticky;      // 1: a launch whose clusters (8 CUs per tile) all fit may march its tiles to the end (DISTR_STICKY=0: off)
   uint32_t epochs;     // epochs this launch may use: epoch .. epoch + epochs - 1 (one per march step of a sticky tile)
   int32_t force_sc1;   // tests (DISTR_XCHG_SC1=1): write-through stores even when all members share an XCD (the mixed-XCD path)
+  int32_t t_go;        // 100 MHz ticks a member waits for the lead's verdict; 0: CL_T_GO. The persistent tail kernel (k_tail) sets a short one:
+                       // its workgroups start a step together, and a tile whose lead is not resident is evaluated by another workgroup
 };
 constexpr int XSLOT_BYTES = 2048 * 32;            // one granule slot: 512 rows x 16 rays x 8 B
 constexpr int XCLUSTER_BYTES = 2 * XSLOT_BYTES;
@@ -1632,7 +1664,7 @@ __device__ __forceinline__ void cl_load_start(const float* __restrict__ init, in
 __device__ __forceinline__ constexpr int cl_lead(int cl) { return cl - 1; }
 
 template <int CL>
-__device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int32_t* sc1, int test_abort, int force_sc1) {
+__device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_t epoch, int tid, int32_t* fail, int32_t* sc1, int test_abort, int force_sc1, long long t_go) {
   if (tid < 64) {
     const long long t0 = (long long)wall_clock64();
     if (member == cl_lead(CL)) {
@@ -1640,7 +1672,7 @@ __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_
       for (;;) {
         const uint32_t v = (tid < CL) ? __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (epoch << 4);
         if (__ballot((v >> 4) != epoch) == 0ull) {
-          ok = !test_abort;
+          ok = __ballot(test_abort != 0) == 0ull;     // (any lane: k_tail hands the lead's lost-claim flag in on lane 0)
           const uint32_t x0 = __shfl(v & 15u, 0);
           mixed = __ballot(tid < CL && (v & 15u) != x0) != 0ull;
           break;
@@ -1659,7 +1691,7 @@ __device__ __forceinline__ void cl_assemble(uint32_t* flags, int member, uint32_
         const uint32_t v = (tid < 3) ? __hip_atomic_load(flags + 8 * 8 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const unsigned long long hit = __ballot(v == epoch);
         if (hit & 5ull) { if (tid == 0) *sc1 = (hit & 4ull) ? 1 : 0; break; }     // go (same XCD / mixed)
-        if ((hit & 2ull) || (long long)wall_clock64() - t0 > CL_T_GO) {   // abort, or no verdict: withdraw the arrival word and leave
+        if ((hit & 2ull) || (long long)wall_clock64() - t0 > t_go) {   // abort, or no verdict: withdraw the arrival word and leave
           if (tid == 0) { *fail = 1; __hip_atomic_store(flags + member, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           break;
         }
@@ -1971,7 +2003,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
 template <int CL, bool KEEP, bool ALL_LIN8 = false, bool MASK_OWN = false>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
                                                   const float* __restrict__ c4, Smem16CLX& S, const Xchg& xc, int cluster, int member,
-                                                  bool assemble = true) {
+                                                  bool assemble = true, int32_t abort_lane = 0) {
   const int tid = cl_tid();
   const int wave = cl_wave(tid);
   const int lane = tid & 63;
@@ -2023,7 +2055,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   }
   DISTR_XTS(1);
   if (assemble) {
-    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, &S.sc1, xc.test_abort, xc.force_sc1);
+    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, &S.sc1, xc.test_abort | abort_lane, xc.force_sc1, xc.t_go > 0 ? (long long)xc.t_go : CL_T_GO);
     if (S.fail) { cl_wait_vm<0>(); return 0.f; }
   }
   // position of every layer's chunk 0 in the network-wide chunk sequence (see layer_cl)

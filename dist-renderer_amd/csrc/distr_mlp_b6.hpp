@@ -420,7 +420,7 @@ __device__ __forceinline__ void mlp_backward_b6(const DecoderDev& D, const Decod
 }
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-bf16 arithmetic
-__global__ void __launch_bounds__(256, 1) k_eval_b6(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
+DISTR_GLOBAL void __launch_bounds__(256, 1) k_eval_b6(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
                                                     float* __restrict__ sdf, DecoderDev D, DecoderB6 B6) {
   __shared__ SmemB6<2> S;
   const int tid = threadIdx.x;

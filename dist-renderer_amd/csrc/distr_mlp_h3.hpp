@@ -447,7 +447,7 @@ __device__ __forceinline__ void mlp_backward_h3(const DecoderDev& D, const Decod
 
 // decode_sdf (core/utils/decoder_utils.py:53-74) for n explicit points in split-f16 arithmetic; a point whose evaluation left the
 // f16 range gets NaN (not a clamped number)
-__global__ void __launch_bounds__(256, 1) k_eval_h3(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
+DISTR_GLOBAL void __launch_bounds__(256, 1) k_eval_h3(const float* __restrict__ xyz, int64_t n, const float* __restrict__ c0c4, float clamp,
                                                     float* __restrict__ sdf, DecoderDev D, DecoderH3 H3) {
   __shared__ SmemH3<2> S;
   const int tid = threadIdx.x;

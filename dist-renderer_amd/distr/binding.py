@@ -26,7 +26,7 @@ EXPORTS = ['distr_version', 'distr_abi_version', 'distr_create_abi', 'distr_dest
            'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
            'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6', 'distr_mlp_eval_f16x3']
 
-ABI_VERSION = 4                                   # DISTR_ABI_VERSION of include/distr.h this mirror was written against
+ABI_VERSION = 5                                   # DISTR_ABI_VERSION of include/distr.h this mirror was written against
 MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
 VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
 
@@ -94,10 +94,14 @@ def make_warp_cfg(img_hw, intrinsic, thres_depth):
 
 class RenderStats(_Sized):
     _fields_ = [('struct_size', C.c_uint32), ('reserved', C.c_uint32), ('num_in_sphere', C.c_int64), ('num_march_launches', C.c_int64), ('num_point_evals', C.c_int64),
-                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64), ('f16_overflows', C.c_int64)]
+                ('num_valid', C.c_int64), ('num_grad_samples', C.c_int64), ('cluster_fallbacks', C.c_int64), ('f16_overflows', C.c_int64),
+                ('tail_from', C.c_int64), ('tail_steals', C.c_int64)]
 
 
-SOURCES = ('distr_api.hip', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_mlp_h3.hpp', 'distr_losses.hpp', 'distr_dense_asm.hpp')
+SOURCES = ('distr_api.hip', 'distr_inst.hip', 'distr_inst.hpp', 'distr_kernels.hpp', 'distr_mlp.hpp', 'distr_mlp_b6.hpp', 'distr_mlp_h3.hpp', 'distr_losses.hpp',
+           'distr_dense_asm.hpp')
+INST_GROUPS = 6            # distr_inst.hpp: DISTR_NUM_INST_GROUPS translation units of explicit kernel instantiations
+HIPCC_FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC']
 
 
 def source_digest():
@@ -112,18 +116,67 @@ def source_digest():
     return h.hexdigest()
 
 
-def build_library(force=False, verbose=False):
-    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
+def build_commands(obj_dir=None):
+    """[(label, argv, output)] of the compile steps and the link step of libdistr.so: distr_api.hip (host code, launch sequences, the small
+    kernels) and one translation unit per group of explicit instantiations of the big template kernels (distr_inst.hip with
+    -DDISTR_INST_GROUP=n) -- independent of each other, compiled side by side -- then one link."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    obj_dir = obj_dir or os.path.join(CSRC, '_obj')
+    steps = [('api', [hipcc] + HIPCC_FLAGS + ['-c', os.path.join(CSRC, 'distr_api.hip'), '-o', os.path.join(obj_dir, 'distr_api.o')],
+              os.path.join(obj_dir, 'distr_api.o'))]
+    for g in range(1, INST_GROUPS + 1):
+        o = os.path.join(obj_dir, 'distr_inst_%d.o' % g)
+        steps.append(('inst%d' % g, [hipcc] + HIPCC_FLAGS + ['-DDISTR_INST_GROUP=%d' % g, '-c', os.path.join(CSRC, 'distr_inst.hip'), '-o', o], o))
+    link = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + [s[2] for s in steps]
+    return steps, link
+
+
+def build_library(force=False, verbose=False, jobs=None, only=None):
+    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU): the translation units of build_commands() in parallel (`jobs`
+    at a time: default min(cores, 7); DISTR_BUILD_JOBS overrides), then the link. Returns the .so path. only = labels to recompile (the other
+    objects are reused as they are: local iteration on one kernel group; never used by build())."""
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
     srcs.append(os.path.join(_HERE, '..', '..', 'include', 'distr.h'))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    if not force and not only and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
-           '-o', LIB_PATH, os.path.join(CSRC, 'distr_api.hip')]
+    steps, link = build_commands()
+    os.makedirs(os.path.dirname(steps[0][2]), exist_ok=True)
+    if only:
+        missing = [s[0] for s in steps if s[0] not in only and not os.path.exists(s[2])]
+        if missing:
+            raise DistrError('build_library(only=%r): no object yet for %s' % (only, ', '.join(missing)))
+        todo = [s for s in steps if s[0] in only]
+    else:
+        todo = list(steps)
+    jobs = int(os.environ.get('DISTR_BUILD_JOBS', jobs or max(1, min(os.cpu_count() or 1, 7))))
+    running, failed = [], []
+    import time as _time
+    t0 = _time.time()
+    while todo or running:
+        while todo and len(running) < jobs:
+            label, cmd, out = todo.pop(0)
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            running.append((label, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for item in list(running):
+            label, pr = item
+            if pr.poll() is None:
+                continue
+            out = pr.communicate()[0]
+            running.remove(item)
+            if pr.returncode != 0:
+                failed.append((label, out))
+                for _, other in running:
+                    other.kill()
+                todo = []
+            elif verbose:
+                print('[%s done after %.0f s]%s' % (label, _time.time() - t0, ('\n' + out) if out.strip() else ''), flush=True)
+        _time.sleep(0.2)
+    if failed:
+        raise DistrError('hipcc failed on %s:\n%s' % (failed[0][0], failed[0][1][-6000:]))
     if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(' '.join(link), flush=True)
+    subprocess.check_call(link, cwd=CSRC)
     return LIB_PATH
 
 

@@ -12,27 +12,39 @@ import torch
 import torch.distributed as dist
 
 
+class LaunchError(RuntimeError):
+    """The job was launched in a way the one-process-per-GPU design cannot run (e.g. more RCCL ranks than GPUs on the node)."""
+
+
 def init_from_env(backend=None):
     """Initialises torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
-    Returns (rank, world_size, local_rank). backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'."""
+    Returns (rank, world_size, local_rank). backend: 'nccl' (= RCCL on ROCm) when CUDA/HIP is available, else 'gloo'.
+    Under RCCL every rank needs its OWN GPU: LOCAL_RANK >= device_count is refused (LaunchError) before any communicator exists -- a
+    mis-launched job (nproc-per-node above the GPU count, or a HIP_VISIBLE_DEVICES mask the launcher did not see) must not quietly
+    time-share GPUs. Only the test rigs that run several ranks on one GPU over gloo (DISTR_DIST_BACKEND=gloo) wrap the index."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if torch.cuda.is_available():
-        local = local % torch.cuda.device_count()     # (test rigs with fewer GPUs than ranks; one GPU per rank otherwise)
+    have_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = os.environ.get('DISTR_DIST_BACKEND') or ('nccl' if have_gpu else 'gloo')
+    if have_gpu:
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            if backend == 'nccl' and world > 1:
+                raise LaunchError('LOCAL_RANK %d (rank %d of %d) but only %d GPU(s) visible to this process: RCCL ranks cannot share a device. '
+                                  'Launch one process per GPU (--nproc-per-node <= %d), or set DISTR_DIST_BACKEND=gloo for a protocol test '
+                                  'that time-shares GPUs' % (local, rank, world, ndev, ndev))
+            local = local % ndev                       # (gloo test rigs with fewer GPUs than ranks)
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = os.environ.get('DISTR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         kw = {}
-        if torch.cuda.is_available():
+        if have_gpu:
             torch.cuda.set_device(local)
-            if backend == 'nccl' and torch.cuda.device_count() >= int(os.environ.get('LOCAL_WORLD_SIZE', world)):
+            if backend == 'nccl':
                 # bind the communicator to THIS rank's GPU at creation: RCCL then initialises eagerly on that device and
-                # barrier() / the first collective do not have to guess it from "the device under the current context".
-                # (Fewer GPUs than local ranks -- a mis-launched job -- keeps the lazy path: the caller's own check reports
-                # "RCCL ranks cannot share a device" instead of an RCCL error from inside the constructor.)
+                # barrier() / the first collective do not have to guess it from "the device under the current context"
                 kw['device_id'] = torch.device('cuda', local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define DISTR_ABI_VERSION 4u /* bumped whenever a struct layout or an entry point's signature changes (4: struct_size fields, distr_create_abi) */
+#define DISTR_ABI_VERSION 5u /* bumped whenever a struct layout or an entry point's signature changes (4: struct_size fields, distr_create_abi;
+                                5: distr_render_stats.tail_from / tail_steals) */
 
 /* zero a boundary struct and announce its size: distr_render_cfg cfg; DISTR_INIT(cfg); cfg.H = ...; */
 #define DISTR_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); } while (0)
@@ -145,6 +146,11 @@ typedef struct distr_render_stats {
                                  evaluated it alone instead -- same values bit for bit, only slower. 0 on an otherwise idle GPU. */
   int64_t f16_overflows;      /* arith = DISTR_ARITH_F16X3 only: decoder evaluations of the march whose result was not finite because an
                                  activation left the f16 range. Anything but 0 means the render is not to be trusted: use arith 1 or 0. */
+  int64_t tail_from;          /* first full-resolution march step that ran inside the persistent tail launch (one launch for ALL remaining
+                                 steps, no launch behind the last live ray); = the number of full-resolution steps when there was none.
+                                 num_march_launches counts the tail launch once. */
+  int64_t tail_steals;        /* tiles of the tail launch evaluated by a workgroup other than their owner because the owner was not resident
+                                 in time (compute units held by another stream / process): same values, only slower. 0 on an idle GPU. */
 } distr_render_stats;
 
 /* distr_create(&ctx, device): a macro, so that the ABI version the CALLER was compiled with reaches the library. A context is

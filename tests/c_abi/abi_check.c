@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
   OFF(distr_decoder_desc, struct_size); OFF(distr_decoder_desc, latent_size); OFF(distr_decoder_desc, hidden); OFF(distr_decoder_desc, num_linear); OFF(distr_decoder_desc, latent_in);
   OFF(distr_render_stats, struct_size); OFF(distr_render_stats, reserved); OFF(distr_render_stats, num_in_sphere); OFF(distr_render_stats, num_march_launches); OFF(distr_render_stats, num_point_evals);
   OFF(distr_render_stats, num_valid); OFF(distr_render_stats, num_grad_samples); OFF(distr_render_stats, cluster_fallbacks); OFF(distr_render_stats, f16_overflows);
+  OFF(distr_render_stats, tail_from); OFF(distr_render_stats, tail_steals);
   OFF(distr_warp_cfg, struct_size); OFF(distr_warp_cfg, H); OFF(distr_warp_cfg, W); OFF(distr_warp_cfg, K); OFF(distr_warp_cfg, K_inv); OFF(distr_warp_cfg, thres_depth);
   printf("sizeof distr_decoder_desc %zu\nsizeof distr_render_stats %zu\nsizeof distr_warp_cfg %zu\n", sizeof(distr_decoder_desc),
          sizeof(distr_render_stats), sizeof(distr_warp_cfg));
