@@ -110,6 +110,8 @@ def optimize_multi_view(renderer, evaluator, shape_code, shape_optimizer, images
                         on_round=None, distributed=None, batched=True):
     from distr import parallel
     rank, world = _dist_state(distributed)
+    if world > 1:
+        parallel.reset_pending_errors()      # (a flag left behind by a loop that ended through another exception must not surface here)
     lead = rank == 0                         # printing / mesh extraction / evaluation happen once, on rank 0
     num_images = len(images)
     rot_freq = num_images / num_views_per_round

@@ -50,6 +50,8 @@ def optimize_single_view(sdfrenderer_list, evaluator, optimizer, shape_code, cam
     from distr import parallel
     from .optimize_multi import _dist_state, _StreamPool
     rank, world = _dist_state(distributed)
+    if world > 1:
+        parallel.reset_pending_errors()      # (a flag left behind by a loop that ended through another exception must not surface here)
     silent = silent or rank != 0             # printing / plots / evaluation once, on rank 0
     weights = list(renderer_weights) if renderer_weights else [1.0] * len(sdfrenderer_list)
     if grad_settings is None:

@@ -51,9 +51,11 @@ struct distr_ctx {
   bool cluster = true;          // DISTR_CLUSTER=0: single-workgroup 16-ray tiles only
   int max_cl = 8;               // DISTR_CLUSTER=4|8: largest cluster size
   int min_cl = 2;               // smallest cluster: pair tiles (2 CUs per 16 rays) for 1008 < rays <= 2032 (DISTR_CLUSTER_MIN=4: off)
-  int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT=1 (tests): every cluster aborts at assembly -> exercises the fallback path
+  int cluster_test_abort = 0;   // DISTR_CLUSTER_TEST_ABORT (tests): 1 = every cluster aborts at assembly (fallback path); 2 = member 0 of every cluster
+                                // gives up while staging h7, behind its last slice (the others complete without noticing: Xchg::test_abort)
   bool sticky = true;           // DISTR_STICKY=0: cluster tiles never keep their rays across march steps (sticky_tile16)
   int xchg_sc1 = 0;             // DISTR_XCHG_SC1=1 (tests): write-through slice stores even for clusters on one XCD (the mixed-XCD path)
+  int cluster_spread = 0;       // DISTR_CLUSTER_SPREAD=1 (tests): cluster members on consecutive workgroups = different XCDs (Xchg::spread)
   // Persistent tail launch (k_tail): the full-resolution steps from `tail_from` on run inside one launch. tail_from is a HOST decision
   // taken without synchronising: the step at which the PREVIOUS render of the same configuration first had at most tail_rays live rays
   // (k_finalize writes it to a host-mapped word, read here whenever the next render is enqueued: stale is fine, k_tail is correct for any
@@ -295,7 +297,7 @@ distr_ctx::XRegion* xchg_region(distr_ctx* ctx, hipStream_t stream) {
 // stream (no stale word or tag may equal a future one) and counting restarts at 1.
 inline Xchg next_xchg(distr_ctx::XRegion* r, hipStream_t s, bool ts, int max_cl, int test_abort, int min_cl, uint32_t epochs = 1, bool sticky = false,
                       int force_sc1 = 0) {
-  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1, force_sc1, 0};
+  Xchg x{nullptr, nullptr, 0, max_cl, min_cl, test_abort, nullptr, 0, 0, 1, force_sc1, 0, 0};
   if (r && ts) x.ts = reinterpret_cast<long long*>(r->flags + 256 * 128);
   if (r) {
     if (r->epoch > 0x0fffffffu - epochs - 1) {
@@ -467,10 +469,11 @@ int distr_create_abi(distr_ctx** out, int hip_device, uint32_t abi_version) {
   if (const char* e = getenv("DISTR_CLUSTER")) { ctx->cluster = atoi(e) != 0; if (atoi(e) >= 4) ctx->max_cl = atoi(e); }
   if (const char* e = getenv("DISTR_CLUSTER_MIN")) ctx->min_cl = atoi(e);
   if (const char* e = getenv("DISTR_XCHG_TS")) ctx->xchg_ts = atoi(e) != 0;
-  if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_CLUSTER_TEST_ABORT")) ctx->cluster_test_abort = atoi(e);     // 1: abort at assembly; 2: member 0 drops out behind its last slice
   if (const char* e = getenv("DISTR_SAVE_MASKS")) ctx->save_masks = atoi(e) != 0;
   if (const char* e = getenv("DISTR_STICKY")) ctx->sticky = atoi(e) != 0;
   if (const char* e = getenv("DISTR_XCHG_SC1")) ctx->xchg_sc1 = atoi(e) != 0;
+  if (const char* e = getenv("DISTR_CLUSTER_SPREAD")) ctx->cluster_spread = atoi(e) != 0;
   if (const char* e = getenv("DISTR_TAIL")) ctx->tail = atoi(e) != 0;
   if (const char* e = getenv("DISTR_TAIL_PX")) ctx->tail_px = atoi(e);
   if (const char* e = getenv("DISTR_TAIL_RAYS")) ctx->tail_rays = atoi(e);
@@ -590,12 +593,15 @@ static int build_decoder(distr_ctx* ctx, int nlat, int nout, const float* w, siz
   D.b8x[0] = nout > 1 ? b[8][1] : 0.f; D.b8x[1] = nout > 2 ? b[8][2] : 0.f;
   D.nlat = nlat;
   if (D16) for (int l = 0; l < 8; ++l) D16->Wf[l] = d + offW16[l];
-  // DIAGNOSTICS ONLY (values are wrong): every 512 x 512 layer of the 16-ray / cluster tiles reads lin1's fragments, so that their weight
-  // stream (2 MB instead of 6.3 MB) stays in one XCD's 4 MiB L2 -- separates "waiting for weights" from "issuing instructions" in the tail
+#ifdef DISTR_DIAG
+  // DIAGNOSTICS BUILDS ONLY (-DDISTR_DIAG; values are wrong): every 512 x 512 layer of the 16-ray / cluster tiles reads lin1's fragments, so
+  // that their weight stream (2 MB instead of 6.3 MB) stays in one XCD's 4 MiB L2 -- separates "waiting for weights" from "issuing
+  // instructions" in the tail. Not in the product library: an environment variable must never be able to change a render's values.
   if (D16 && getenv("DISTR_DEBUG_ALIAS_WEIGHTS")) {
     fprintf(stderr, "distr: DISTR_DEBUG_ALIAS_WEIGHTS is set -- the 16-ray / cluster tiles compute with the WRONG weights (timing diagnostics only)\n");
     for (int l : {2, 5, 6, 7}) D16->Wf[l] = D16->Wf[1];
   }
+#endif
   if (B6) {   // split-bf16 planes of lin1..lin7 for the opt-in arithmetic mode (distr_mlp_eval_bf16x6): 9.4 MB, own allocation
     std::vector<uint16_t> hb;
     size_t offb[8] = {0}, offbt[8] = {0};
@@ -824,6 +830,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       const int ctile = c16 ? 16 : 32 * crb;
       unsigned tiles = NV * (unsigned)((ln + ctile - 1) / ctile);
       A.xc = next_xchg(c16 ? xr : nullptr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, 1, false, ctx->xchg_sc1);
+      A.xc.spread = ctx->cluster_spread;
       if (c16 && xr) tiles = std::max(tiles, 256u);      // cluster tiles: up to 8 workgroups per 16 rays
       timer.begin();
       if (c16) {
@@ -867,6 +874,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
       // every remaining step inside this launch (k_tail): 256 workgroups, one per compute unit
       A.origin_tile = 1;
       A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky, ctx->xchg_sc1);
+      A.xc.spread = ctx->cluster_spread;
       A.xc.t_go = TAIL_T_GO;
       A.tail_absent = ctx->tail_absent;
       if (V.save_masks) hipLaunchKernelGGL((k_tail<true>), dim3(256), dim3(NTHREADS), 0, s, A, D, ctx->D16);
@@ -914,6 +922,7 @@ int render_forward_impl(distr_ctx* ctx, const distr_render_cfg* cfg, int nviews,
     } else {
       G.n32 = skip32 ? 0 : up8(std::min<int64_t>(N64, t32) / 32);
       A.xc = next_xchg(xr, s, ctx->xchg_ts, ctx->max_cl, ctx->cluster_test_abort, ctx->min_cl, (uint32_t)(V.fine_steps - st), ctx->sticky && !cfg->concurrent, ctx->xchg_sc1);
+      A.xc.spread = ctx->cluster_spread;
       unsigned n16 = (unsigned)(std::min<int64_t>(N64, t16) / 16) + (A.origin_tile ? NV : 0u);
       if (xr) n16 = std::max(n16, 256u);                             // cluster tiles: 8 / 4 / 2 workgroups per tile of at most 32 / 64 / 128
       G.n16 = up8(n16);

@@ -892,6 +892,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
   }
   const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
   bool solo = solo0;                  // the cluster broke up: the lead member finishes the tile alone
+  bool leaving = false;               // a member other than the lead that gave up after `go`: one evaluation of its own for the mask blocks, then out
   for (int step = step0, k = 0;; ++step, ++k) {
     if (tid < TILE) {
       float p[3] = {0.f, 0.f, 0.f};
@@ -921,8 +922,12 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0, (TAIL && k == 0) ? lost : 0);
       clustered = S.fail == 0;
       if (!clustered) {
-        if (!lead) return;
-        if (TAIL && k == 0) {   // the lead's claim had been lost (it told its members to leave): the tile belongs to somebody else
+        if (!lead) {
+          // (see tile16_run: a member that gives up after `go` stores this step's whole mask blocks from an evaluation of its own, then leaves)
+          if (!KEEP || !S.went) return;
+          leaving = true;
+        }
+        if (lead && TAIL && k == 0) {   // the lead's claim had been lost (it told its members to leave): the tile belongs to somebody else
           if (tid == 0) S.cont = lost;
           __syncthreads();
           if (S.cont) return;
@@ -992,7 +997,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         m = mn;
         stay = (za < maxbound) && (a >= Ve.cfg.threshold);
       }
-      if (!TAIL && solo && k == 0) {
+      if (!TAIL && solo && k == 0 && lead) {
         // the cluster never assembled (its compute units are held by another stream / rank): this tile does NOT turn sticky -- the
         // lead member evaluated the step alone and hands the surviving rays to the next step's live list like a per-step tile
         // (marching 16 rays to the end on ONE compute unit would cost twice a cluster step, every step)
@@ -1006,7 +1011,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
         if (lead && k > 0) atomicAdd(&Ve.C->cnt_sticky[step], __popcll(was));   // (the tile's first step is counted in cnt_live)
       }
     }
-    if (KEEP && (lead || clustered)) {
+    if (KEEP && (lead || clustered || leaving)) {
       if (tid < TILE) S.mb[tid] = mblock;
       __syncthreads();
       if (clustered) {
@@ -1016,6 +1021,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       }
     }
     __syncthreads();                   // S.cont visible; this step's LDS reads are done before the next step's points land
+    if (leaving) return;
     if (!S.cont || step + 1 >= Ve.fine_steps) break;
   }
 }
@@ -1071,7 +1077,18 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
         float cx, cy;
         level_center(L, id, cx, cy);
         const RayGeo g = make_ray(V.cfg.K_inv, cam.R, cx, cy);
-        if (MODE == MODE_FINE) { raypre_load<false>(V, id, st); zd = st.init_now + st.m; }
+        if (MODE == MODE_FINE) {
+          raypre_load<false>(V, id, st);
+          zd = st.init_now + st.m;
+          if constexpr (TAIL) {
+            // the persistent tail launch parks the ray's state in LDS across the evaluation instead of twenty registers per lane (inside
+            // its step loop they end up in scratch). NOT re-read from memory in the epilogue: a cluster's members other than the lead
+            // need the selected rows as they were BEFORE the lead member's epilogue rewrites them (topk_slot_pre: where the mask block goes)
+            S.sst[0][tid] = st.m; S.sst[1][tid] = st.init_now; S.sst[2][tid] = st.maxbound; S.sst[3][tid] = st.minabs;
+#pragma unroll
+            for (int k = 0; k < MAX_BS; ++k) { S.sk[k][tid] = st.ks[k]; S.ssl[k][tid] = st.sl[k]; }
+          }
+        }
         else zd = L.cinit[id] + L.cm[id];
         make_point(V.cfg.M, cam.c, g.d, zd, p);
       }
@@ -1098,7 +1115,16 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
     } else pre = 0.f;
     helper = member != cl_lead(cl);      // only the lead member runs the epilogue; with KEEP the others store their mask words
     clustered = S.fail == 0;
-    if (helper && (!KEEP || !clustered)) return;
+    if (helper && !clustered) {
+      // Gave up before `go` (or no masks to save): the lead member evaluates the tile alone and stores whole mask blocks. Gave up AFTER
+      // `go` with masks to save: it may have published every slice already (a timeout while staging h7) -- then the others complete the
+      // tile and store THEIR words of the rays' mask blocks, and this member's words would keep what an earlier render left there (ADVICE
+      // r5). It evaluates the tile on its own and stores the whole blocks (the same bits the others store: harmless where they overlap).
+      if (!KEEP || !S.went) return;
+      if (tid == 0) atomicAdd(&V.C->xchg_err, 1);
+      __syncthreads();
+      pre = mlp_forward16<KEEP>(D, D16, c0, c4, S, nib);
+    } else
     if (!clustered) {
       if constexpr (TAIL) {      // ... or its lead's claim had been lost: the tile is somebody else's
         if (tid == 0) S.cont = t.lost;
@@ -1123,14 +1149,16 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
   long long mblock = -1;
   if (tid < 64) {
     const float s = tanh_spec(pre);
-    // the persistent tail launch reads the ray's state AGAIN here instead of carrying twenty registers per lane across the evaluation
-    // (inside its step loop they end up in scratch); its per-step tiles are not where its time goes (k_tail takes over at the sticky regime)
-    RayPre st_again;
+    RayPre st_again;         // (the persistent tail launch: the state parked in LDS by the prologue)
     if constexpr (TAIL && MODE == MODE_FINE) {
       st_again.m = 0.f; st_again.init_now = 0.f; st_again.maxbound = 0.f; st_again.minabs = 0.f;
 #pragma unroll
       for (int k = 0; k < MAX_BS; ++k) { st_again.ks[k] = 0.f; st_again.sl[k] = 0; }
-      if (valid) raypre_load<false>(V, id, st_again);
+      if (valid) {
+        st_again.m = S.sst[0][tid]; st_again.init_now = S.sst[1][tid]; st_again.maxbound = S.sst[2][tid]; st_again.minabs = S.sst[3][tid];
+#pragma unroll
+        for (int k = 0; k < MAX_BS; ++k) { st_again.ks[k] = S.sk[k][tid]; st_again.sl[k] = S.ssl[k][tid]; }
+      }
     }
     const RayPre& sr = (TAIL && MODE == MODE_FINE) ? st_again : st;
     if (helper) {      // where the mask blocks go, nothing else (the lead member writes the step's results)
@@ -1250,6 +1278,7 @@ __device__ __forceinline__ void march_tile16(const MarchArgs& A, const DecoderDe
     const int gq = bidx / (8 * cl), r = bidx % (8 * cl);
     tile = gq * 8 + (r & 7);
     member = r >> 3;
+    if (A.xc.spread) { tile = gq * 8 + r / cl; member = r % cl; }     // tests: members on consecutive workgroups = different XCDs
   }
   const bool origin = norigin > 0 && tile >= ntiles && tile < ntiles + norigin;
   int vb = 0;
@@ -1387,12 +1416,18 @@ __device__ __forceinline__ void tail_slot(const MarchArgs& A, const DecoderDev& 
   // second counter of the rays that stay live: the count word next to the step's barrier word, in the tile's view
   t.count2 = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(&V0.C->tail_sync[2 * k + 1]) + (int64_t)t.vb * V0.vstride);
   tile16_run<MODE_FINE, KEEP, Smem16CLX, true>(A, D, D16, S, t, xc);
-  __syncthreads();                // the tile's stores are issued; its LDS is free for the next tile
-  if (lead && !sticky && tid == 0 && !t.lost) {
-    // release the tile's results (ray state, next step's list entries: plain stores) to the other XCDs, THEN count the tile
+  // EVERY wave's stores have reached the L2 (vmcnt(0)) before ONE lane writes the L2's dirty lines back: a mask-block store of waves 1..3
+  // that lands behind the write-back would stay dirty in this XCD's L2 until some later release -- and then overwrite what a cluster on
+  // another XCD has meanwhile written THROUGH to the same block (the slot was reused two steps later): wrong ReLU masks in the backward,
+  // found by the absent-workgroup test (plain whole-block stores of taken-over tiles next to write-through words of cluster members).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                // ... and the tile's LDS is free for the next tile
+  if (!sticky && tid == 0) {
+    // release the tile's results (ray state, next step's list entries, whole mask blocks: plain stores) to the other XCDs -- every member
+    // that stored anything (a member that gave up after `go` stores whole blocks too) --, THEN the lead member counts the tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    atomicAdd(&V0.C->tail_sync[2 * k], 1);
+    if (lead && !t.lost) atomicAdd(&V0.C->tail_sync[2 * k], 1);
   }
 }
 
@@ -1454,6 +1489,7 @@ __global__ void __launch_bounds__(256, 1) k_tail(MarchArgs A, DecoderDev D, Deco
       const int gq = bidx / (8 * P.cl), r = bidx % (8 * P.cl);
       cur = gq * 8 + (r & 7);
       member = r >> 3;
+      if (xc.spread) { cur = gq * 8 + r / P.cl; member = r % P.cl; }     // tests: members on consecutive workgroups = different XCDs
     }
     const long long t_step = (long long)wall_clock64();
     for (;;) {
@@ -1465,10 +1501,12 @@ __global__ void __launch_bounds__(256, 1) k_tail(MarchArgs A, DecoderDev D, Deco
           // done, or none) watches the claim words until all are taken; after TAIL_T_STEAL an unclaimed tile's lead member is not coming.
           int32_t v = k + 1;
           if (tid < slots) v = __hip_atomic_load(tail_claim_word(V0, tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (ONE thread reads the clock: every wave must take the same branch -- the tile code behind it is full of workgroup barriers)
+          if (tid == 0) ctl[1] = ((long long)wall_clock64() - t_step > TAIL_T_STEAL) ? 2 : 0;
           const bool open = __syncthreads_or(tid < 64 && v < k + 1) != 0;
-          state = !open ? 1 : ((long long)wall_clock64() - t_step > TAIL_T_STEAL) ? 2 : 0;
+          state = !open ? 1 : ctl[1];
+          __syncthreads();
           if (state == 0) __builtin_amdgcn_s_sleep(32);
-          state = __builtin_amdgcn_readfirstlane(state);
         } else {
           if (tid == 0) {
             // ONE 8-byte load per poll: { tiles counted, rays entering the next step } -- when the first says "all", the second is final (a

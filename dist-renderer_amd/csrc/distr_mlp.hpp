@@ -782,8 +782,10 @@ struct Smem16CL : Smem16 {
   int32_t fail;           // != 0: this member gave up on the cluster (assembly or a staging unit timed out / aborted)
   int32_t sc1;            // the cluster's members sit on more than one XCD: slices are stored write-through (cl_assemble)
   int32_t cont;           // sticky tiles: any ray of the tile still live after this step
+  int32_t went;           // the cluster assembled (`go` seen): a member that gives up AFTER that may have published every slice the others need
   float sk[8][16];        // sticky tiles: the rays' selected-row keys (sdf, |.| ascending) and mask slots between steps
   int32_t ssl[8][16];     // (DISTR_MAX_BUFFER_SIZE rows; kept here, not in registers, across the decoder evaluation)
+  float sst[4][16];       // k_tail's per-step tiles: the rays' m, init_now, maxbound, minabs between a tile's prologue and its epilogue (with sk / ssl)
 };
 
 using Smem16CLX = Smem16CL;      // (cluster tiles need no landing zone in LDS: the granule requests land in fixed registers)
@@ -1027,6 +1029,9 @@ struct Xchg {
   int32_t force_sc1;   // tests (DISTR_XCHG_SC1=1): write-through stores even when all members share an XCD (the mixed-XCD path)
   int32_t t_go;        // 100 MHz ticks a member waits for the lead's verdict; 0: CL_T_GO. The persistent tail kernel (k_tail) sets a short one:
                        // its workgroups start a step together, and a tile whose lead is not resident is evaluated by another workgroup
+  int32_t spread;      // tests (DISTR_CLUSTER_SPREAD=1): the members of a cluster are CONSECUTIVE workgroups (one per XCD) instead of workgroups
+                       // with equal index mod 8 (one XCD): every cluster then really spans XCDs -- the assembly sees different XCC ids and
+                       // switches the cluster to write-through slice stores (the mixed-XCD path, otherwise only reached by dispatcher accident)
 };
 constexpr int XSLOT_BYTES = 2048 * 32;            // one granule slot: 512 rows x 16 rays x 8 B
 constexpr int XCLUSTER_BYTES = 2 * XSLOT_BYTES;
@@ -2019,6 +2024,7 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   if (tid == 0) {   // arrival word first: the lead member counts them while everybody computes lin0
     S.fail = 0;
     if (assemble) {
+      S.went = 0;
       uint32_t xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       S.sc1 = 1;    // (until the verdict)
@@ -2055,8 +2061,9 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   }
   DISTR_XTS(1);
   if (assemble) {
-    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, &S.sc1, xc.test_abort | abort_lane, xc.force_sc1, xc.t_go > 0 ? (long long)xc.t_go : CL_T_GO);
+    cl_assemble<CL>(flags, member, xc.epoch, tid, &S.fail, &S.sc1, (xc.test_abort & 1) | abort_lane, xc.force_sc1, xc.t_go > 0 ? (long long)xc.t_go : CL_T_GO);
     if (S.fail) { cl_wait_vm<0>(); return 0.f; }
+    if (tid == 0) S.went = 1;        // (read behind later barriers only)
   }
   // position of every layer's chunk 0 in the network-wide chunk sequence (see layer_cl)
   constexpr int N1 = ClGeom<512, 512, CL>::NCH, N3 = ClGeom<512, 256, CL>::NCH, N4 = ClGeom<256, 512, CL>::NCH;
@@ -2087,6 +2094,8 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
     cl_request_unit<CL, 3>(slot7, wave, lane);
     cl_stage_unit<CL, 2, 4>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
     cl_stage_unit<CL, 3, 0>(slot7, tag7, member * PER7, PER7, S, tid, wave, KEEP && lead && !MASK_OWN, 7, 7);
+    // tests (test_abort bit 1): member 0 gives up HERE, behind its last slice -- the rest of the cluster completes without noticing
+    if ((xc.test_abort & 2) && member == 0 && !lead && tid == 0) S.fail = 1;
     __syncthreads();
     if (S.fail) { cl_wait_vm<0>(); return 0.f; }
   }

@@ -122,13 +122,68 @@ def build_commands(obj_dir=None):
     -DDISTR_INST_GROUP=n) -- independent of each other, compiled side by side -- then one link."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     obj_dir = obj_dir or os.path.join(CSRC, '_obj')
-    steps = [('api', [hipcc] + HIPCC_FLAGS + ['-c', os.path.join(CSRC, 'distr_api.hip'), '-o', os.path.join(obj_dir, 'distr_api.o')],
-              os.path.join(obj_dir, 'distr_api.o'))]
+    # every unit in a directory of its own, with -save-temps=obj: the device assembly the objects were made from stays next to them
+    # (<unit>/<source>-hip-amdgcn-amd-amdhsa-gfx950.s) and is what check_generated_code() reads -- the checked code IS the shipped code
+    flags = HIPCC_FLAGS + ['-save-temps=obj']
+    steps = [('api', [hipcc] + flags + ['-c', os.path.join(CSRC, 'distr_api.hip'), '-o', os.path.join(obj_dir, 'api', 'distr_api.o')],
+              os.path.join(obj_dir, 'api', 'distr_api.o'))]
     for g in range(1, INST_GROUPS + 1):
-        o = os.path.join(obj_dir, 'distr_inst_%d.o' % g)
-        steps.append(('inst%d' % g, [hipcc] + HIPCC_FLAGS + ['-DDISTR_INST_GROUP=%d' % g, '-c', os.path.join(CSRC, 'distr_inst.hip'), '-o', o], o))
+        o = os.path.join(obj_dir, 'inst%d' % g, 'distr_inst.o')
+        steps.append(('inst%d' % g, [hipcc] + flags + ['-DDISTR_INST_GROUP=%d' % g, '-c', os.path.join(CSRC, 'distr_inst.hip'), '-o', o], o))
     link = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB_PATH] + [s[2] for s in steps]
     return steps, link
+
+
+# kernels that contain the cluster tile (hand-counted vmcnt waits, live data in fixed registers between asm statements): unit, symbol part
+CLUSTER_KERNELS = (('inst1', 'k_stepILb1ELi0'), ('inst1', 'k_stepILb0ELi0'), ('inst2', 'k_tailILb1'), ('inst2', 'k_tailILb0'),
+                   ('inst3', 'k_march16ILi1ELb1'), ('inst3', 'k_march16ILi1ELb0'))
+NO_SCRATCH = ('k_step', 'k_march', 'k_bwd')          # kernels that must not carry scratch (private segment 0): name prefixes
+
+
+def check_generated_code(verbose=False, obj_dir=None):
+    """Static checks of the code hipcc generated for THIS build (the cluster tile passes live data between asm statements in
+    hard-coded registers, protected only by clobber lists -- so every build proves the compiler stayed out of them):
+      * profiles/tools/vm_hazard_scan.py: no instruction touches a register an asm-issued load has not delivered (hand-counted vmcnt waits);
+      * profiles/tools/check_fixed_regs.py: no compiler-generated instruction names a fixed register inside the cluster code;
+      * code-object notes of libdistr.so: the march / backward kernels carry no scratch (private_segment_fixed_size 0).
+    Raises DistrError with the findings; returns the per-kernel resource table."""
+    import contextlib
+    import importlib.util
+    import io
+    tools = os.path.abspath(os.path.join(_HERE, '..', '..', 'profiles', 'tools'))
+
+    def tool(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    obj_dir = obj_dir or os.path.join(CSRC, '_obj')
+    problems, log = [], []
+    scan, fixed = tool('vm_hazard_scan'), tool('check_fixed_regs')
+    for unit, sym in CLUSTER_KERNELS:
+        asm = os.path.join(obj_dir, unit, 'distr_inst-hip-amdgcn-amd-amdhsa-gfx950.s')
+        if not os.path.exists(asm):
+            problems.append('%s: no device assembly at %s (build_library writes it)' % (sym, asm))
+            continue
+        for fn, args in ((scan.main, [asm, sym, '10']), (fixed.main, [asm, sym])):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                n = fn(args)
+            log.append(buf.getvalue().strip())
+            if n:
+                problems.append(buf.getvalue().strip())
+    res = tool('kernel_resources').resources(LIB_PATH)
+    checked = [n for n in res if any(k in n for k in NO_SCRATCH)]        # (names are mangled when llvm-cxxfilt is missing: substring match)
+    for name in sorted(checked):
+        r = res[name]
+        if r['scratch'] != 0 or r['vgpr_spill'] != 0:
+            problems.append('%s: %d bytes of scratch per lane, %d spilled VGPRs (must be 0)' % (name.split('(')[0], r['scratch'], r['vgpr_spill']))
+    if verbose:
+        print('\n'.join(log))
+        print('scratch: %d kernels of k_step* / k_march* / k_bwd* checked: none carries scratch' % len(checked) if not problems else 'scratch: see below')
+    if problems:
+        raise DistrError('generated-code checks failed:\n' + '\n'.join(problems))
+    return res
 
 
 def build_library(force=False, verbose=False, jobs=None, only=None):
@@ -140,7 +195,8 @@ def build_library(force=False, verbose=False, jobs=None, only=None):
     if not force and not only and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     steps, link = build_commands()
-    os.makedirs(os.path.dirname(steps[0][2]), exist_ok=True)
+    for st in steps:
+        os.makedirs(os.path.dirname(st[2]), exist_ok=True)
     if only:
         missing = [s[0] for s in steps if s[0] not in only and not os.path.exists(s[2])]
         if missing:

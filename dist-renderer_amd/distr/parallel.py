@@ -192,6 +192,12 @@ def _reduction_device(group, params):
 _pending_flags = {}          # group -> (host copy of a step's error flag, event after the copy): read before the NEXT collective
 
 
+def reset_pending_errors(group=None):
+    """Forgets a deferred error flag of `group` without reading it: called where an optimisation loop STARTS, so that a flag left behind
+    by a loop that ended through some other exception cannot surface as a stale RemoteRankError in the first step of the next run."""
+    _pending_flags.pop(group, None)
+
+
 def check_pending_errors(group=None):
     """Reads the error flag of the previous allreduce_grads of `group`, if that call deferred it (device buffers: the flag is copied
     to pinned host memory behind the all-reduce and read here, i.e. before the next collective or at the end of the loop, when the
@@ -221,7 +227,12 @@ def allreduce_grads(params, scalars=(), group=None, error=None, lazy=None):
     exception after the all-reduce, every other rank raises RemoteRankError. Returns the reduced scalars as 0-d tensors.
     `lazy` (default: on for device buffers): the flag of THIS step is not read here (a device -> host sync in every optimiser
     step) but by check_pending_errors() at the start of the next call / the end of the loop: the failing rank still raises at
-    once (it knows), the others one step later and before they enter another collective, so nobody is left waiting either."""
+    once (it knows), the others one step later and before they enter another collective, so nobody is left waiting either.
+    What the healthy ranks do with the failed step in between: the failing rank contributed ZEROS (never a half-accumulated .grad), and
+    the reduced gradients are multiplied ON THE DEVICE by (flag == 0) -- so the optimiser step the healthy ranks still take on that
+    step sees a zero gradient (Adam: its momentum decays, nothing of the failed step enters the parameters), the callbacks of that one
+    step see the state before it plus that momentum-only update, and RemoteRankError follows before anything else is reduced. A caller
+    that checkpoints in an `except RemoteRankError` handler saves a valid, slightly stale state -- not a corrupted one."""
     params = [p for p in params if p is not None]
     if not is_distributed(group):
         if error is not None:
@@ -250,6 +261,7 @@ def allreduce_grads(params, scalars=(), group=None, error=None, lazy=None):
     if lazy is None:
         lazy = flat.is_cuda
     if lazy:
+        flat[:-1] *= (flat[-1:] == 0).to(flat.dtype)      # a step some rank failed in applies NO gradient anywhere (no host sync: a device-side gate)
         if flat.is_cuda:
             host = torch.empty(1, dtype=flat.dtype, pin_memory=True)
             host.copy_(flat[-1:], non_blocking=True)

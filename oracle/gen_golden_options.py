@@ -80,6 +80,11 @@ def main():
         for k in ('g_latent', 'g_R', 'g_T'):
             out['%s.%s_floor_rel' % (name, k)] = float(np.abs(a[k] - b[k]).max() / np.abs(a[k]).max())
         out['%s.flips_floor' % name] = int((a['mask'] != b['mask']).sum())
+        # the reference's own floor of the NORMAL image (99th percentile over pixels valid in both renders) and the size of its normal
+        # vectors (1 when normalised; 3 |grad f| otherwise): the bar of the normal comparison is derived from these, not hand-tuned
+        both = a['mask'].astype(bool) & b['mask'].astype(bool)
+        out['%s.normal_p99_floor' % name] = float(np.percentile(np.abs(a['normal'] - b['normal'])[both], 99)) if both.any() else 0.0
+        out['%s.normal_scale' % name] = float(np.percentile(np.linalg.norm(a['normal'][a['mask'].astype(bool)], axis=-1), 99)) if a['mask'].any() else 1.0
         print(name, 'valid', int(a['mask'].sum()), 'loss %.4f' % a['loss'], '|g_latent| %.3g' % np.abs(a['g_latent']).max(), flush=True)
     a = run(dec, latent, K, R, T, {}, {}, img_hw=None)                                    # size from the intrinsic (renderer.py:31-33)
     for k, v in a.items():

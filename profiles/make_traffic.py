@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, 'dist-renderer_amd'))
 def rows(path):
     out = {}
     for line in open(path):
-        m = re.match(r'\| (?:void )?(k_step|k_march)[^|]*\| (\w+) \| (\d+) \| ([0-9.e+]+) \|', line)
+        m = re.match(r'\| (?:void )?(k_step|k_march|k_tail)[^|]*\| (\w+) \| (\d+) \| ([0-9.e+]+) \|', line)
         if m:
             out[(m.group(1), m.group(2))] = (int(m.group(3)), float(m.group(4)))
     return out

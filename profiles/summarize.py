@@ -29,11 +29,12 @@ def main():
         rows = [r for r in csv.DictReader(open(f))]
         rows.sort(key=lambda r: int(r['Start_Timestamp']))
         march = [(r['Kernel_Name'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r.get('Grid_Size', ''), r.get('VGPR_Count', ''),
-                  r.get('Accum_VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Scratch_Size', '')) for r in rows if 'k_march' in r['Kernel_Name'] or 'k_step' in r['Kernel_Name']]
+                  r.get('Accum_VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Scratch_Size', '')) for r in rows if 'k_march' in r['Kernel_Name'] or 'k_step' in r['Kernel_Name'] or 'k_tail' in r['Kernel_Name']]
         if march:
             lines.append('## k_march-family launches of the last forward in launch order: <tile size>:<us> (16/32/64-ray kernels; c = coarse level)\n')
             def tag(name):
                 if 'k_step' in name: return 'step'
+                if 'k_tail' in name: return 'tail'
                 if 'k_march16' in name: return '16'
                 if 'k_march<1' in name: return 'c'
                 return '32' if ', 1, ' in name else '64'

@@ -9,10 +9,12 @@ import re
 import sys
 
 
-def main():
-    path, key = sys.argv[1], sys.argv[2]
-    a_lo = int(sys.argv[3]) if len(sys.argv) > 3 else 96
-    v_lo = int(sys.argv[4]) if len(sys.argv) > 4 else 224
+def main(argv=None):
+    """Returns the number of findings (0 = clean); importable: main(['x.s', 'k_step'])."""
+    argv = sys.argv[1:] if argv is None else argv
+    path, key = argv[0], argv[1]
+    a_lo = int(argv[2]) if len(argv) > 2 else 96
+    v_lo = int(argv[3]) if len(argv) > 3 else 224
     lines = open(path).read().split('\n')
     start = end = None
     for i, l in enumerate(lines):
@@ -62,8 +64,8 @@ def main():
     print('%s: cluster code spans lines %d..%d; compiler instructions naming a%d+ / v%d+ inside it: %d' % (key, lo, hi, a_lo, v_lo, len(hits)))
     for h in hits[:20]:
         print('   ', h[0], h[1][:110])
-    return 1 if hits else 0
+    return len(hits)
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    sys.exit(1 if main() else 0)

@@ -23,9 +23,11 @@ def regs(tok):
     return set()
 
 
-def main():
-    path, key = sys.argv[1], sys.argv[2]
-    limit = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+def main(argv=None):
+    """Returns the number of hazards found (0 = clean); importable: main(['x.s', 'k_step'])."""
+    argv = sys.argv[1:] if argv is None else argv
+    path, key = argv[0], argv[1]
+    limit = int(argv[2]) if len(argv) > 2 else 40
     lines = open(path).read().split('\n')
     start = None
     end = len(lines)
@@ -96,8 +98,9 @@ def main():
             nrep += 1
             if nrep <= limit:
                 print('line %d: %-70s touches %s in flight from: %s' % (i, l, sorted(hz)[:4], [q[1] for q in queue if q[0] & hz][:2]))
-    print('%d loads scanned, %d hazards' % (nload, nrep))
+    print('%s: %d loads scanned, %d hazards' % (key, nload, nrep))
+    return nrep
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(1 if main() else 0)

@@ -13,6 +13,38 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run on the GPU box with -m gpu)')
+    config.addinivalue_line('markers', 'big_oracle(key): needs a full-size CPU-oracle render (tests/helpers.py::BIG_ORACLE); such tests run last, '
+                                       'their oracle renders are made by a background thread from the start of the session')
+
+
+def pytest_collection_modifyitems(config, items):
+    # tests that wait for a full-size oracle render go to the END of the session (stable otherwise): the render thread then has the
+    # whole session's head start and the GPU is never idle behind 20-85 s of host work
+    big = [it for it in items if it.get_closest_marker('big_oracle')]
+    if big:
+        rest = [it for it in items if not it.get_closest_marker('big_oracle')]
+        items[:] = rest + big
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _big_oracle_prefetch(request):
+    keys = []
+    for it in request.session.items:
+        m = it.get_closest_marker('big_oracle')
+        if m and m.args:
+            k = m.args[0]
+            if k == 'param':                    # the key is built from the test's parameters
+                k = it.callspec.params.get('big_key')
+            if k and k not in keys:
+                keys.append(k)
+    if keys and os.environ.get('DISTR_NO_ORACLE_PREFETCH') != '1':
+        import helpers
+        from distr import fixture
+        from oracle import oracle as orc
+        orc.build()
+        Ws, bs, latent = fixture.make_decoder_weights()
+        helpers.start_big_oracle(orc.Oracle(Ws, bs), orc, latent, keys)
+    yield
 
 
 @pytest.fixture(scope='session')

@@ -82,8 +82,15 @@ def main():
     eng.ctx.profile_enable(False)
     counts = eng.ctx.live_counts(cfg, ws)
     ms = np.median(np.array(times), axis=0)
-    assert len(ms) == len(counts), (len(ms), len(counts))
     ncoarse = 6 if args.marcher == 'pyramid_recursive' else 0
+    st1 = eng.ctx.render_stats(cfg, ws)
+    tail_from = int(st1['tail_from'])
+    tail_steps = 0
+    if len(ms) != len(counts):
+        # the persistent tail launch: ONE launch for every full-resolution step from tail_from on (its row sums their evaluations)
+        assert len(ms) == ncoarse + tail_from + 1, (len(ms), len(counts), tail_from)
+        tail_steps = sum(1 for c in counts[ncoarse + tail_from:] if c > 0)
+        counts = list(counts[:ncoarse + tail_from]) + [int(sum(counts[ncoarse + tail_from:]))]
     dense_rate = None
     lines = ['# march launches of one forward: %dx%d, %d steps, %s, view %d (median of %d forwards)' % (H, W, args.march_step, args.marcher, args.view, args.reps), '',
              '| launch | rays evaluated | us | TFLOP/s | frac of %.1f | tile class | us at the dense rate |' % PEAK, '|---|---|---|---|---|---|---|']
@@ -100,13 +107,16 @@ def main():
         prop = FLOP * n / (dense_rate * 1e12) * 1e6 if dense_rate else 0.0
         name = ('coarse %d' % i) if i < ncoarse else ('step %d' % (i - ncoarse))
         cls = tile_class(n) if i >= ncoarse else 'coarse'
+        if tail_steps and i == len(ms) - 1:
+            name, cls = 'tail launch: steps %d..%d (%d with live rays: %.1f us per step)' % (tail_from, tail_from + tail_steps - 1, tail_steps, us / max(tail_steps, 1)), 'tail'
         lines.append('| %s | %d | %.1f | %.1f | %.3f | %s | %.1f |' % (name, n, us, tf, tf / PEAK, cls, prop))
         tot_us += us
         tot_prop += prop
         key = 'coarse' if i < ncoarse else ('rounds' if n >= 16384 else cls)
         c = classes.setdefault(key, [0, 0.0, 0])
         c[0] += 1; c[1] += us; c[2] += n
-    lines += ['', 'whole forward, 20 back-to-back without brackets: %.3f ms each; cluster fallbacks %d' % (wall_ms, st0['cluster_fallbacks'])]
+    lines += ['', 'whole forward, 20 back-to-back without brackets: %.3f ms each; cluster fallbacks %d; march launches %d (tail launch from step %d; tiles taken over: %d)'
+              % (wall_ms, st0['cluster_fallbacks'], st1['num_march_launches'], tail_from, st1['tail_steals'])]
     lines += ['', 'total: %d evaluations, %.2f ms in march kernels = %.1f TFLOP/s = %.3f of peak; at the dense rate (%.1f TFLOP/s) the same evaluations '
               'take %.2f ms' % (sum(counts), tot_us / 1e3, FLOP * sum(counts) / (tot_us * 1e-6) / 1e12, FLOP * sum(counts) / (tot_us * 1e-6) / 1e12 / PEAK,
                                dense_rate or 0.0, tot_prop / 1e3), '',

@@ -155,3 +155,56 @@ def write_deepsdf_experiment(root, state_dict, checkpoint='2000', module_prefix=
     sd = {(('module.' + k) if module_prefix else k): torch.from_numpy(np.ascontiguousarray(v)) for k, v in state_dict.items()}
     torch.save({'epoch': epoch, 'model_state_dict': sd}, os.path.join(root, 'ModelParameters', checkpoint + '.pth'))
     return root
+
+
+# ---- the few FULL-SIZE oracle renders of the GPU suite (one 512 x 512 oracle render = ~20 s of all host cores, the 1024 x 1024 / 100-step one
+# ~85 s: a third of the suite's wall time in round 5). They are independent of the GPU, so a background thread renders them from the
+# start of the session (tests/conftest.py: the tests that need them run LAST) while the other tests use the GPU; ctypes releases the GIL
+# inside the oracle. key -> (image side, camera of the C4 circle, march steps); all: pyramid_recursive, buffer 3, depth2normal, dense loss.
+BIG_ORACLE = {'c5_image0': (1024, 0, 100), 'c3': (512, 0, 50), 'c4_view1': (512, 1, 50), 'c4_view3': (512, 3, 50), 'c4_view5': (512, 5, 50),
+              'c4_view7': (512, 7, 50)}
+_big = {'thread': None, 'results': {}, 'events': {}, 'errors': {}}
+
+
+def bench_camera(view):
+    """The cameras of bench.py (8 on a circle around the object)."""
+    from distr import fixture
+    return fixture.make_camera(45.0 * view, 25.0 if view else 0.0, 1.6, 0.0) if view else fixture.make_camera(0, 0, 1.6, 0)
+
+
+def _big_oracle_render(key, O, orc, latent):
+    from distr import fixture
+    size, view, steps = BIG_ORACLE[key]
+    K = fixture.make_intrinsic(size, size)
+    R, T = bench_camera(view)
+    return oracle_render(O, orc, size, size, K, R, T, latent, march_step=steps, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)
+
+
+def start_big_oracle(O, orc, latent, keys):
+    """Background thread: the renders of `keys` one after the other (each already uses every core)."""
+    import threading
+    if _big['thread'] is not None:
+        return
+    for k in keys:
+        _big['events'][k] = threading.Event()
+
+    def work():
+        for k in keys:
+            try:
+                _big['results'][k] = _big_oracle_render(k, O, orc, latent)
+            except BaseException as e:          # (re-raised in the test that asks for the result)
+                _big['errors'][k] = e
+            _big['events'][k].set()
+    _big['thread'] = threading.Thread(target=work, name='big-oracle-prefetch', daemon=True)
+    _big['thread'].start()
+
+
+def big_oracle(key, O, orc, latent):
+    """The oracle's fwd + bwd result of BIG_ORACLE[key]: from the prefetch thread if it is (being) rendered there, else rendered now."""
+    ev = _big['events'].get(key)
+    if ev is None:
+        return _big_oracle_render(key, O, orc, latent)
+    ev.wait()
+    if key in _big['errors']:
+        raise _big['errors'][key]
+    return _big['results'].pop(key)

@@ -315,7 +315,11 @@ def test_c5_size_runs(engine, fixture_decoder):
     assert np.isfinite(a['g_latent']).all() and np.abs(a['g_latent']).max() > 0
     assert np.isfinite(a['g_R']).all() and np.isfinite(a['g_T']).all()
     st = engine.ctx.render_stats(a['cfg'], _last_ws(engine, a['cfg'], latent, R, T))
-    assert st['num_march_launches'] == 100 and st['num_in_sphere'] == H * W
+    # 6 coarse + 94 full-resolution steps: one launch each, or -- this configuration has been rendered before, so the previous render's hint
+    # moved the steps of the sticky regime into the persistent tail launch -- 6 + tail_from + 1
+    fine = 94
+    assert st['num_march_launches'] == (100 if st['tail_from'] == fine else 6 + st['tail_from'] + 1) and st['num_in_sphere'] == H * W
+    assert 0 < st['tail_from'] <= fine and st['tail_steals'] == 0
     assert st['num_valid'] == int(m.sum())
 
 

@@ -217,3 +217,44 @@ def test_two_tail_launches_on_two_streams(fixture_decoder, per_step_engine):
             z, mask, q, depth, normal = outs[i]
             for k, o in (('zdepth', z), ('mask', mask), ('min_sdf', q), ('depth', depth), ('normal', normal)):
                 assert np.array_equal(np.asarray(refs[i][k]).reshape(-1).view(np.uint8), o.cpu().numpy().reshape(-1).view(np.uint8)), (rep, i, k)
+
+
+@pytest.mark.parametrize('knobs', [{}, {'DISTR_TAIL_FROM': 0}], ids=['per-step', 'tail'])
+def test_cluster_member_dropping_out_behind_its_last_slice(fixture_decoder, per_step_engine, knobs):
+    """with saved masks every cluster member stores its OWN words of the rays' mask blocks. A helper that gives up after `go`,
+    behind its last slice (a timeout while staging h7), is not missed by the others -- its words would keep what an earlier render left
+    there and the backward would run on wrong ReLU masks without any signal. Forced for member 0 of every cluster
+    (DISTR_CLUSTER_TEST_ABORT=2): it evaluates the tile on its own and stores whole blocks; gradients stay bit-identical, the event is counted."""
+    from distr import binding, fixture
+    _, _, latent = fixture_decoder
+    eng = _engine(fixture_decoder, DISTR_CLUSTER_TEST_ABORT=2, **knobs)
+    H = W = 64
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(33, 12, 1.6, 0)
+    for marcher in ('recursive', 'pyramid_recursive'):
+        kw = dict(march_step=60, buffer_size=3, marcher=marcher, use_depth2normal=True, ratio=1.5)
+        for rep in range(2):          # (twice: the second render's workspace holds the first one's mask blocks)
+            a = helpers.hip_render(eng, H, W, K, R, T, latent, **kw)
+        b = helpers.hip_render(per_step_engine, H, W, K, R, T, latent, **kw)
+        assert _same(a, b) == [], (marcher, _same(a, b))
+        st, _ = _stats(eng, binding.make_cfg((H, W), K, **kw), latent, R, T)
+        assert st['cluster_fallbacks'] > 10, st
+
+
+@pytest.mark.parametrize('knobs', [{}, {'DISTR_TAIL_FROM': 0}], ids=['per-step', 'tail'])
+def test_clusters_spread_over_xcds(fixture_decoder, per_step_engine, knobs):
+    """the members of a cluster normally share an XCD (equal workgroup index mod 8); the mixed-XCD path (write-through slice
+    stores, chosen by the assembly from the members' XCC ids) was only ever forced with all members still on one XCD. DISTR_CLUSTER_SPREAD=1
+    puts the members of every cluster on CONSECUTIVE workgroups = eight different XCDs: the granules really cross XCDs. Same bytes, no fallback."""
+    from distr import binding, fixture
+    _, _, latent = fixture_decoder
+    eng = _engine(fixture_decoder, DISTR_CLUSTER_SPREAD=1, **knobs)
+    for (H, W, steps, marcher) in [(64, 64, 60, 'recursive'), (80, 80, 50, 'pyramid_recursive')]:
+        K = fixture.make_intrinsic(H, W)
+        R, T = fixture.make_camera(33, 12, 1.6, 0)
+        kw = dict(march_step=steps, buffer_size=3, marcher=marcher, use_depth2normal=True, ratio=1.5)
+        a = helpers.hip_render(eng, H, W, K, R, T, latent, **kw)
+        b = helpers.hip_render(per_step_engine, H, W, K, R, T, latent, **kw)
+        assert _same(a, b) == [], (marcher, _same(a, b))
+        st, _ = _stats(eng, binding.make_cfg((H, W), K, **kw), latent, R, T)
+        assert st['cluster_fallbacks'] == 0, st

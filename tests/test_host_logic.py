@@ -787,3 +787,81 @@ def test_cluster_members_own_disjoint_words_of_a_mask_block():
                     word, shift = put(layer, rb, wr_log, kq)
                     piece = [k for k in written if k[0] == word and k[1] <= shift < k[1] + k[2]]
                     assert len(piece) == 1 and written[piece[0]] == owner, (CL, layer, rb, kq)
+
+
+def test_rccl_launch_with_more_ranks_than_gpus_is_refused(monkeypatch):
+    """under backend 'nccl' (= RCCL) a LOCAL_RANK beyond the visible GPUs is a mis-launched job and is REFUSED before any
+    communicator exists -- not wrapped onto a shared GPU. The wrap stays for the gloo test rigs that time-share one GPU on purpose."""
+    import torch
+    from distr import parallel
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 2)
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    monkeypatch.setenv('RANK', '5')
+    monkeypatch.setenv('LOCAL_RANK', '5')
+    with pytest.raises(parallel.LaunchError) as e:
+        parallel.init_from_env(backend='nccl')
+    assert 'RCCL ranks cannot share a device' in str(e.value) and 'only 2 GPU' in str(e.value)
+    monkeypatch.delenv('DISTR_DIST_BACKEND', raising=False)
+    with pytest.raises(parallel.LaunchError):
+        parallel.init_from_env()                     # (default backend with a GPU visible: nccl)
+    # a single process, or the gloo rig: wrapped as before (no process group is created at world size 1)
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    monkeypatch.setenv('RANK', '0')
+    assert parallel.init_from_env(backend='gloo') == (0, 1, 1)
+    assert parallel.init_from_env(backend='nccl') == (0, 1, 1)
+
+
+@pytest.mark.parametrize('workload,n', [('c3', 8), ('c5', 8), ('c5', 2), ('c3', 4)])
+def test_bench_plan_only(workload, n):
+    """`bench.py --gpus N --plan-only`: the partition and the predicted per-rank load of an N-rank run as ONE JSON line, without a GPU and
+    without starting ranks. The partition is the one the real run starts from (parallel.shard_views / shard_rows)."""
+    import json
+    import subprocess
+    from distr import parallel
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--plan-only', '--workload', workload], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['plan_only'] is True and d['n_gpus'] == n and d['workload'] == workload and len(d['partition']) == n == len(d['predicted_ms_per_rank'])
+    if workload == 'c5':
+        assert d['scaling'] == 'strong'
+        rows = {}
+        for r, pieces in enumerate(d['partition']):
+            assert [tuple(p[:1] + p[2:]) for p in pieces] == [tuple(x) for x in parallel.shard_rows(4, 1024, r, n)]
+            for (img, _, r0, r1) in pieces:
+                assert r0 % 4 == 0
+                rows.setdefault(img, []).append((r0, r1))
+        for img in range(4):          # every image tiled exactly once
+            segs = sorted(rows[img])
+            assert segs[0][0] == 0 and segs[-1][1] == 1024 and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    else:
+        assert d['scaling'] == 'weak' and [p[0][1] for p in d['partition']] == list(range(n))
+    assert max(d['predicted_ms_per_rank']) == d['predicted_slowest_ms'] and 0.5 < d['predicted_efficiency_vs_n1'] <= 1.0
+
+
+def test_build_is_split_into_parallel_units_and_checked():
+    """libdistr.so = distr_api.hip + one translation unit per group of explicit kernel instantiations (distr_inst.hpp), compiled side by side;
+    every unit keeps its device assembly, and build() runs the generated-code checks on it (the checkers were claimed, not wired)."""
+    import re
+    from distr import binding
+    steps, link = binding.build_commands()
+    labels = [s[0] for s in steps]
+    assert labels == ['api'] + ['inst%d' % g for g in range(1, binding.INST_GROUPS + 1)]
+    hdr = open(os.path.join(binding.CSRC, 'distr_inst.hpp')).read()
+    assert int(re.search(r'DISTR_NUM_INST_GROUPS = (\d+)', hdr).group(1)) == binding.INST_GROUPS
+    assert sorted(set(int(g) for g in re.findall(r'DISTR_GROUP_ON\((\d+)\)', hdr))) == list(range(1, binding.INST_GROUPS + 1))
+    for label, cmd, out in steps:
+        assert '--offload-arch=gfx950' in cmd and '-save-temps=obj' in cmd and '-ffp-contract=off' in cmd
+        assert ('-DDISTR_INST_GROUP=%s' % label[4:] in cmd) == label.startswith('inst')
+    assert all(s[2] in link for s in steps) and link[-len(steps) - 1] == binding.LIB_PATH or binding.LIB_PATH in link
+    entry = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    assert 'check_generated_code' in entry
+    # every kernel that holds the cluster tile is on the list the checkers walk
+    assert {k for _, k in binding.CLUSTER_KERNELS} >= {'k_stepILb1ELi0', 'k_stepILb0ELi0', 'k_tailILb1', 'k_tailILb0', 'k_march16ILi1ELb1', 'k_march16ILi1ELb0'}
+    asm = os.path.join(binding.CSRC, '_obj', 'inst1', 'distr_inst-hip-amdgcn-amd-amdhsa-gfx950.s')
+    if os.path.exists(asm) and os.path.exists(binding.LIB_PATH) and os.path.getmtime(binding.LIB_PATH) >= os.path.getmtime(asm):
+        res = binding.check_generated_code()          # (the build of this checkout, if it is there: raises on a finding)
+        assert any('k_step' in n for n in res)

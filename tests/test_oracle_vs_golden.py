@@ -369,7 +369,12 @@ def check_g24(a, g, name):
     assert np.abs(a['min_sdf'].reshape(H, W) - g[name + '.q']).max() <= 1e-4, name
     dn = np.abs(a['normal'].reshape(H, W, 3) - g[name + '.normal'])[both]
     fx = float(g['K'][0, 0])
-    assert np.percentile(dn, 99) <= (max(1e-4, 1e-5 * fx) if 'd2n' in name else 1e-4) * (30.0 if name == 'unnormalized_normal' else 1.0), (name, np.percentile(dn, 99))
+    # north_star's 1e-4 relative to the size of the normal vectors (1 when normalised; 3 |grad f| for normalize_normal=False), or twice the
+    # reference's own floor of this very image under 1e-7 weight noise -- both recorded in the golden (oracle/gen_golden_options.py)
+    bar_n = max(1e-4 * max(1.0, float(g[name + '.normal_scale'])), 2.0 * float(g[name + '.normal_p99_floor']))
+    if 'd2n' in name:
+        bar_n = max(bar_n, 1e-5 * fx)
+    assert np.percentile(dn, 99) <= bar_n, (name, np.percentile(dn, 99), bar_n)
     res = {}
     for k in ('g_latent', 'g_R', 'g_T'):
         rel = float(np.abs(a[k].reshape(-1) - g['%s.%s' % (name, k)].reshape(-1)).max() / np.abs(g['%s.%s' % (name, k)]).max())
