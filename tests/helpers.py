@@ -189,6 +189,12 @@ def start_big_oracle(O, orc, latent, keys):
         _big['events'][k] = threading.Event()
 
     def work():
+        # half the cores for this thread's OpenMP regions (omp_set_num_threads is per calling thread): the foreground tests run oracle
+        # renders and multi-process loops of their own -- two full-width teams thrash (round 6, first try: the suite got no faster)
+        try:
+            orc.lib().orc_set_num_threads(max(8, orc.lib().orc_num_threads() // 2))
+        except Exception:
+            pass
         for k in keys:
             try:
                 _big['results'][k] = _big_oracle_render(k, O, orc, latent)
