@@ -798,7 +798,7 @@ def main():
 
     stats = forward_stats(cfg)
 
-    traffic = None
+    traffic = traffic_hbm = None
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))   # newest round's PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
     tpath = cands[-1] if cands else os.path.join(ROOT, 'profiles', 'r02_traffic.json')
@@ -812,6 +812,7 @@ def main():
             # the PMC pass describes the kernels it ran: if csrc/ has changed since, the number is not this library's
             traffic_stale = traffic_digest != built_from
             traffic = None if traffic_stale else tj['bytes_per_launch']
+            traffic_hbm = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
     rccl_info = collective_info(world, local)           # (collective: every rank takes part in the all-gather)
@@ -857,7 +858,11 @@ def main():
                          'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16 / f16 MFMA dense peak; algorithmic FLOP counted once (the six bf16 / three f16 products per f32 product are not counted several times)',
                          'traffic_csrc_sha256': traffic_digest, 'csrc_sha256': built_from,
                          'traffic_note': ('null: the committed PMC pass (%s) was taken on other kernels (csrc digest differs); re-run profiles/promote.sh' % os.path.relpath(tpath, ROOT)) if traffic_stale else 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
-                         'kernel': 'k_march / k_step (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
+                         'traffic_hbm': traffic_hbm,
+                         'traffic_hbm_note': 'null: not observable -- rocprofv3 on this stack exposes the L2\'s memory-side request counters only (every read request counts as '
+                                             '"destined for DRAM", TCC_EA0_RDREQ_DRAM = TCC_EA0_RDREQ); Infinity-Cache hits are not separated from HBM reads. HBM traffic <= `traffic`; '
+                                             'the render\'s working set (14.5 MB of weights + ray state) is far below the 256 MiB Infinity Cache (profiles/r06_traffic.json: memory_side_reads)',
+                         'kernel': 'k_march / k_step / k_tail (fused 9-layer decoder + march update; one hipEvent bracket per march launch, separate pass of %d steps), %d launches, %.3f ms total, avg %.1f us'
                                    % (ROOF_STEPS, launches, kernel_ms, 1e3 * kernel_ms / max(launches, 1)),
                          'flop_per_eval': FLOP_PER_EVAL, 'evals': evals},
         }

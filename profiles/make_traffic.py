@@ -32,17 +32,37 @@ def run_digest(pre):
 def main():
     pre = sys.argv[1]
     f, w, mf, l2 = (rows('%s_pmc_%s.md' % (pre, k)) for k in ('fetch', 'write', 'mfma', 'l2'))
-    n = f[('k_step', 'FETCH_SIZE')][0] + f[('k_march', 'FETCH_SIZE')][0]
-    fetch = f[('k_step', 'FETCH_SIZE')][1] + f[('k_march', 'FETCH_SIZE')][1]
-    write = w[('k_step', 'WRITE_SIZE')][1] + w[('k_march', 'WRITE_SIZE')][1]
+    fams = [k for k in ('k_step', 'k_march', 'k_tail') if (k, 'FETCH_SIZE') in f]      # (k_tail: only when the workload reaches the sticky regime)
+    n = sum(f[(k, 'FETCH_SIZE')][0] for k in fams)
+    fetch = sum(f[(k, 'FETCH_SIZE')][1] for k in fams)
+    write = sum(w[(k, 'WRITE_SIZE')][1] for k in fams)
     busy = lambda k: mf[(k, 'SQ_VALU_MFMA_BUSY_CYCLES')][1] / (mf[(k, 'GRBM_GUI_ACTIVE')][1] / 8.0 * 1024.0)
     hit = lambda k: l2[(k, 'TCC_HIT_sum')][1] / (l2[(k, 'TCC_HIT_sum')][1] + l2[(k, 'TCC_MISS_sum')][1])
+    # round 6: the L2's memory-side read requests split by destination (TCC_EA0_RDREQ_DRAM vs all TCC_EA0_RDREQ), if that pass exists
+    ea = None
+    try:
+        e, dr = rows(pre + '_pmc_ea.md'), rows(pre + '_pmc_dram.md')
+        rd = sum(e[(k, 'TCC_EA0_RDREQ_sum')][1] for k in fams)
+        rd32 = sum(e[(k, 'TCC_EA0_RDREQ_32B_sum')][1] for k in fams)
+        rdd = sum(dr[(k, 'TCC_EA0_RDREQ_DRAM_sum')][1] for k in fams)
+        wrd = sum(dr[(k, 'TCC_EA0_WRREQ_DRAM_sum')][1] for k in fams)
+        ea = {'TCC_EA0_RDREQ_sum': rd, 'TCC_EA0_RDREQ_32B_sum': rd32, 'TCC_EA0_RDREQ_DRAM_sum': rdd, 'TCC_EA0_WRREQ_DRAM_sum': wrd,
+              'rdreq_dram_fraction': rdd / rd if rd else None, 'fetch_size_check_kb': rd * 64.0 / 1024.0,
+              'hbm_bytes_per_launch': None,
+              'finding': 'every memory-side read request of the L2 is counted as "destined for DRAM (MC)" (TCC_EA0_RDREQ_DRAM = TCC_EA0_RDREQ; GMI / IO: none; '
+                         'FETCH_SIZE = RDREQ x 64 B exactly): the counters rocprofv3 exposes on this stack (profiles/r06_rocprof_counters.txt: no MALL / '
+                         'Infinity-Cache / UMC counter) see the fabric side of the L2 only -- whether a request is then served by the 256 MiB Infinity Cache or by '
+                         'HBM is NOT observable. Upper bound: HBM traffic <= the fabric figure (bytes_per_launch). The whole working set of a render (14.5 MB '
+                         'of packed weights + the ray state + the mask store of the live rows) is far below 256 MiB, so in steady state the re-fetched weight '
+                         'stream is expected to be served on-die; hbm_bytes_per_launch stays null rather than guessed.'}
+    except (OSError, KeyError):
+        pass
     name = pre.split('/')[-1]
     d = {
         'kernel': "k_step / k_march (all tile-size roles of one march step = one 'launch' of bench.py's roofline)",
         'source': 'profiles/%s_pmc_fetch.md (FETCH_SIZE) + profiles/%s_pmc_write.md (WRITE_SIZE): rocprofv3 --pmc, separate passes, '
-                  '`bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass` (%d march launches: %d k_step + %d coarse k_march); profiles/make_traffic.py'
-                  % (name, name, n, f[('k_step', 'FETCH_SIZE')][0], f[('k_march', 'FETCH_SIZE')][0]),
+                  '`bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass` (%d march launches: %s); profiles/make_traffic.py'
+                  % (name, name, n, ' + '.join('%d %s' % (f[(k, 'FETCH_SIZE')][0], k) for k in fams)),
         'fetch_size_kb_total': fetch, 'write_size_kb_total': write, 'march_launches': n,
         'fetch_correction': 'x2: gfx950 FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming loads (MI355X_MICROARCH.md, HBM '
                             'section); the weight fragments are buffer_load_dwordx4',
@@ -62,6 +82,9 @@ def main():
                 '(stream fits L2) changes the dense rate by 0.3 %; a non-temporal hint on layers 1-4 cut the coarse launches\' fetches by 15 % '
                 'and cost 1 % of the dense rate (profiles/README.md).',
     }
+    if ea is not None:
+        d['memory_side_reads'] = ea
+        d['hbm_bytes_per_launch'] = None
     json.dump(d, open('%s_traffic.json' % pre, 'w'), indent=1)
     print(json.dumps(d, indent=1))
 
