@@ -1314,20 +1314,22 @@ __global__ void __launch_bounds__(256, (MODE == MODE_EVAL) ? 2 : 1) k_march16(Ma
 
 // ------------------------------------------------------------------------------------------ persistent tail launch
 // k_tail: the full-resolution steps [tail_from, fine_steps) of the recursive marchers inside ONE launch of 256 workgroups (one per
-// compute unit), for the regime where a step is one 16-ray-tile latency or less (small images from their first step, every image
-// once few rays are left): a launch per step costs more than the step's hand-over needs there, and every launch the host issues after
-// the last ray has finished (it cannot know) is pure waste -- 72 of the 94 full-resolution launches of a 137 x 137 / 100-step render
-// (renderer.py:528-567 breaks out of its loop there; it synchronises the host every step to know).
+// compute unit). Every launch the host issues after the last ray has finished is pure waste, and the host cannot know when that is
+// without synchronising (renderer.py:528-567 breaks out of its loop there: one host sync per step) -- 72 of the 94 full-resolution
+// launches of a 137 x 137 / 100-step render found nothing to do. The host starts this launch where the previous render of the same
+// configuration entered the sticky regime (distr_api.hip: tail_hint_slot; a hint, never a correctness input: the kernel is correct for
+// any live count at any start step) and enqueues nothing behind it.
 // Per step every workgroup derives the SAME plan from the device-side live counts (tail_plan): the step's rays on 16-ray tiles --
 // cluster tiles of 8 / 4 / 2 workgroups while at most 32 / 64 / 128 tiles are left, single-workgroup tiles in rounds of 256 above
 // that -- and, once everything fits 32 cluster tiles, sticky tiles that march their rays to the end (sticky_tile16); then the launch
-// is over. A ray's arithmetic is exactly the per-step launches' one: bit-identical renders (tests: tail on / off).
+// is over. A ray's arithmetic is exactly the per-step launches' one: bit-identical renders (tests/test_gpu_tail.py).
 // Step barrier WITHOUT a co-residency assumption (the hardware promises none: another stream or process may hold compute units, and
 // two spinning launches could starve each other for ever): a tile is OWNED through a claim word (atomicMax with the step's tag), its
-// owner evaluates it, releases its stores (one agent-scope release fence per tile; every workgroup takes one acquire fence per step) and
-// counts it in tail_sync[2 step]; a step is complete when the count equals the number of tiles. Tiles are handed out statically (workgroup b: tiles b, b + 256, ...; clusters as in march_tile16, the lead member
-// claims), but a workgroup that has waited TAIL_T_STEAL for a step takes over every tile nobody has claimed and evaluates it alone --
-// so the launch finishes with ANY subset of its workgroups resident, and a lead that arrives late finds its tile taken and moves on.
+// owner evaluates it, releases its stores (one agent-scope release fence per tile; every workgroup takes one acquire fence per step)
+// and counts it in tail_sync[2 step]; a step is complete when the count equals the number of tiles. Tiles are handed out statically
+// (workgroup b: tiles b, b + 256, ...; clusters as in march_tile16, the lead member claims), but a workgroup that has waited
+// TAIL_T_STEAL for a step takes over every tile nobody has claimed and evaluates it alone -- so the launch finishes with ANY subset of
+// its workgroups resident, and a lead that arrives late finds its tile taken and moves on.
 constexpr long long TAIL_T_STEAL = 400 * 100;     // 400 us (100 MHz ticks): several tile latencies
 constexpr int32_t TAIL_T_GO = 150 * 100;          // a cluster member waits this long for its lead's verdict (workgroups start a step together)
 
