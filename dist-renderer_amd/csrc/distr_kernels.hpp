@@ -1146,6 +1146,9 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
     }
   }
 
+  // (the persistent tail launch: the epilogue takes its view of the workspace from kernel arguments re-read HERE, like a sticky tile's --
+  // inside the step loop the prologue's pointers would otherwise stay alive across the evaluation, in scratch)
+  const View Ve = TAIL ? view_at(kernarg_ref<MarchArgs>(0).V, t.vb) : V;
   long long mblock = -1;
   if (tid < 64) {
     const float s = tanh_spec(pre);
@@ -1163,56 +1166,58 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
     const RayPre& sr = (TAIL && MODE == MODE_FINE) ? st_again : st;
     if (helper) {      // where the mask blocks go, nothing else (the lead member writes the step's results)
       if (origin) {
-        if (tid == 0) mblock = V.morigin;
+        if (tid == 0) mblock = Ve.morigin;
       } else if (MODE == MODE_COARSE) {
-        if (valid) mblock = V.mfine + moff_sel(V, A.lvl) + (long long)((size_t)t.step * level_sel(V, A.lvl).n + id);
+        if (valid) mblock = Ve.mfine + moff_sel(Ve, A.lvl) + (long long)((size_t)t.step * level_sel(Ve, A.lvl).n + id);
       } else if (MODE == MODE_FINE) {
         if (valid) {
-          const int slot = topk_slot_pre(V, sr, s);
-          if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+          const int slot = topk_slot_pre(Ve, sr, s);
+          if (slot >= 0) mblock = (long long)id * (Ve.cfg.buffer_size + 1) + slot;
         }
       }
     } else if (origin) {
-      if (tid == 0) { V.C->f_origin = s; V.C->origin_done = 1; mblock = V.morigin; }
+      if (tid == 0) { Ve.C->f_origin = s; Ve.C->origin_done = 1; mblock = Ve.morigin; }
     } else if (MODE == MODE_EVAL) {
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
     } else if (MODE == MODE_COARSE) {
       if (valid) {
-        const LevelView L = level_sel(V, A.lvl);
-        const float mn = L.cm[id] + clampf(s, -V.cfg.clamp_dist, V.cfg.clamp_dist) * V.cfg.ratio;
+        const LevelView L = level_sel(Ve, A.lvl);
+        const float mn = L.cm[id] + clampf(s, -Ve.cfg.clamp_dist, Ve.cfg.clamp_dist) * Ve.cfg.ratio;
         L.cm[id] = mn;
         const size_t o = (size_t)t.step * L.n + id;
         L.rs[o] = s;
         L.rzb[o] = zd;
         L.rza[o] = mn + L.cinit[id];
-        mblock = V.mfine + moff_sel(V, A.lvl) + (long long)o;
+        mblock = Ve.mfine + moff_sel(Ve, A.lvl) + (long long)o;
       }
     } else {
-      const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
+      const float cd = Ve.cfg.clamp_dist, ratio = Ve.cfg.ratio;
       bool stay = false;
       if (valid) {
         const float mn = sr.m + clampf(s, -cd, cd) * ratio;
-        V.m[(uint32_t)id] = mn;
+        Ve.m[(uint32_t)id] = mn;
         const float za = mn + sr.init_now;
-        const int slot = topk_insert_pre<false>(V, sr, id, s, zd, V.pyramid ? za : mn, id);
-        if (slot >= 0) mblock = (long long)id * (V.cfg.buffer_size + 1) + slot;
+        const int slot = topk_insert_pre<false>(Ve, sr, id, s, zd, Ve.pyramid ? za : mn, id);
+        if (slot >= 0) mblock = (long long)id * (Ve.cfg.buffer_size + 1) + slot;
         const float a = fabsf(s);
-        if (a < sr.minabs) V.minabs[(uint32_t)id] = a;
-        if (t.step == 0) V.first_sdf[(uint32_t)id] = s;
-        stay = (za < sr.maxbound) && (a >= V.cfg.threshold);
+        if (a < sr.minabs) Ve.minabs[(uint32_t)id] = a;
+        if (t.step == 0) Ve.first_sdf[(uint32_t)id] = s;
+        stay = (za < sr.maxbound) && (a >= Ve.cfg.threshold);
       }
-      wave_append<false>(stay, id, live_sel(V, t.step + 1), &V.C->cnt_live[t.step + 1], TAIL ? t.count2 : nullptr);
+      wave_append<false>(stay, id, live_sel(Ve, t.step + 1), &Ve.C->cnt_live[t.step + 1], TAIL ? t.count2 : nullptr);
     }
   }
   if (KEEP && MODE != MODE_EVAL) {
     if (tid < TILE) S.mb[tid] = mblock;
     __syncthreads();
     if (clustered) {   // every member: its own words of the rays' blocks
-      if (cl == 8) store_own_mask_words<8, TAIL>(V.mstore, S.mb, S, member, tid);
-      else if (cl == 4) store_own_mask_words<4, TAIL>(V.mstore, S.mb, S, member, tid);
-      else store_own_mask_words<2, TAIL>(V.mstore, S.mb, S, member, tid);
+      int tz = 0;        // (tail launch: the word indices derived from the thread index are computed HERE, not once in front of the step loop)
+      if constexpr (TAIL) asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
+      if (cl == 8) store_own_mask_words<8, TAIL>(Ve.mstore, S.mb, S, member, tid + tz);
+      else if (cl == 4) store_own_mask_words<4, TAIL>(Ve.mstore, S.mb, S, member, tid + tz);
+      else store_own_mask_words<2, TAIL>(Ve.mstore, S.mb, S, member, tid + tz);
     } else {
-      store_masks16<false>(V.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+      store_masks16<false>(Ve.mstore, S.mb, nib, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     }
   }
 }

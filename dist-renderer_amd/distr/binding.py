@@ -137,7 +137,7 @@ def build_commands(obj_dir=None):
 # kernels that contain the cluster tile (hand-counted vmcnt waits, live data in fixed registers between asm statements): unit, symbol part
 CLUSTER_KERNELS = (('inst1', 'k_stepILb1ELi0'), ('inst1', 'k_stepILb0ELi0'), ('inst2', 'k_tailILb1'), ('inst2', 'k_tailILb0'),
                    ('inst3', 'k_march16ILi1ELb1'), ('inst3', 'k_march16ILi1ELb0'))
-NO_SCRATCH = ('k_step', 'k_march', 'k_bwd')          # kernels that must not carry scratch (private segment 0): name prefixes
+NO_SCRATCH = ('k_step', 'k_march', 'k_bwd', 'k_tail')          # kernels that must not carry scratch (private segment 0): name parts
 
 
 def check_generated_code(verbose=False, obj_dir=None):
@@ -180,7 +180,7 @@ def check_generated_code(verbose=False, obj_dir=None):
             problems.append('%s: %d bytes of scratch per lane, %d spilled VGPRs (must be 0)' % (name.split('(')[0], r['scratch'], r['vgpr_spill']))
     if verbose:
         print('\n'.join(log))
-        print('scratch: %d kernels of k_step* / k_march* / k_bwd* checked: none carries scratch' % len(checked) if not problems else 'scratch: see below')
+        print('scratch: %d kernels of k_step* / k_march* / k_bwd* / k_tail* checked: none carries scratch' % len(checked) if not problems else 'scratch: see below')
     if problems:
         raise DistrError('generated-code checks failed:\n' + '\n'.join(problems))
     return res
