@@ -537,6 +537,7 @@ def test_bench_rccl_multi_gpu():
         c = j['config']
         assert c['serial_check']['ok'] is True and c['scaling_measurement'] is True and c['rccl']['one_gpu_per_rank'] is True, c
         assert len({r['device_index'] for r in c['rccl']['ranks']}) == 2
+        assert len(c['partition']) == 2 and all(len(piece) == 4 for p in c['partition'] for piece in p), c['partition']     # (round 6: who renders what)
     cb = bal['config']
     assert cb['unbalanced_ms_per_step'] > 0 and cb['balanced_ms_per_step'] > 0 and cb['value_is'] in ('balanced', 'unbalanced')
     # the real backend is named, the N = 1-equivalent mode is stated, `value` switches only above the noise margin

@@ -962,6 +962,9 @@ def _check_multi_rank_line(j, n, balanced_possible):
     for mode, d in c['per_rank'].items():
         assert len(d['local_ms']) == n and len(d['allreduce_and_wait_ms']) == n and all(x > 0 for x in d['local_ms']), (mode, d)
     assert 'split_bf16' not in j and 'split_f16' not in j and 'cpu_baseline' not in j           # N > 1 times the exact path only
+    # round 6: what every rank renders per step under the mode `value` was timed in -- [shape, view, first row, end row] per piece
+    assert len(c['partition']) == n and all(len(p) >= 1 and all(len(piece) == 4 and piece[2] < piece[3] for piece in p) for p in c['partition']), c['partition']
+    assert 'extra' not in j                                                                      # (small renders: N = 1 only)
     # the line names the collective backend that really ran (gloo on this rig) and which timed mode is the N = 1 protocol on N GPUs
     assert 'gloo' in c['parallelism'] and 'NOT RCCL' in c['parallelism'] and 'RCCL all-reduce' not in c['parallelism'], c['parallelism']
     assert c['n1_protocol_equivalent'].startswith(('unbalanced', 'row_bands')), c['n1_protocol_equivalent']
