@@ -28,5 +28,7 @@ cp $F/cluster_phases.log $P/${R}_cluster_phases.log
   grep -E "passed|failed|^real" $F/soak_spread.log
   echo "#   six times: python -m pytest tests/test_gpu_tail.py -q -x   (tail launch: bit identity, hint, absent workgroups, batch, oracle, two streams, member drop-out, XCD spread)"
   grep -E "passed|failed|^real" $F/soak_tail.log ) > $P/${R}_soak.log
+# the timed GPU test run: summary line, slowest tests, wall clock
+if [ -f $F/pytest_gpu.log ]; then ( grep -E "passed|failed" $F/pytest_gpu.log | tail -1; grep -E "^real" $F/pytest_gpu.log; echo; grep -E "^[0-9.]+s (call|setup)" $F/pytest_gpu.log ) > $P/${R}_pytest_gpu_durations.log; fi
 python $P/make_traffic.py $P/$R > /dev/null
 ls -la $P | grep " ${R}_" | wc -l

@@ -1,6 +1,13 @@
 import os
 import sys
 
+# Idle OpenMP threads must SLEEP, not spin: the GPU suite renders its full-size oracle images in a background thread (tests/helpers.py) while
+# the foreground tests run oracle renders and multi-process loops of their own -- with the default active wait policy two teams of 128
+# spinning threads thrash each other (round 6, measured: 128 x 128 oracle renders 1 s -> 16 s, the suite slower than without the thread).
+# Read by libgomp when it is first loaded, i.e. before anything here imports torch or the oracle.
+os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+os.environ.setdefault('GOMP_SPINCOUNT', '0')
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
