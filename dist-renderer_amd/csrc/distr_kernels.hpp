@@ -248,6 +248,11 @@ __device__ __forceinline__ void st_x(T* p, T v) {
   else *p = v;
 }
 
+// number of set bits of a ballot below this lane (v_mbcnt: no per-lane 64-bit mask to build and keep)
+__device__ __forceinline__ int ballot_rank(unsigned long long ball) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+}
+
 // wave-level stream compaction: appends `id` of flagged lanes to list, one atomic per wavefront (counter2: a second counter that gets
 // the same increment -- k_tail keeps the next step's count next to the step's barrier word)
 template <bool XC = false>
@@ -259,7 +264,7 @@ __device__ __forceinline__ void wave_append(bool flag, int32_t id, int32_t* list
   int base = 0;
   if (lane == 0) { base = atomicAdd(counter, n); if (counter2) atomicAdd(counter2, n); }
   base = __shfl(base, 0);
-  if (flag) st_x<XC>(list + base + __popcll(ball & ((1ull << lane) - 1ull)), id);
+  if (flag) st_x<XC>(list + base + ballot_rank(ball), id);
 }
 
 // block-level stream compaction for the full-image setup kernels (256 threads): one atomic per BLOCK -- with one per
@@ -277,7 +282,7 @@ __device__ __forceinline__ void block_append(bool flag, int32_t id, int32_t* lis
   __syncthreads();
   int base = s_base;
   for (int w = 0; w < wave; ++w) base += s_n[w];
-  if (flag) list[base + __popcll(ball & ((1ull << lane) - 1ull))] = id;
+  if (flag) list[base + ballot_rank(ball)] = id;
 }
 
 // wave-level max, then one atomicMax per wavefront (skipped when the wave has nothing to contribute)
@@ -855,6 +860,10 @@ __device__ __forceinline__ void store_own_mask_words(uint4* mstore, const long l
   }
 }
 
+// kernel-argument offsets of the march kernels that take (MarchArgs, DecoderDev, DecoderDev16, ...): k_march16, k_step, k_tail
+constexpr size_t KERNARG_OFF_D = (sizeof(MarchArgs) + alignof(DecoderDev) - 1) / alignof(DecoderDev) * alignof(DecoderDev);
+constexpr size_t KERNARG_OFF_D16 = (KERNARG_OFF_D + sizeof(DecoderDev) + alignof(DecoderDev16) - 1) / alignof(DecoderDev16) * alignof(DecoderDev16);
+
 // Sticky tail tile (renderer.py:528-567 from the point where few rays are left): once ALL live rays of a step fit the cluster
 // tiles of one launch (<= 32 tiles of 16 rays, 8 compute units each), every tile marches ITS 16 rays through all remaining steps
 // inside that launch -- no compaction, no launch boundary, no device-wide barrier: tiles never exchange anything. The ray state
@@ -890,6 +899,16 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
 #pragma unroll
     for (int k = 0; k < MAX_BS; ++k) { S.sk[k][tid] = st.ks[k]; S.ssl[k][tid] = st.sl[k]; }   // selected-row keys / slots: LDS between steps
   }
+  if constexpr (TAIL) {   // lin0's operands into LDS, once for all of the tile's steps (Smem16CLX; visible behind the first step's barrier). Uniform bases
+      // re-read from the kernel arguments + 32-bit lane offsets: no per-lane 64-bit address lives across the caller's job loop
+    const f32x4* wb = reinterpret_cast<const f32x4*>(kernarg_ref<DecoderDev16>(KERNARG_OFF_D16).Wf[0]);
+    const float* cb = view_at(kernarg_ref<MarchArgs>(0).V, vb).C->c0;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, t32 = tid;
+#pragma unroll
+    for (uint32_t ob = 0; ob < 8; ++ob) S.w0s[w][ob][ln] = wb[w * 512u + ob * 64u + ln];
+    S.c0s[t32] = cb[t32];
+    S.c0s[t32 + NTHREADS] = cb[t32 + (uint32_t)NTHREADS];
+  }
   const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
   bool solo = solo0;                  // the cluster broke up: the lead member finishes the tile alone
   bool leaving = false;               // a member other than the lead that gave up after `go`: one evaluation of its own for the mask blocks, then out
@@ -919,7 +938,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
       Xchg xs = xc;
       xs.epoch = xc.epoch + (uint32_t)k;          // one epoch per march step (the host reserved them: Xchg::epochs)
       xs.par = (xc.par + k) & 1;                   // alternate the exchange slots: layer 1 of step k+1 must not reuse layer 7's
-      pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0, (TAIL && k == 0) ? lost : 0);
+      pre = mlp_forward16_cl<8, KEEP, true, true>(D, D16, c0 + zero, c4 + zero, S, xs, tile + zero, member + zero, k == 0, (TAIL && k == 0) ? lost : 0, TAIL);
       clustered = S.fail == 0;
       if (!clustered) {
         if (!lead) {
@@ -1340,7 +1359,8 @@ constexpr int32_t TAIL_T_GO = 150 * 100;          // a cluster member waits this
 
 __device__ __forceinline__ int32_t vload_fresh(const int32_t* p0, int64_t stride, int B) {   // vload past the L1 (counters other workgroups of THIS launch wrote)
   if (B <= 1) return __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));      // (the 64-bit lane x stride product is formed here, not once at kernel entry and kept across the job loop)
   return (lane < B) ? __hip_atomic_load(reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p0) + (int64_t)lane * stride), __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT) : 0;
 }
@@ -1546,8 +1566,7 @@ __global__ void __launch_bounds__(256, 1) k_tail(MarchArgs A, DecoderDev D, Deco
       const int cl = (mode == OWN) ? P.cl : 1;
       // the tile reads the kernel's arguments through references taken HERE (kernarg_ref): none of them is loaded in front of the step
       // loop and carried across every tile
-      constexpr size_t OFF_D = (sizeof(MarchArgs) + alignof(DecoderDev) - 1) / alignof(DecoderDev) * alignof(DecoderDev);
-      constexpr size_t OFF_D16 = (OFF_D + sizeof(DecoderDev) + alignof(DecoderDev16) - 1) / alignof(DecoderDev16) * alignof(DecoderDev16);
+      constexpr size_t OFF_D = KERNARG_OFF_D, OFF_D16 = KERNARG_OFF_D16;
       tail_slot<KEEP>(kernarg_ref<MarchArgs>(0), kernarg_ref<DecoderDev>(OFF_D), kernarg_ref<DecoderDev16>(OFF_D16), S, ctl, P, xc, vt + zero, k, cl,
                       ((mode == OWN) ? member : 0) + zero, P.sticky && vt < P.ntiles, mode == SCAN);
       if (mode == OWN) cur = (P.cl > 1) ? slots : cur + nwg;
@@ -2254,7 +2273,7 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V0, const float* g_zdepth
       }
       const bool fine_row = src_level(src) == 0;
       sm.flags = (fine_row && !grad_camera && V.cfg.marcher != DISTR_MARCH_TRIVIAL) ? 0 : 1;
-      samples[wbase + __popcll(ball & ((1ull << lane) - 1ull))] = sm;
+      samples[wbase + ballot_rank(ball)] = sm;
     }
     base += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
   }

@@ -788,7 +788,16 @@ struct Smem16CL : Smem16 {
   float sst[4][16];       // k_tail's per-step tiles: the rays' m, init_now, maxbound, minabs between a tile's prologue and its epilogue (with sk / ssl)
 };
 
-using Smem16CLX = Smem16CL;      // (cluster tiles need no landing zone in LDS: the granule requests land in fixed registers)
+// ... where cluster tiles can occur (MODE_FINE / MODE_COARSE kernels: one workgroup per compute unit). The granule requests land in fixed
+// registers, not here; what IS here since round 6: lin0's operands of a STICKY tile. A sticky tile evaluates the decoder ~70 times in a row
+// with the same latent constants and the same lin0 weights; fetched from global memory each time, lin0's compiler-issued loads sit in the
+// wave's in-order memory queue BEHIND the three weight chunks of lin1 requested just before (the compiler's vmcnt wait for them drains
+// the whole queue): every step started with ~1 us of waiting for lin1's weights before lin0's first MFMA. From LDS lin0 needs no vector
+// memory operation at all and runs while the ring fills.
+struct Smem16CLX : Smem16CL {
+  float c0s[HID];          // c0 = b0 + W0[:, :256] latent (this view's)
+  f32x4 w0s[4][8][64];     // lin0's A-fragments: [wave][row block][lane] = what dense16<16, 8> loads from DecoderDev16::Wf[0]
+};
 
 struct DecoderDev16 {
   const float* Wf[8];   // 16x16x4 A-fragments: float4 ((g*4 + w)*NB + ob)*64 + lane = { W[w*16*NB + 16*ob + i][16g + 4s + kq] : s=0..3 }
@@ -832,6 +841,22 @@ __device__ __forceinline__ void dense16(const float* __restrict__ Wp, const floa
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[s] = bn[s];
   }
+}
+
+// lin0 (K = 16: one k-group) of a sticky tile with the A-fragments in LDS (Smem16CLX::w0s): the same MFMAs in the same order as
+// dense16<16, 8> -- k-step s outer, row block inner; each accumulator's chain is k-ordered -- without a vector memory operation
+__device__ __forceinline__ void dense16_lin0_lds(const f32x4 (&w0)[8][64], const float* X, f32x4 (&acc)[8], int lane) {
+  f32x4 a[8];
+  float b[4];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) a[ob] = w0[ob][lane];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) b[s] = X[lane + 4 * s * 16];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][s], b[s], acc[ob], 0, 0, 0);
 }
 
 // relu + write back; nib (KEEP): bit (4*ob + r) = output (ob, r) > 0
@@ -1101,8 +1126,11 @@ constexpr int CL_AHEAD = 3;   // chunks in flight (ring of CL_AHEAD + 1 buffers)
 #define CL_CLOB4 "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 #define CL_CLOB2 "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 // one statement, clobber list by cluster size (the fixed range is smaller for larger clusters: fewer row blocks per wave)
-#define CL_ASM(CL, ...) do { if constexpr ((CL) == 8) asm volatile(__VA_ARGS__, CL_CLOB8); else if constexpr ((CL) == 4) asm volatile(__VA_ARGS__, CL_CLOB4); \
-                             else asm volatile(__VA_ARGS__, CL_CLOB2); } while (0)
+// (every statement opens with a comment naming its cluster size: profiles/tools/check_fixed_regs.py takes the fixed range that holds around a
+// compiler instruction from the nearest statement's tag)
+#define CL_ASM(CL, ...) do { if constexpr ((CL) == 8) asm volatile("; distr-cl 8\n\t" __VA_ARGS__, CL_CLOB8); \
+                             else if constexpr ((CL) == 4) asm volatile("; distr-cl 4\n\t" __VA_ARGS__, CL_CLOB4); \
+                             else asm volatile("; distr-cl 2\n\t" __VA_ARGS__, CL_CLOB2); } while (0)
 // Fixed registers of a cluster of CL members (NBLM = row blocks per wave of a 512-row layer = 8 / CL):
 //   accumulator set p (= layer & 1), row block ob, register r:   a[ACC0 + 4 NBLM p + 4 ob + r]        2 x 4 NBLM registers, top of the file
 //   weight ring: chunk slot r, float4 i, element s:              a[RING0 + 32 r + 4 i + s]            128 registers below them
@@ -2008,7 +2036,7 @@ __device__ __forceinline__ bool layer_cl(const float* __restrict__ Wf, const flo
 template <int CL, bool KEEP, bool ALL_LIN8 = false, bool MASK_OWN = false>
 __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const DecoderDev16& D16, const float* __restrict__ c0,
                                                   const float* __restrict__ c4, Smem16CLX& S, const Xchg& xc, int cluster, int member,
-                                                  bool assemble = true, int32_t abort_lane = 0) {
+                                                  bool assemble = true, int32_t abort_lane = 0, bool lin0_lds = false) {
   const int tid = cl_tid();
   const int wave = cl_wave(tid);
   const int lane = tid & 63;
@@ -2045,9 +2073,15 @@ __device__ __forceinline__ float mlp_forward16_cl(const DecoderDev& D, const Dec
   __syncthreads();
   {  // lin0 (K = 16 padded): cheaper to compute whole in every member than to exchange
     f32x4 acc[8];
-    acc_init16<8>(acc, c0, wave * 128, kq);
+    if (lin0_lds) {          // sticky tiles: latent constants and lin0 fragments from LDS (Smem16CLX, filled once per tile)
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) acc[ob] = *reinterpret_cast<const f32x4*>(&S.c0s[wave * 128 + 16 * ob + 4 * kq]);
+    } else {
+      acc_init16<8>(acc, c0, wave * 128, kq);
+    }
     CL_ASM(CL, "" ::: "memory");        // (lin0's accumulators live across this point: not in the fixed registers the ring is landing in)
-    dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
+    if (lin0_lds) dense16_lin0_lds(S.w0s[wave], X, acc, lane);
+    else dense16<16, 8>(D16.Wf[0], X, acc, wave, lane);
     CL_ASM(CL, "" ::: "memory");
     __syncthreads();
     (void)writeback16<8, false>(X, acc, wave * 128, lane);

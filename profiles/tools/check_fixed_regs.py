@@ -26,11 +26,20 @@ def main(argv=None):
     # statements that name fixed registers (hex register indices only come from the "n" operands of those asm statements)
     asm_lines = [i for i in range(start, end) if re.search(r'\b[av]\[0x', lines[i])]
     lo, hi = min(asm_lines), max(asm_lines)
-    # cluster size of the code around a line, from the accumulator base of the nearest MFMA statement: a[0xf8..] 8, a[0xf0..] 4, a[0xe0..] 2
-    mf = [(i, int(re.search(r'v_mfma\S+ a\[0x([0-9a-f]+)', lines[i]).group(1), 16)) for i in asm_lines if 'v_mfma' in lines[i]]
+    # cluster size of the code around a line: the tag ("; distr-cl N", first line of every CL_ASM statement) of the NEAREST fixed-register
+    # statement on either side (round 6: the accumulator base of the previous MFMA statement mis-classified the prologue of a 2-member
+    # instance laid out behind an 8-member one); without tags (older .s files) the accumulator base of the previous MFMA statement
     import bisect
+    tags = [(i, int(re.search(r'distr-cl (\d)', lines[i]).group(1))) for i in range(start, end) if '; distr-cl ' in lines[i]]
+    tag_idx = [t[0] for t in tags]
+    mf = [(i, int(re.search(r'v_mfma\S+ a\[0x([0-9a-f]+)', lines[i]).group(1), 16)) for i in asm_lines if 'v_mfma' in lines[i]]
     mf_idx = [m[0] for m in mf]
     def a_limit(i):
+        if tags:
+            k = bisect.bisect_left(tag_idx, i)
+            cand = [tags[j] for j in (k - 1, k) if 0 <= j < len(tags)]
+            cl = min(cand, key=lambda t: abs(t[0] - i))[1]
+            return {8: 120, 4: 112, 2: 96}[cl]
         k = bisect.bisect_right(mf_idx, i) - 1
         base = mf[max(k, 0)][1]
         return {0xf8: 120, 0xfc: 120, 0xf0: 112, 0xe0: 96}.get(base & ~7 if base >= 0xf8 else base & ~15, a_lo)
