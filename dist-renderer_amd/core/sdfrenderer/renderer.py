@@ -57,8 +57,14 @@ class SDFRenderer(object):
         self.threshold = threshold
         self.scale_list = list(scale_list)
         self.march_step_list = list(march_step_list)
-        if list(self.scale_list) != [4, 2, 1] or len(self.march_step_list) != 3:
-            raise NotImplementedError('only the 3-level pyramid scale_list=[4,2,1] is implemented')
+        # pyramids built here: the reference's default [4, 2, 1] and the two-level [2, 1] (renderer.py:731-753 takes any list ending in 1;
+        # every driver of the reference constructs the renderer with the default). One march_step_list entry per level, the last may be -1.
+        if list(self.scale_list) not in ([4, 2, 1], [2, 1]) or len(self.march_step_list) != len(self.scale_list):
+            raise NotImplementedError('pyramid scale_list=%r / march_step_list=%r: only [4,2,1] and [2,1] (one step count per level) are implemented'
+                                      % (self.scale_list, self.march_step_list))
+        if any(int(v) < 1 for v in self.march_step_list[:-1]):
+            raise ValueError('march_step_list %r: every coarse level needs at least one step (renderer.py:765: ray_marching_trivial with 0 steps '
+                             'concatenates an empty list)' % (self.march_step_list,))
         if isinstance(intrinsic, torch.Tensor):
             intrinsic = intrinsic.detach().cpu().numpy()
         self.intrinsic = intrinsic
@@ -151,9 +157,12 @@ class SDFRenderer(object):
     def _cfg(self, clamp_dist, ray_marching_type, use_transform, want_normal, normalize_normal=True,
              no_grad_depth=False, no_grad_mask=False, no_grad_camera=False):
         msl = list(self.march_step_list)
-        return binding.make_cfg(self.img_hw, self.intrinsic, march_step=self.march_step, buffer_size=self.buffer_size,
+        march_step = self.march_step
+        if ray_marching_type == 'pyramid_recursive' and int(msl[-1]) != -1:
+            march_step = int(sum(msl))        # an explicit last entry is the full-resolution step count (renderer.py:724-725 only fills in a -1)
+        return binding.make_cfg(self.img_hw, self.intrinsic, march_step=march_step, buffer_size=self.buffer_size,
                                 ratio=self.ray_marching_ratio, threshold=self.threshold, radius=self.radius,
-                                clamp_dist=clamp_dist, marcher=ray_marching_type, coarse_steps=(msl[0], msl[1]),
+                                clamp_dist=clamp_dist, marcher=ray_marching_type, coarse_steps=(msl[0], msl[1] if len(msl) == 3 else 0),
                                 transform_matrix=self._M_np, use_transform=use_transform,
                                 use_depth2normal=self.use_depth2normal, normalize_normal=normalize_normal,
                                 want_normal=want_normal, grad_depth=not no_grad_depth, grad_mask=not no_grad_mask,

@@ -225,7 +225,9 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
   int fine = c->march_step;
   if (c->marcher == DISTR_MARCH_PYRAMID_RECURSIVE) {
-    if (c->coarse_steps[0] < 1 || c->coarse_steps[1] < 1) return fail(ctx, DISTR_ERR_UNSUPPORTED, "pyramid needs >=1 step per coarse level");
+    // coarse_steps[1] == 0: the two-level pyramid scale_list=[2,1] (coarse_steps[0] steps at half resolution); a level with no steps
+    // does not exist in the reference (ray_marching_trivial concatenates an empty list)
+    if (c->coarse_steps[0] < 1 || c->coarse_steps[1] < 0) return fail(ctx, DISTR_ERR_UNSUPPORTED, "pyramid needs >=1 step per coarse level");
     if (c->coarse_steps[0] > 15 || c->coarse_steps[1] > 15) return fail(ctx, DISTR_ERR_UNSUPPORTED, "at most 15 steps per coarse level");
     fine -= c->coarse_steps[0] + c->coarse_steps[1];
   }
@@ -360,7 +362,7 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
   V.band = (V.rows != c.H) ? 1 : 0;
   V.P = V.rows * c.W;
   V.pyramid = (c.marcher == DISTR_MARCH_PYRAMID_RECURSIVE) ? 1 : 0;
-  V.nlev = V.pyramid ? 3 : 1;
+  V.nlev = V.pyramid ? (c.coarse_steps[1] == 0 ? 2 : 3) : 1;      // scale_list [4,2,1] / [2,1] (coarse_steps = march_step_list[0:nlev-1], 0-padded)
   V.fine_steps = c.march_step - (V.pyramid ? c.coarse_steps[0] + c.coarse_steps[1] : 0);
   V.C = cv.take<Consts>(1);
   V.lv[0].h = V.rows; V.lv[0].w = c.W; V.lv[0].scale = 1.f; V.lv[0].off = 0.f;

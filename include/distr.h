@@ -100,7 +100,8 @@ typedef struct distr_render_cfg {
   float radius;               /* renderer.py:23  */
   float clamp_dist;           /* clamp_dist kwarg of render()                               renderer.py:943 */
   int32_t marcher;            /* DISTR_MARCH_*   ray_marching_type                          renderer.py:807-834 */
-  int32_t coarse_steps[2];    /* march_step_list[0:2] for scale_list=[4,2,1]                renderer.py:25-26, 724-725 */
+  int32_t coarse_steps[2];    /* march_step_list[0:2] for scale_list=[4,2,1]; {s, 0}: scale_list=[2,1] with march_step_list=[s,-1]
+                                 (steps of the coarse levels, coarsest first, 0 = no such level) renderer.py:25-26, 724-765 */
   int32_t use_depth2normal;   /* renderer.py:22, 972-975 */
   int32_t normalize_normal;   /* normalize_normal kwarg                                     renderer.py:898-901 */
   int32_t want_normal;        /* 0: render_depth() only (no depth/normal image outputs) */

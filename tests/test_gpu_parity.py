@@ -271,6 +271,8 @@ SWEEP = [
     (40, 40, 18, 5, 1.0, 'trivial', True, (-60, 30, 1.5, 0), {}),
     (50, 70, 30, 8, 1.5, 'pyramid_recursive', False, (0, 0, 1.6, 0), {}),
     (64, 48, 25, 3, 2.0, 'pyramid_recursive', True, (100, 45, 1.4, -20), dict(coarse_steps=(2, 4))),
+    (45, 59, 22, 3, 1.5, 'pyramid_recursive', True, (-40, 15, 1.5, 12), dict(coarse_steps=(3, 0))),        # two levels: scale_list=[2, 1] (G28)
+    (31, 33, 40, 5, 1.0, 'pyramid_recursive', False, (70, -25, 1.8, 0), dict(coarse_steps=(1, 0))),
     (36, 36, 16, 3, 1.5, 'recursive', False, (20, 10, 1.6, 0), dict(use_transform=False)),
     (36, 36, 16, 3, 1.5, 'pyramid_recursive', False, (20, 10, 1.6, 0), dict(grad_camera=False)),
     (36, 36, 16, 3, 1.5, 'recursive', True, (20, 10, 1.6, 0), dict(grad_depth=False)),
@@ -1778,6 +1780,48 @@ def test_multiscale_shape_loop_matches_reference_golden(fixture_decoder):
     opt2 = torch.optim.Adam([lat2], lr=float(g['lr']))
     optimize_single_view(rs, None, opt2, lat2, RT, gt_pack, wd, optimizer_type='shape', num_iters=int(g['iters']), renderer_weights=[1.0, 1.0, 1.0], silent=True, streams=0)
     assert torch.equal(lat2.detach(), lat.detach())
+
+
+@pytest.mark.gpu
+def test_two_level_pyramid_matches_reference_golden(fixture_decoder):
+    """G28 through the drop-in class with the reference's own keywords: SDFRenderer(scale_list=[2, 1], march_step_list=[s, -1]) on an odd-sized
+    image, fixtures F1 and F2, and an explicit last march_step_list entry (renderer.py:713-805, 724-725), against the reference's outputs
+    and gradients at G24's bars; other pyramids stay rejected at construction."""
+    import torch
+    import test_oracle_vs_golden as tg
+    from core.sdfrenderer import SDFRenderer
+    from distr import fixture
+    g = np.load(os.path.join(GOLDEN, 'g28_two_level_pyramid.npz'))
+    H, W = int(g['H']), int(g['W'])
+    cases = {
+        'two_level_3': ('f1', dict(scale_list=[2, 1], march_step_list=[3, -1])),
+        'two_level_6_d2n': ('f1', dict(scale_list=[2, 1], march_step_list=[6, -1], use_depth2normal=True)),
+        'two_level_explicit_2_20': ('f1', dict(scale_list=[2, 1], march_step_list=[2, 20], march_step=50)),
+        'two_level_3_f2': ('f2', dict(scale_list=[2, 1], march_step_list=[3, -1])),
+    }
+    assert sorted(cases) == sorted(str(n) for n in g['names'])
+    wd, wq, wn = (torch.from_numpy(a).cuda() for a in helpers.loss_weights(H, W, 5))
+    decs = {'f1': _plain_decoder(fixture_decoder), 'f2': _plain_decoder(fixture.load_fixture_f2())}
+    for name, (fx, ckw) in sorted(cases.items()):
+        kw = dict(march_step=int(g['march_step']), buffer_size=3, ray_marching_ratio=1.5, use_depth2normal=False)
+        kw.update(ckw)
+        r = SDFRenderer(decs[fx], g['K'], img_hw=(H, W), **kw)
+        lat = torch.from_numpy(g[fx + '.latent']).cuda().requires_grad_(True)
+        Rt, Tt = torch.from_numpy(g['R']).cuda().requires_grad_(True), torch.from_numpy(g['T']).cuda().requires_grad_(True)
+        depth, normal, mask, mq = r.render(lat, Rt, Tt)
+        L = (depth * wd)[mask.bool()].sum() + (mq * wq).sum() + (normal * wn).sum()
+        L.backward()
+        a = dict(mask=mask.cpu().numpy(), depth=depth.detach().cpu().numpy(), normal=normal.detach().cpu().numpy(), min_sdf=mq.detach().cpu().numpy(),
+                 g_latent=lat.grad.cpu().numpy(), g_R=Rt.grad.cpu().numpy(), g_T=Tt.grad.cpu().numpy())
+        res = tg.check_g24(a, g, name)
+        assert abs(float(L.detach()) - float(g[name + '.loss'])) <= 5e-5 * abs(float(g[name + '.loss'])), (name, float(L.detach()), float(g[name + '.loss']))
+        print('G28', name, {k: '%.1e' % v for k, v in res.items()})
+    for bad in (dict(scale_list=[8, 4, 2, 1], march_step_list=[2, 2, 2, -1]), dict(scale_list=[3, 1], march_step_list=[3, -1]),
+                dict(scale_list=[2, 1], march_step_list=[3, 3, -1])):
+        with pytest.raises(NotImplementedError):
+            SDFRenderer(decs['f1'], g['K'], img_hw=(H, W), **bad)
+    with pytest.raises(ValueError):
+        SDFRenderer(decs['f1'], g['K'], img_hw=(H, W), scale_list=[2, 1], march_step_list=[0, -1])
 
 
 @pytest.mark.gpu

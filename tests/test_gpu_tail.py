@@ -119,6 +119,23 @@ def test_tail_hint_moves_the_launch_to_the_sticky_regime(fixture_decoder, per_st
     assert _same(a, b) == []
 
 
+def test_two_level_pyramid_through_the_tail_launch(fixture_decoder, per_step_engine, cpu_oracle, orc):
+    """scale_list=[2, 1] (coarse_steps = (s, 0), golden G28): the half-resolution level feeds the full-resolution march directly; the tail
+    launch from step 0 and from step 7 = the launch-per-step render byte for byte, and both match the oracle."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    H, W = 61, 75
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-20, 25, 1.6, 5)
+    kw = dict(march_step=60, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True, ratio=1.5, coarse_steps=(4, 0))
+    b = helpers.hip_render(per_step_engine, H, W, K, R, T, latent, **kw)
+    for frm in (0, 7):
+        a = helpers.hip_render(_engine(fixture_decoder, DISTR_TAIL_FROM=frm), H, W, K, R, T, latent, **kw)
+        assert _same(a, b) == [], (frm, _same(a, b))
+    o = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    print(helpers.compare(b, o, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4))
+
+
 @pytest.mark.parametrize('absent', [1, 8, 37, 200])
 def test_tail_tiles_of_absent_workgroups_are_taken_over(fixture_decoder, per_step_engine, absent):
     """Co-residency of the tail launch's 256 workgroups is not promised by the hardware. DISTR_TAIL_TEST_ABSENT=n makes the first n leave

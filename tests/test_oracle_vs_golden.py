@@ -397,6 +397,33 @@ def test_oracle_renderer_options_match_reference_golden(cpu_oracle, name):
     print(name, check_g24(b, g, name))
 
 
+# G28 cases as cfg keyword arguments (oracle/gen_golden_pyramid2.py::CASES): coarse_steps = (s, 0) is the two-level pyramid scale_list=[2, 1]
+G28_CFG = {
+    'two_level_3': ('f1', dict(coarse_steps=(3, 0))),
+    'two_level_6_d2n': ('f1', dict(coarse_steps=(6, 0), use_depth2normal=True)),
+    'two_level_explicit_2_20': ('f1', dict(coarse_steps=(2, 0), march_step=22)),
+    'two_level_3_f2': ('f2', dict(coarse_steps=(3, 0))),
+}
+
+
+@pytest.mark.parametrize('name', sorted(G28_CFG))
+def test_oracle_two_level_pyramid_matches_reference_golden(name):
+    """G28 (oracle/gen_golden_pyramid2.py): ray_marching_pyramid_recursive with scale_list=[2, 1] (renderer.py:713-805 builds one level per
+    entry) rendered by the reference itself on an odd-sized image, fixtures F1 and F2; an explicit last march_step_list entry. Same
+    bars as G24 (the reference's own floors are in the golden)."""
+    import helpers
+    from distr import fixture
+    g = np.load(os.path.join(GOLDEN, 'g28_two_level_pyramid.npz'))
+    fx, ckw = G28_CFG[name]
+    Ws, bs, latent = fixture.make_decoder_weights() if fx == 'f1' else fixture.load_fixture_f2()
+    assert fixture.weights_sha256(Ws, bs) == str(g[fx + '.weights_sha256'])
+    H, W = int(g['H']), int(g['W'])
+    kw = dict(march_step=int(g['march_step']), buffer_size=3, ratio=1.5, marcher='pyramid_recursive', use_depth2normal=False)
+    kw.update(ckw)
+    b = helpers.oracle_render(orc.Oracle(Ws, bs), orc, H, W, g['K'], g['R'], g['T'], g[fx + '.latent'], **kw)
+    print(name, check_g24(b, g, name))
+
+
 G25_RUNS = [(n, m, d) for n in ('away', 'far', 'inside', 'nosurf') for (m, d) in (('recursive', False), ('pyramid_recursive', False), ('pyramid_recursive', True))]
 
 
