@@ -57,11 +57,15 @@ class SDFRenderer(object):
         self.threshold = threshold
         self.scale_list = list(scale_list)
         self.march_step_list = list(march_step_list)
-        # pyramids built here: the reference's default [4, 2, 1] and the two-level [2, 1] (renderer.py:731-753 takes any list ending in 1;
-        # every driver of the reference constructs the renderer with the default). One march_step_list entry per level, the last may be -1.
-        if list(self.scale_list) not in ([4, 2, 1], [2, 1]) or len(self.march_step_list) != len(self.scale_list):
-            raise NotImplementedError('pyramid scale_list=%r / march_step_list=%r: only [4,2,1] and [2,1] (one step count per level) are implemented'
-                                      % (self.scale_list, self.march_step_list))
+        # pyramids built here (renderer.py:731-753 builds one level per scale_list entry): 2..4 levels, integer scales ending in 1, every
+        # scale a 2..8-fold multiple of the next (the `scale` of get_downscaled_grid_map, :604-629), one march_step_list entry per level
+        # (the last may be -1). Fractional ratios ([3, 2, 1]) and more levels are not built.
+        sl = self.scale_list
+        ok = 2 <= len(sl) <= 4 and len(self.march_step_list) == len(sl) and all(float(v) == int(v) and int(v) >= 1 for v in sl) and int(sl[-1]) == 1 \
+            and all(int(a) % int(b) == 0 and 2 <= int(a) // int(b) <= 8 for a, b in zip(sl[:-1], sl[1:]))
+        if not ok:
+            raise NotImplementedError('pyramid scale_list=%r / march_step_list=%r: implemented are 2..4 integer scales ending in 1, each a 2..8-fold '
+                                      'multiple of the next, with one step count per level' % (self.scale_list, self.march_step_list))
         if any(int(v) < 1 for v in self.march_step_list[:-1]):
             raise ValueError('march_step_list %r: every coarse level needs at least one step (renderer.py:765: ray_marching_trivial with 0 steps '
                              'concatenates an empty list)' % (self.march_step_list,))
@@ -160,13 +164,16 @@ class SDFRenderer(object):
         march_step = self.march_step
         if ray_marching_type == 'pyramid_recursive' and int(msl[-1]) != -1:
             march_step = int(sum(msl))        # an explicit last entry is the full-resolution step count (renderer.py:724-725 only fills in a -1)
+        general = {}
+        if [int(v) for v in self.scale_list] not in ([4, 2, 1], [2, 1]):       # (the default pyramids travel as coarse_steps, include/distr.h)
+            general = dict(scale_list=[int(v) for v in self.scale_list], march_step_list=[int(v) for v in msl])
         return binding.make_cfg(self.img_hw, self.intrinsic, march_step=march_step, buffer_size=self.buffer_size,
                                 ratio=self.ray_marching_ratio, threshold=self.threshold, radius=self.radius,
                                 clamp_dist=clamp_dist, marcher=ray_marching_type, coarse_steps=(msl[0], msl[1] if len(msl) == 3 else 0),
                                 transform_matrix=self._M_np, use_transform=use_transform,
                                 use_depth2normal=self.use_depth2normal, normalize_normal=normalize_normal,
                                 want_normal=want_normal, grad_depth=not no_grad_depth, grad_mask=not no_grad_mask,
-                                grad_camera=not no_grad_camera, arith=self.arith)
+                                grad_camera=not no_grad_camera, arith=self.arith, **general)
 
     @staticmethod
     def _check_marcher(ray_marching_type):

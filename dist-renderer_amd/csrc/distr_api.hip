@@ -68,7 +68,7 @@ struct distr_ctx {
   int tail_rays = 640;          // DISTR_TAIL_RAYS
   int tail_force = -1;          // DISTR_TAIL_FROM=n (tests): tail_from = n for every render of the recursive marchers
   int tail_absent = 0;          // DISTR_TAIL_TEST_ABSENT=n (tests): the first n workgroups of the tail launch leave at once (never resident)
-  struct TailHint { int32_t key[10]; bool used = false; uint64_t last_use = 0; };
+  struct TailHint { int32_t key[16]; bool used = false; uint64_t last_use = 0; };
   static constexpr int NHINT = 16;
   TailHint hints[NHINT];
   int32_t* hint_host = nullptr; // NHINT host-mapped words (hipHostMalloc): -1 = nothing written yet
@@ -215,6 +215,37 @@ struct Carver {
   }
 };
 
+// The pyramid of a cfg, finest level first (index = LevelView index): scale[0] = 1, steps[l] = dense steps of coarse level l.
+// distr_render_cfg::num_levels == 0: the default scale_list [4,2,1] ([2,1] with coarse_steps = {s, 0}) described by coarse_steps;
+// else level_scale / level_steps (coarsest first, like scale_list / march_step_list of renderer.py:25-26). Returns why not, or null.
+struct Pyramid { int nlev; int scale[MAX_LEVELS]; int steps[MAX_LEVELS]; };
+const char* pyramid_of(const distr_render_cfg& c, Pyramid& p) {
+  memset(&p, 0, sizeof(p));
+  p.nlev = 1; p.scale[0] = 1;
+  if (c.marcher != DISTR_MARCH_PYRAMID_RECURSIVE) return nullptr;
+  if (c.num_levels == 0) {
+    // coarse_steps[1] == 0: the two-level pyramid scale_list=[2,1] (coarse_steps[0] steps at half resolution); a level with no steps
+    // does not exist in the reference (ray_marching_trivial concatenates an empty list)
+    if (c.coarse_steps[0] < 1 || c.coarse_steps[1] < 0) return "pyramid needs >=1 step per coarse level";
+    p.nlev = (c.coarse_steps[1] == 0) ? 2 : 3;
+    for (int l = 1; l < p.nlev; ++l) { p.scale[l] = 1 << l; p.steps[l] = c.coarse_steps[p.nlev - 1 - l]; }
+  } else {
+    if (c.num_levels < 2 || c.num_levels > MAX_LEVELS) return "num_levels must be 0 (coarse_steps) or 2..4";
+    p.nlev = c.num_levels;
+    for (int l = 0; l < p.nlev; ++l) { p.scale[l] = c.level_scale[p.nlev - 1 - l]; p.steps[l] = l ? c.level_steps[p.nlev - 1 - l] : 0; }
+    if (p.scale[0] != 1) return "the last entry of level_scale (scale_list) must be 1 (renderer.py:726)";
+    for (int l = 1; l < p.nlev; ++l) {
+      if (p.scale[l] <= p.scale[l - 1] || p.scale[l] % p.scale[l - 1] != 0 || p.scale[l] / p.scale[l - 1] > 8)
+        return "level_scale: every scale must be an integer multiple (2..8 x) of the next finer one";
+    }
+  }
+  for (int l = 1; l < p.nlev; ++l) {
+    if (p.steps[l] < 1) return "pyramid needs >=1 step per coarse level";
+    if (p.steps[l] > 15) return "at most 15 steps per coarse level";
+  }
+  return nullptr;
+}
+
 int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (!c) return fail(ctx, DISTR_ERR_INVALID_ARG, "cfg is null");
   if (c->struct_size != sizeof(distr_render_cfg))      // ABI handshake (include/distr.h): a caller built against another header
@@ -225,11 +256,11 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
   int fine = c->march_step;
   if (c->marcher == DISTR_MARCH_PYRAMID_RECURSIVE) {
-    // coarse_steps[1] == 0: the two-level pyramid scale_list=[2,1] (coarse_steps[0] steps at half resolution); a level with no steps
-    // does not exist in the reference (ray_marching_trivial concatenates an empty list)
-    if (c->coarse_steps[0] < 1 || c->coarse_steps[1] < 0) return fail(ctx, DISTR_ERR_UNSUPPORTED, "pyramid needs >=1 step per coarse level");
-    if (c->coarse_steps[0] > 15 || c->coarse_steps[1] > 15) return fail(ctx, DISTR_ERR_UNSUPPORTED, "at most 15 steps per coarse level");
-    fine -= c->coarse_steps[0] + c->coarse_steps[1];
+    Pyramid py;
+    if (const char* why = pyramid_of(*c, py)) return fail(ctx, DISTR_ERR_UNSUPPORTED, "%s", why);
+    for (int l = 1; l < py.nlev; ++l) fine -= py.steps[l];
+    if (c->rows != 0 && c->rows != c->H && 4 % py.scale[py.nlev - 1] != 0)
+      return fail(ctx, DISTR_ERR_UNSUPPORTED, "row bands (row0 a multiple of 4) need a pyramid whose coarsest scale divides 4");
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
   if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
@@ -331,7 +362,10 @@ int32_t* tail_hint_slot(distr_ctx* ctx, const distr_render_cfg& c, int nviews, b
     ctx->hint_host = (int32_t*)h; ctx->hint_dev = (int32_t*)d;
     for (int i = 0; i < distr_ctx::NHINT; ++i) ctx->hint_host[i] = -1;
   }
-  const int32_t key[10] = {c.H, c.W, c.row0, c.rows, c.march_step, c.coarse_steps[0], c.coarse_steps[1], c.marcher, c.buffer_size, nviews};
+  Pyramid py;
+  (void)pyramid_of(c, py);
+  const int32_t key[16] = {c.H, c.W, c.row0, c.rows, c.march_step, c.marcher, c.buffer_size, nviews, py.nlev, py.scale[1], py.scale[2], py.scale[3],
+                           py.steps[1], py.steps[2], py.steps[3], 0};
   static uint64_t clock = 0;
   int lru = 0;
   for (int i = 0; i < distr_ctx::NHINT; ++i) {
@@ -362,23 +396,28 @@ size_t make_view(const distr_render_cfg& c, void* base, View& V, bool save_masks
   V.band = (V.rows != c.H) ? 1 : 0;
   V.P = V.rows * c.W;
   V.pyramid = (c.marcher == DISTR_MARCH_PYRAMID_RECURSIVE) ? 1 : 0;
-  V.nlev = V.pyramid ? (c.coarse_steps[1] == 0 ? 2 : 3) : 1;      // scale_list [4,2,1] / [2,1] (coarse_steps = march_step_list[0:nlev-1], 0-padded)
-  V.fine_steps = c.march_step - (V.pyramid ? c.coarse_steps[0] + c.coarse_steps[1] : 0);
+  Pyramid py;
+  (void)pyramid_of(c, py);             // (check_cfg has accepted it)
+  V.nlev = py.nlev;
+  V.fine_steps = c.march_step;
+  for (int l = 1; l < V.nlev; ++l) V.fine_steps -= py.steps[l];
   V.C = cv.take<Consts>(1);
   V.lv[0].h = V.rows; V.lv[0].w = c.W; V.lv[0].scale = 1.f; V.lv[0].off = 0.f;
-  V.lv[0].y0 = V.row0; V.lv[0].full_h = c.H;
-  for (int l = 1; l < V.nlev; ++l) {
-    V.lv[l].h = (V.lv[l - 1].h + 1) / 2;
-    V.lv[l].w = (V.lv[l - 1].w + 1) / 2;
-    V.lv[l].y0 = V.lv[l - 1].y0 / 2;                 // row0 is a multiple of 4: exact
-    V.lv[l].full_h = (V.lv[l - 1].full_h + 1) / 2;
-    V.lv[l].scale = V.lv[l - 1].scale * 2.f;
+  V.lv[0].y0 = V.row0; V.lv[0].full_h = c.H; V.lv[0].rdiv = 1; V.lv[0].sdiv = 1;
+  for (int l = 1; l < V.nlev; ++l) {     // get_downscaled_grid_map (renderer.py:604-629): ceil(h / ratio) cells, centres scale * i + (scale - 1) / 2
+    const int r = py.scale[l] / py.scale[l - 1];
+    V.lv[l].rdiv = r; V.lv[l].sdiv = py.scale[l];
+    V.lv[l].h = (V.lv[l - 1].h + r - 1) / r;
+    V.lv[l].w = (V.lv[l - 1].w + r - 1) / r;
+    V.lv[l].y0 = V.lv[l - 1].y0 / r;                 // a band's row0 is a multiple of the coarsest scale: exact
+    V.lv[l].full_h = (V.lv[l - 1].full_h + r - 1) / r;
+    V.lv[l].scale = (float)py.scale[l];
     V.lv[l].off = (V.lv[l].scale - 1.f) / 2.f;
   }
   for (int l = 0; l < V.nlev; ++l) {
     LevelView& L = V.lv[l];
     L.n = L.h * L.w;
-    L.steps = (l == 0) ? 0 : c.coarse_steps[V.nlev - 1 - l];
+    L.steps = py.steps[l];
     L.valid = cv.take<uint8_t>(L.n);
     L.list = cv.take<int32_t>(L.n);
     if (l > 0) {
@@ -451,7 +490,7 @@ struct MarchTimer {  // optional hipEvent bracket around the march kernel launch
 
 extern "C" {
 
-const char* distr_version(void) { return "distr 0.5 (ABI 5; gfx950, f32 MFMA)"; }
+const char* distr_version(void) { return "distr 0.6 (ABI 6; gfx950, f32 MFMA)"; }
 
 uint32_t distr_abi_version(void) { return DISTR_ABI_VERSION; }
 

@@ -19,6 +19,7 @@
 namespace distr {
 
 constexpr int MAX_BS = DISTR_MAX_BUFFER_SIZE;
+constexpr int MAX_LEVELS = DISTR_MAX_PYRAMID_LEVELS;     // levels of the pyramid marcher (renderer.py:713-805: one per scale_list entry)
 constexpr int MAX_STEPS = 2048;
 constexpr int PSTRIDE = 1040;  // floats per backward tile partial: sd0[512] sd4[512] gR[9] gc[3] pad[4]
 
@@ -32,8 +33,8 @@ struct Consts {
   int32_t xchg_err;       // cluster tiles that fell back to the single-workgroup path (not assembled in time / barrier timeout); results stay exact
   float f_origin;         // f(0,0,0): sample point of padded history rows (renderer.py:539, 555)
   int32_t origin_done;    // f_origin has been evaluated (by the launch that turned sticky; else the last step evaluates it)
-  uint32_t maxinit_bits[3];
-  int32_t cnt_level[3];   // [0] rays hitting the sphere; [1],[2] valid pixels of the 1/2 and 1/4 grids
+  uint32_t maxinit_bits[MAX_LEVELS];
+  int32_t cnt_level[MAX_LEVELS];   // [0] rays hitting the sphere; [l] valid pixels of the coarse grid of level l
   int32_t cnt_valid;
   int32_t cnt_normal;
   int32_t cnt_samples;
@@ -56,6 +57,7 @@ struct LevelView {
   int32_t h, w, n, steps;
   int32_t y0, full_h;     // row band: first row of this level's grid in the full image's level grid; rows of the full grid
   float scale, off;       // pixel centre = scale*i + off  (renderer.py:616-617)
+  int32_t rdiv, sdiv;     // grid of this level = the next finer level's / rdiv (scale_list[l] / scale_list[l-1], renderer.py:739), = the full image's / sdiv
   uint8_t* valid;
   int32_t* list;
   float* cinit;           // start depth of this level
@@ -68,7 +70,7 @@ struct LevelView {
 struct View {
   distr_render_cfg cfg;
   Consts* C;
-  LevelView lv[3];
+  LevelView lv[MAX_LEVELS];
   int32_t nlev, P, fine_steps, pyramid;
   int32_t row0, rows, band;   // band: rows [row0, row0+rows) of cfg.H are rendered (band != 0: a proper sub-range)
   int32_t* live[2];
@@ -82,7 +84,7 @@ struct View {
   //   block = px*(bs+1) + slot                      rows of the full-resolution march
   //   block = mfine + moff[lvl] + step*n_lvl + ray  rows of the coarse pyramid levels
   uint4* mstore;
-  int64_t mfine, moff[3], morigin;   // morigin: block of f(origin) (sample point of padded rows)
+  int64_t mfine, moff[MAX_LEVELS], morigin;   // morigin: block of f(origin) (sample point of padded rows)
   int32_t save_masks;
   float *zdepth_s, *depth_pre, *nrm_t;
   uint8_t* mask_s;
@@ -109,7 +111,7 @@ __device__ __forceinline__ View view_at(const View& V0, int b) {
   const int64_t d = (int64_t)b * V0.vstride;
   adv(V.C, d);
 #pragma unroll
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < MAX_LEVELS; ++l) {
     adv(V.lv[l].valid, d); adv(V.lv[l].list, d); adv(V.lv[l].cinit, d); adv(V.lv[l].cm, d);
     adv(V.lv[l].rs, d); adv(V.lv[l].rzb, d); adv(V.lv[l].rza, d);
   }
@@ -126,15 +128,18 @@ __device__ __forceinline__ View view_at(const View& V0, int b) {
 // local copy (a dynamically indexed member array would force the whole struct into scratch memory)
 template <typename T>
 __device__ __forceinline__ T sel3(int l, T a0, T a1, T a2) { return l == 2 ? a2 : (l == 1 ? a1 : a0); }   // operands by VALUE (a ternary of lvalues selects addresses)
+template <typename T>
+__device__ __forceinline__ T sel4(int l, T a0, T a1, T a2, T a3) { return l == 3 ? a3 : (l == 2 ? a2 : (l == 1 ? a1 : a0)); }
+static_assert(MAX_LEVELS == 4, "sel4 / level_sel / moff_sel list the levels");
 __device__ __forceinline__ LevelView level_sel(const View& V, int l) {
   LevelView L;
-#define DISTR_LSEL(f) L.f = sel3(l, V.lv[0].f, V.lv[1].f, V.lv[2].f)
-  DISTR_LSEL(h); DISTR_LSEL(w); DISTR_LSEL(n); DISTR_LSEL(steps); DISTR_LSEL(y0); DISTR_LSEL(full_h); DISTR_LSEL(scale); DISTR_LSEL(off);
+#define DISTR_LSEL(f) L.f = sel4(l, V.lv[0].f, V.lv[1].f, V.lv[2].f, V.lv[3].f)
+  DISTR_LSEL(h); DISTR_LSEL(w); DISTR_LSEL(n); DISTR_LSEL(steps); DISTR_LSEL(y0); DISTR_LSEL(full_h); DISTR_LSEL(scale); DISTR_LSEL(off); DISTR_LSEL(rdiv); DISTR_LSEL(sdiv);
   DISTR_LSEL(valid); DISTR_LSEL(list); DISTR_LSEL(cinit); DISTR_LSEL(cm); DISTR_LSEL(rs); DISTR_LSEL(rzb); DISTR_LSEL(rza);
 #undef DISTR_LSEL
   return L;
 }
-__device__ __forceinline__ int64_t moff_sel(const View& V, int l) { return sel3<int64_t>(l, V.moff[0], V.moff[1], V.moff[2]); }
+__device__ __forceinline__ int64_t moff_sel(const View& V, int l) { return sel4<int64_t>(l, V.moff[0], V.moff[1], V.moff[2], V.moff[3]); }
 __device__ __forceinline__ int32_t* live_sel(const View& V, int i) { return sel3<int32_t*>(i & 1, V.live[0], V.live[1], V.live[1]); }
 
 // Virtual concatenation of the views' work lists: view b contributes its count c_b rounded up to a multiple of `g` (so that no
@@ -319,7 +324,7 @@ DISTR_GLOBAL void __launch_bounds__(256) k_prep(View V0, DecoderDev D, const flo
     for (int i = t; i < MAX_STEPS + 2; i += 256) { C->cnt_live[i] = 0; C->cnt_sticky[i] = 0; C->tail_sync[2 * i] = 0; C->tail_sync[2 * i + 1] = 0; }
     for (int i = t; i < PSTRIDE; i += 256) C->red[i] = 0.f;
     if (t < 12) C->cam_acc[t] = 0.f;
-    if (t < 3) { C->maxinit_bits[t] = 0u; C->cnt_level[t] = 0; }
+    if (t < MAX_LEVELS) { C->maxinit_bits[t] = 0u; C->cnt_level[t] = 0; }
     if (t == 0) {
       float c[3];
 #pragma unroll
@@ -355,7 +360,7 @@ DISTR_GLOBAL void __launch_bounds__(256) k_latent_consts(float* c0c4 /*[1024]*/,
 
 // ------------------------------------------------------------------------------------------ ray setup
 // get_intersections_with_unit_spheres (renderer.py:254-273) for one pyramid level; coarse masks are the OR of the
-// 2x2 children (maxpool_valid_mask_with_index / torch_scatter.scatter_max, renderer.py:668-680).
+// rdiv x rdiv children (maxpool_valid_mask_with_index / torch_scatter.scatter_max, renderer.py:668-680).
 DISTR_GLOBAL void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
   const View V = view_at(V0, blockIdx.y);
   const LevelView L = level_sel(V, lvl);
@@ -374,12 +379,10 @@ DISTR_GLOBAL void __launch_bounds__(256) k_setup_level(View V0, int lvl) {
       valid = s.in;
     } else {
       const LevelView F = level_sel(V, lvl - 1);
-      const int y = i / L.w, x = i % L.w;
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int fy = 2 * y + dy, fx = 2 * x + dx;
+      const int y = i / L.w, x = i % L.w, r = L.rdiv;
+      for (int dy = 0; dy < r; ++dy)
+        for (int dx = 0; dx < r; ++dx) {
+          const int fy = r * y + dy, fx = r * x + dx;
           if (fy < F.h && fx < F.w) valid = valid || (F.valid[fy * F.w + fx] != 0);
         }
     }
@@ -424,7 +427,7 @@ DISTR_GLOBAL void __launch_bounds__(256) k_coarse_init(View V0, int lvl) {
     init = inside ? 0.f : (s.in ? s.init_raw : __uint_as_float(V.C->maxinit_bits[lvl]));
   } else {
     const LevelView Pp = level_sel(V, lvl + 1);
-    const int par = ((i / L.w) / 2) * Pp.w + ((i % L.w) / 2);
+    const int par = ((i / L.w) / Pp.rdiv) * Pp.w + ((i % L.w) / Pp.rdiv);
     init = Pp.rza[(size_t)(Pp.steps - 1) * Pp.n + par];
   }
   L.cinit[i] = init;
@@ -569,7 +572,7 @@ DISTR_GLOBAL void __launch_bounds__(256) k_fine_init(View V0) {
     const int y = px / L0.w, x = px % L0.w;
     if (V.pyramid) {
       const LevelView& L1 = V.lv[1];
-      const int par1 = (y / 2) * L1.w + (x / 2);
+      const int par1 = (y / L1.rdiv) * L1.w + (x / L1.rdiv);
       init_now = L1.rza[(size_t)(L1.steps - 1) * L1.n + par1];
     }
     for (int k = 0; k < V.cfg.buffer_size; ++k) {
@@ -582,7 +585,7 @@ DISTR_GLOBAL void __launch_bounds__(256) k_fine_init(View V0) {
     if (V.pyramid) {
       for (int lvl = V.nlev - 1; lvl >= 1; --lvl) {
         const LevelView Lc = level_sel(V, lvl);
-        const int par = (y >> lvl) * Lc.w + (x >> lvl);
+        const int par = (y / Lc.sdiv) * Lc.w + (x / Lc.sdiv);
         for (int st = 0; st < Lc.steps; ++st) {
           const size_t o = (size_t)st * Lc.n + par;
           topk_insert(V, px, Lc.rs[o], Lc.rzb[o], Lc.rza[o], src_coarse(lvl, st, par));

@@ -26,7 +26,7 @@ EXPORTS = ['distr_version', 'distr_abi_version', 'distr_create_abi', 'distr_dest
            'distr_profile_read_list', 'distr_get_live_counts', 'distr_color_backward',
            'distr_render_forward_batch', 'distr_render_backward_batch', 'distr_render_normal_batch', 'distr_mlp_eval_bf16x6', 'distr_mlp_eval_f16x3']
 
-ABI_VERSION = 5                                   # DISTR_ABI_VERSION of include/distr.h this mirror was written against
+ABI_VERSION = 6                                   # DISTR_ABI_VERSION of include/distr.h this mirror was written against
 MAX_VIEWS = 64                                    # DISTR_MAX_VIEWS
 VIEW_GRAD_DEPTH, VIEW_GRAD_MASK, VIEW_GRAD_CAMERA = 1, 2, 4      # DISTR_VIEW_GRAD_*
 
@@ -65,6 +65,9 @@ class RenderCfg(_Sized):
         ('row0', C.c_int32), ('rows', C.c_int32),
         ('arith', C.c_int32),
         ('concurrent', C.c_int32),
+        ('num_levels', C.c_int32),
+        ('level_scale', C.c_int32 * 4),
+        ('level_steps', C.c_int32 * 4),
     ]
 
     @property
@@ -329,8 +332,10 @@ class concurrent_section(object):
 def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
              marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
              use_depth2normal=False, normalize_normal=True, want_normal=True,
-             grad_depth=True, grad_mask=True, grad_camera=True, band=None, arith='f32'):
-    """Host-side part of SDFRenderer.__init__ (core/sdfrenderer/renderer.py:13-59) as a C struct."""
+             grad_depth=True, grad_mask=True, grad_camera=True, band=None, arith='f32', scale_list=None, march_step_list=None):
+    """Host-side part of SDFRenderer.__init__ (core/sdfrenderer/renderer.py:13-59) as a C struct. scale_list / march_step_list (the
+    reference's keywords, coarsest level first): the general pyramid (num_levels / level_scale / level_steps of include/distr.h); without
+    them coarse_steps describes the default [4, 2, 1] (or [2, 1]: coarse_steps = (s, 0))."""
     cfg = RenderCfg()
     cfg.H, cfg.W = int(img_hw[0]), int(img_hw[1])
     K = np.asarray(intrinsic, dtype=np.float64)
@@ -355,6 +360,13 @@ def make_cfg(img_hw, intrinsic, march_step=50, buffer_size=5, ratio=1.5, thresho
         raise ValueError('Error! Invalid type of ray marching: {}.'.format(marcher))
     cfg.marcher = MARCHERS[marcher]
     cfg.coarse_steps = (C.c_int32 * 2)(int(coarse_steps[0]), int(coarse_steps[1]))
+    if scale_list is not None:
+        sl, ms = [int(v) for v in scale_list], [int(v) for v in (march_step_list if march_step_list is not None else [])]
+        if any(float(v) != int(v) for v in scale_list) or not 2 <= len(sl) <= 4 or len(ms) != len(sl):
+            raise NotImplementedError('pyramid scale_list=%r / march_step_list=%r: 2..4 integer scales with one step count each' % (scale_list, march_step_list))
+        cfg.num_levels = len(sl)
+        cfg.level_scale = (C.c_int32 * 4)(*(sl + [0] * (4 - len(sl))))
+        cfg.level_steps = (C.c_int32 * 4)(*(ms[:-1] + [0] * (5 - len(sl))))
     cfg.use_depth2normal, cfg.normalize_normal, cfg.want_normal = int(use_depth2normal), int(normalize_normal), int(want_normal)
     cfg.grad_depth, cfg.grad_mask, cfg.grad_camera = int(grad_depth), int(grad_mask), int(grad_camera)
     cfg.save_for_backward = 1

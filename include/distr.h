@@ -35,8 +35,8 @@
 extern "C" {
 #endif
 
-#define DISTR_ABI_VERSION 5u /* bumped whenever a struct layout or an entry point's signature changes (4: struct_size fields, distr_create_abi;
-                                5: distr_render_stats.tail_from / tail_steals) */
+#define DISTR_ABI_VERSION 6u /* bumped whenever a struct layout or an entry point's signature changes (4: struct_size fields, distr_create_abi;
+                                5: distr_render_stats.tail_from / tail_steals; 6: distr_render_cfg.num_levels / level_scale / level_steps) */
 
 /* zero a boundary struct and announce its size: distr_render_cfg cfg; DISTR_INIT(cfg); cfg.H = ...; */
 #define DISTR_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); } while (0)
@@ -59,6 +59,7 @@ extern "C" {
                                 distr_render_stats.f16_overflows / NaN for activations), not bit-identical */
 
 #define DISTR_MAX_BUFFER_SIZE 8
+#define DISTR_MAX_PYRAMID_LEVELS 4 /* len(scale_list) of the pyramid marcher (distr_render_cfg::num_levels) */
 #define DISTR_MAX_VIEWS 64 /* views per batched render (distr_render_forward_batch) */
 
 /* per-view gradient switches of a batched render (view_flags[]): the no_grad_* keyword arguments of render_depth / render
@@ -131,6 +132,13 @@ typedef struct distr_render_cfg {
                                  then does not turn "sticky": a sticky launch keeps up to 248 compute units to itself for milliseconds, which
                                  is the fastest way to finish ONE small render and the slowest way to share the chip. Values never depend on
                                  it (tests/gpu_diag_multiscale.py: three scales on three streams 23.8 -> 20.6 ms per iteration). */
+  int32_t num_levels;         /* pyramid marcher, ABI 6. 0 (what a zeroed struct selects): the pyramid is described by coarse_steps above
+                                 (scale_list [4,2,1], or [2,1] with coarse_steps = {s, 0}). 2..DISTR_MAX_PYRAMID_LEVELS: the general form
+                                 of ray_marching_pyramid_recursive (renderer.py:713-805: one level per scale_list entry) --                */
+  int32_t level_scale[4];     /* scale_list, coarsest first; integers, the last one 1, each a multiple of the next (the ratio of two
+                                 consecutive levels is the `scale` of get_downscaled_grid_map, renderer.py:604-629, 739)                  */
+  int32_t level_steps[4];     /* march_step_list of the coarse levels (1..15 steps each), coarsest first; entry num_levels-1 is ignored:
+                                 the full-resolution level marches march_step minus the coarse steps (renderer.py:724-725)               */
 } distr_render_cfg;
 
 /* Counters of one forward call (read back with distr_get_render_stats). */

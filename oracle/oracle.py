@@ -28,6 +28,7 @@ class OrcCfg(C.Structure):
         ('coarse_steps', C.c_int32 * 2),
         ('use_depth2normal', C.c_int32), ('normalize_normal', C.c_int32), ('want_normal', C.c_int32),
         ('grad_depth', C.c_int32), ('grad_mask', C.c_int32), ('grad_camera', C.c_int32),
+        ('num_levels', C.c_int32), ('level_scale', C.c_int32 * 4), ('level_steps', C.c_int32 * 4),
     ]
 
 
@@ -90,7 +91,7 @@ def _f32(a):
 def make_cfg(H, W, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold=5e-5, radius=1.0, clamp_dist=0.1,
              marcher='pyramid_recursive', coarse_steps=(3, 3), transform_matrix=None, use_transform=True,
              use_depth2normal=False, normalize_normal=True, want_normal=True,
-             grad_depth=True, grad_mask=True, grad_camera=True):
+             grad_depth=True, grad_mask=True, grad_camera=True, scale_list=None, march_step_list=None):
     cfg = OrcCfg()
     cfg.H, cfg.W = H, W
     K = np.asarray(intrinsic, dtype=np.float64)
@@ -107,6 +108,11 @@ def make_cfg(H, W, intrinsic, march_step=50, buffer_size=5, ratio=1.5, threshold
     cfg.ratio, cfg.threshold, cfg.radius, cfg.clamp_dist = ratio, threshold, radius, clamp_dist
     cfg.marcher = MARCHERS[marcher]
     cfg.coarse_steps = (C.c_int32 * 2)(*coarse_steps)
+    if scale_list is not None:       # the general pyramid (renderer.py:713-805), coarsest level first like the reference's keywords
+        sl, ms = [int(v) for v in scale_list], [int(v) for v in march_step_list]
+        cfg.num_levels = len(sl)
+        cfg.level_scale = (C.c_int32 * 4)(*(sl + [0] * (4 - len(sl))))
+        cfg.level_steps = (C.c_int32 * 4)(*(ms[:-1] + [0] * (5 - len(sl))))
     cfg.use_depth2normal, cfg.normalize_normal, cfg.want_normal = int(use_depth2normal), int(normalize_normal), int(want_normal)
     cfg.grad_depth, cfg.grad_mask, cfg.grad_camera = int(grad_depth), int(grad_mask), int(grad_camera)
     return cfg

@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
   OFF(distr_render_cfg, coarse_steps); OFF(distr_render_cfg, use_depth2normal); OFF(distr_render_cfg, normalize_normal);
   OFF(distr_render_cfg, want_normal); OFF(distr_render_cfg, grad_depth); OFF(distr_render_cfg, grad_mask); OFF(distr_render_cfg, grad_camera);
   OFF(distr_render_cfg, save_for_backward); OFF(distr_render_cfg, row0); OFF(distr_render_cfg, rows); OFF(distr_render_cfg, arith); OFF(distr_render_cfg, concurrent);
+  OFF(distr_render_cfg, num_levels); OFF(distr_render_cfg, level_scale); OFF(distr_render_cfg, level_steps);
   OFF(distr_decoder_desc, struct_size); OFF(distr_decoder_desc, latent_size); OFF(distr_decoder_desc, hidden); OFF(distr_decoder_desc, num_linear); OFF(distr_decoder_desc, latent_in);
   OFF(distr_render_stats, struct_size); OFF(distr_render_stats, reserved); OFF(distr_render_stats, num_in_sphere); OFF(distr_render_stats, num_march_launches); OFF(distr_render_stats, num_point_evals);
   OFF(distr_render_stats, num_valid); OFF(distr_render_stats, num_grad_samples); OFF(distr_render_stats, cluster_fallbacks); OFF(distr_render_stats, f16_overflows);

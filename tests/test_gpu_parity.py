@@ -273,6 +273,9 @@ SWEEP = [
     (64, 48, 25, 3, 2.0, 'pyramid_recursive', True, (100, 45, 1.4, -20), dict(coarse_steps=(2, 4))),
     (45, 59, 22, 3, 1.5, 'pyramid_recursive', True, (-40, 15, 1.5, 12), dict(coarse_steps=(3, 0))),        # two levels: scale_list=[2, 1] (G28)
     (31, 33, 40, 5, 1.0, 'pyramid_recursive', False, (70, -25, 1.8, 0), dict(coarse_steps=(1, 0))),
+    (53, 41, 30, 3, 1.5, 'pyramid_recursive', True, (15, 35, 1.6, -8), dict(scale_list=[8, 4, 2, 1], march_step_list=[1, 2, 3, -1])),      # general pyramids
+    (38, 50, 26, 2, 1.5, 'pyramid_recursive', False, (-75, 5, 1.7, 0), dict(scale_list=[6, 3, 1], march_step_list=[2, 2, -1])),
+    (64, 64, 36, 4, 2.0, 'pyramid_recursive', True, (140, -30, 1.5, 20), dict(scale_list=[5, 1], march_step_list=[4, -1])),
     (36, 36, 16, 3, 1.5, 'recursive', False, (20, 10, 1.6, 0), dict(use_transform=False)),
     (36, 36, 16, 3, 1.5, 'pyramid_recursive', False, (20, 10, 1.6, 0), dict(grad_camera=False)),
     (36, 36, 16, 3, 1.5, 'recursive', True, (20, 10, 1.6, 0), dict(grad_depth=False)),
@@ -1131,6 +1134,18 @@ def test_c_abi_error_paths(engine, fixture_decoder):
         f, b = C.c_size_t(), C.c_size_t()
         assert L.distr_workspace_bytes(h, C.byref(bad), C.byref(f), C.byref(b)) != 0, field
         assert len(err()) > 0
+    # pyramids the kernels are not built for (include/distr.h: num_levels / level_scale / level_steps), and row bands under a pyramid
+    # whose coarsest scale does not divide the bands' 4-row alignment
+    for kw, word in ((dict(scale_list=[3, 2, 1], march_step_list=[2, 2, -1]), 'multiple'), (dict(scale_list=[4, 2], march_step_list=[2, -1]), 'must be 1'),
+                     (dict(scale_list=[16, 1], march_step_list=[2, -1]), 'multiple'), (dict(scale_list=[4, 2, 1], march_step_list=[2, 0, -1]), 'step'),
+                     (dict(scale_list=[4, 2, 1], march_step_list=[2, 16, -1]), '15'), (dict(scale_list=[8, 4, 2, 1], march_step_list=[2, 2, 2, -1], band=(8, 8)), 'band')):
+        bad = binding.make_cfg((32, 32), K, march_step=12, buffer_size=3, **kw)
+        f, b = C.c_size_t(), C.c_size_t()
+        assert L.distr_workspace_bytes(h, C.byref(bad), C.byref(f), C.byref(b)) != 0 and word in err(), (kw, err())
+    bad = cfg.clone()
+    bad.num_levels = 5
+    f, b = C.c_size_t(), C.c_size_t()
+    assert L.distr_workspace_bytes(h, C.byref(bad), C.byref(f), C.byref(b)) != 0 and 'num_levels' in err()
     # backward on a forward that did not save for backward
     inf = cfg.clone()
     inf.save_for_backward = 0
@@ -1784,9 +1799,10 @@ def test_multiscale_shape_loop_matches_reference_golden(fixture_decoder):
 
 @pytest.mark.gpu
 def test_two_level_pyramid_matches_reference_golden(fixture_decoder):
-    """G28 through the drop-in class with the reference's own keywords: SDFRenderer(scale_list=[2, 1], march_step_list=[s, -1]) on an odd-sized
-    image, fixtures F1 and F2, and an explicit last march_step_list entry (renderer.py:713-805, 724-725), against the reference's outputs
-    and gradients at G24's bars; other pyramids stay rejected at construction."""
+    """G28 through the drop-in class with the reference's own keywords: SDFRenderer(scale_list=..., march_step_list=...) on an odd-sized image,
+    fixtures F1 and F2: two levels (also with an explicit last march_step_list entry, renderer.py:724-725), four levels, ratios of 3 and 4
+    (renderer.py:713-805), against the reference's outputs and gradients at G24's bars; what is not built (five levels, fractional
+    ratios, a list that does not end in 1, ratios above 8) is rejected at construction."""
     import torch
     import test_oracle_vs_golden as tg
     from core.sdfrenderer import SDFRenderer
@@ -1798,6 +1814,11 @@ def test_two_level_pyramid_matches_reference_golden(fixture_decoder):
         'two_level_6_d2n': ('f1', dict(scale_list=[2, 1], march_step_list=[6, -1], use_depth2normal=True)),
         'two_level_explicit_2_20': ('f1', dict(scale_list=[2, 1], march_step_list=[2, 20], march_step=50)),
         'two_level_3_f2': ('f2', dict(scale_list=[2, 1], march_step_list=[3, -1])),
+        'four_level_2_2_2': ('f1', dict(scale_list=[8, 4, 2, 1], march_step_list=[2, 2, 2, -1])),
+        'ratio_3': ('f1', dict(scale_list=[3, 1], march_step_list=[3, -1])),
+        'ratio_3_2': ('f1', dict(scale_list=[6, 2, 1], march_step_list=[2, 3, -1])),
+        'ratio_4': ('f1', dict(scale_list=[4, 1], march_step_list=[4, -1], use_depth2normal=True)),
+        'four_level_f2_d2n': ('f2', dict(scale_list=[8, 4, 2, 1], march_step_list=[3, 1, 2, -1], use_depth2normal=True)),
     }
     assert sorted(cases) == sorted(str(n) for n in g['names'])
     wd, wq, wn = (torch.from_numpy(a).cuda() for a in helpers.loss_weights(H, W, 5))
@@ -1816,8 +1837,9 @@ def test_two_level_pyramid_matches_reference_golden(fixture_decoder):
         res = tg.check_g24(a, g, name)
         assert abs(float(L.detach()) - float(g[name + '.loss'])) <= 5e-5 * abs(float(g[name + '.loss'])), (name, float(L.detach()), float(g[name + '.loss']))
         print('G28', name, {k: '%.1e' % v for k, v in res.items()})
-    for bad in (dict(scale_list=[8, 4, 2, 1], march_step_list=[2, 2, 2, -1]), dict(scale_list=[3, 1], march_step_list=[3, -1]),
-                dict(scale_list=[2, 1], march_step_list=[3, 3, -1])):
+    for bad in (dict(scale_list=[16, 8, 4, 2, 1], march_step_list=[2, 2, 2, 2, -1]), dict(scale_list=[3, 2, 1], march_step_list=[3, 3, -1]),
+                dict(scale_list=[2, 1], march_step_list=[3, 3, -1]), dict(scale_list=[4, 2], march_step_list=[3, -1]),
+                dict(scale_list=[16, 1], march_step_list=[3, -1])):
         with pytest.raises(NotImplementedError):
             SDFRenderer(decs['f1'], g['K'], img_hw=(H, W), **bad)
     with pytest.raises(ValueError):

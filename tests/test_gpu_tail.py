@@ -134,6 +134,13 @@ def test_two_level_pyramid_through_the_tail_launch(fixture_decoder, per_step_eng
         assert _same(a, b) == [], (frm, _same(a, b))
     o = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
     print(helpers.compare(b, o, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4))
+    # a general pyramid (four levels, ratios 2 x 3 x 2) the same way
+    kw = dict(march_step=50, buffer_size=5, marcher='pyramid_recursive', use_depth2normal=False, ratio=1.5, scale_list=[12, 6, 2, 1], march_step_list=[2, 1, 3, -1])
+    b = helpers.hip_render(per_step_engine, H, W, K, R, T, latent, **kw)
+    a = helpers.hip_render(_engine(fixture_decoder, DISTR_TAIL_FROM=3), H, W, K, R, T, latent, **kw)
+    assert _same(a, b) == [], _same(a, b)
+    o = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    print(helpers.compare(b, o, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4))
 
 
 @pytest.mark.parametrize('absent', [1, 8, 37, 200])

@@ -43,7 +43,7 @@ def test_cfg_struct_matches_header():
         for n in decl.split(None, 1)[1].split(','):
             names.append(n.strip().split('[')[0])
     assert names == [f[0] for f in binding.RenderCfg._fields_]
-    assert C.sizeof(binding.RenderCfg) == 4 * (1 + 2 + 9 + 2 + 9 + 9 + 2 + 4 + 1 + 2 + 3 + 3 + 1 + 2 + 1 + 1)
+    assert C.sizeof(binding.RenderCfg) == 4 * (1 + 2 + 9 + 2 + 9 + 9 + 2 + 4 + 1 + 2 + 3 + 3 + 1 + 2 + 1 + 1 + 1 + 4 + 4)
 
 
 def test_create_without_gpu_fails_loudly(libdistr):

@@ -403,14 +403,21 @@ G28_CFG = {
     'two_level_6_d2n': ('f1', dict(coarse_steps=(6, 0), use_depth2normal=True)),
     'two_level_explicit_2_20': ('f1', dict(coarse_steps=(2, 0), march_step=22)),
     'two_level_3_f2': ('f2', dict(coarse_steps=(3, 0))),
+    # the general form (num_levels / level_scale / level_steps of the cfg): keywords of the reference, coarsest level first
+    'four_level_2_2_2': ('f1', dict(scale_list=[8, 4, 2, 1], march_step_list=[2, 2, 2, -1])),
+    'ratio_3': ('f1', dict(scale_list=[3, 1], march_step_list=[3, -1])),
+    'ratio_3_2': ('f1', dict(scale_list=[6, 2, 1], march_step_list=[2, 3, -1])),
+    'ratio_4': ('f1', dict(scale_list=[4, 1], march_step_list=[4, -1], use_depth2normal=True)),
+    'four_level_f2_d2n': ('f2', dict(scale_list=[8, 4, 2, 1], march_step_list=[3, 1, 2, -1], use_depth2normal=True)),
 }
 
 
 @pytest.mark.parametrize('name', sorted(G28_CFG))
 def test_oracle_two_level_pyramid_matches_reference_golden(name):
-    """G28 (oracle/gen_golden_pyramid2.py): ray_marching_pyramid_recursive with scale_list=[2, 1] (renderer.py:713-805 builds one level per
-    entry) rendered by the reference itself on an odd-sized image, fixtures F1 and F2; an explicit last march_step_list entry. Same
-    bars as G24 (the reference's own floors are in the golden)."""
+    """G28 (oracle/gen_golden_pyramid2.py): ray_marching_pyramid_recursive with pyramids other than the default (renderer.py:713-805 builds
+    one level per scale_list entry) rendered by the reference itself on an odd-sized image, fixtures F1 and F2: two levels [2, 1] (also
+    with an explicit last march_step_list entry), four levels [8, 4, 2, 1], ratios of 3 and 4 ([3, 1], [6, 2, 1], [4, 1]). Same bars as
+    G24 (the reference's own floors are in the golden)."""
     import helpers
     from distr import fixture
     g = np.load(os.path.join(GOLDEN, 'g28_two_level_pyramid.npz'))
