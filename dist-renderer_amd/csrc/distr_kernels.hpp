@@ -657,6 +657,20 @@ struct MarchArgs {
   int32_t tail_absent;       // tests (DISTR_TAIL_TEST_ABSENT=n): workgroups 0 .. n-1 of k_tail leave at once, as if they never became resident
 };
 
+// One pyramid level of view b, read from the kernel-argument segment (MarchArgs is the first argument of every march kernel): a scalar
+// load of the SELECTED level. level_sel on a register-resident View keeps all MAX_LEVELS x 17 members alive and selects among them --
+// with the fourth level that was 150-240 spilled SGPRs (v_writelane / v_readlane next to the MFMAs) in the coarse launches.
+__device__ __forceinline__ LevelView level_at(int l, int b) {
+  const View& V0 = kernarg_ref<MarchArgs>(0).V;
+  LevelView L = (&V0.lv[0])[l];
+  if (V0.nviews > 1) {
+    const int64_t d = (int64_t)b * V0.vstride;
+    adv(L.valid, d); adv(L.list, d); adv(L.cinit, d); adv(L.cm, d); adv(L.rs, d); adv(L.rzb, d); adv(L.rza, d);
+  }
+  return L;
+}
+__device__ __forceinline__ int64_t moff_at(int l) { return (&kernarg_ref<MarchArgs>(0).V.moff[0])[l]; }
+
 // KEEP: also save the ReLU masks of every row that enters a ray's selected-row buffer (and of every coarse row), so
 // that the backward pass does not have to recompute the decoder forward (View::mstore).
 // Body of one 32*RB-ray tile; `tile` / `ntile_grid` = index and count of the tiles this launch (or this role of a merged
@@ -711,7 +725,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
   }
   const View V = view_at(V0, vb);
   const int32_t* list = nullptr;
-  if (MODE == MODE_COARSE) list = level_sel(V, A.lvl).list;
+  if (MODE == MODE_COARSE) list = level_at(A.lvl, vb).list;
   else if (MODE == MODE_FINE) list = split ? live_sel(V, A.step) : V.lv[0].list;
   const float* c0 = (MODE == MODE_EVAL) ? A.c0c4 : V.C->c0;
   const float* c4 = (MODE == MODE_EVAL) ? A.c0c4 + HID : V.C->c4;
@@ -732,7 +746,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
           p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
         } else {
           id = list[r];
-          const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
+          const LevelView L = (MODE == MODE_COARSE) ? level_at(A.lvl, vb) : V.lv[0];
           const CamRegs cam = load_cam(V.C);
           float cx, cy;
           level_center(L, id, cx, cy);
@@ -770,14 +784,14 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
       const float cd = V.cfg.clamp_dist, ratio = V.cfg.ratio;
       if (MODE == MODE_COARSE) {
         if (valid) {
-          const LevelView L = level_sel(V, A.lvl);
+          const LevelView L = level_at(A.lvl, vb);
           const float mn = L.cm[id] + clampf(s, -cd, cd) * ratio;
           L.cm[id] = mn;
           const size_t o = (size_t)A.step * L.n + id;
           L.rs[o] = s;
           L.rzb[o] = zd;
           L.rza[o] = mn + L.cinit[id];
-          mblock = V.mfine + moff_sel(V, A.lvl) + (int64_t)o;
+          mblock = V.mfine + moff_at(A.lvl) + (int64_t)o;
         }
       } else {  // MODE_FINE
         bool stay = false;
@@ -1078,7 +1092,7 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
     }
   }
   if (origin && V.C->origin_done) return;   // f(origin) was evaluated by an earlier launch (the one that turned sticky)
-  const int32_t* list = (MODE == MODE_COARSE) ? level_sel(V, A.lvl).list : (MODE == MODE_FINE) ? live_sel(V, t.step) : nullptr;
+  const int32_t* list = (MODE == MODE_COARSE) ? level_at(A.lvl, t.vb).list : (MODE == MODE_FINE) ? live_sel(V, t.step) : nullptr;
 
   int32_t id = -1;
   float zd = 0.f;
@@ -1094,7 +1108,7 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
         p[0] = A.xyz[r * 3]; p[1] = A.xyz[r * 3 + 1]; p[2] = A.xyz[r * 3 + 2];
       } else {
         id = ld_x<false>(list + r);
-        const LevelView L = (MODE == MODE_COARSE) ? level_sel(V, A.lvl) : V.lv[0];
+        const LevelView L = (MODE == MODE_COARSE) ? level_at(A.lvl, t.vb) : V.lv[0];
         const CamRegs cam = load_cam(V.C);
         float cx, cy;
         level_center(L, id, cx, cy);
@@ -1190,7 +1204,7 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
       if (origin) {
         if (tid == 0) mblock = Ve.morigin;
       } else if (MODE == MODE_COARSE) {
-        if (valid) mblock = Ve.mfine + moff_sel(Ve, A.lvl) + (long long)((size_t)t.step * level_sel(Ve, A.lvl).n + id);
+        if (valid) mblock = Ve.mfine + moff_at(A.lvl) + (long long)((size_t)t.step * level_at(A.lvl, t.vb).n + id);
       } else if (MODE == MODE_FINE) {
         if (valid) {
           const int slot = topk_slot_pre(Ve, sr, s);
@@ -1203,14 +1217,14 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
       if (valid) A.sdf_out[id] = (A.clamp >= 0.f) ? clampf(s, -A.clamp, A.clamp) : s;
     } else if (MODE == MODE_COARSE) {
       if (valid) {
-        const LevelView L = level_sel(Ve, A.lvl);
+        const LevelView L = level_at(A.lvl, t.vb);
         const float mn = L.cm[id] + clampf(s, -Ve.cfg.clamp_dist, Ve.cfg.clamp_dist) * Ve.cfg.ratio;
         L.cm[id] = mn;
         const size_t o = (size_t)t.step * L.n + id;
         L.rs[o] = s;
         L.rzb[o] = zd;
         L.rza[o] = mn + L.cinit[id];
-        mblock = Ve.mfine + moff_sel(Ve, A.lvl) + (long long)o;
+        mblock = Ve.mfine + moff_at(A.lvl) + (long long)o;
       }
     } else {
       const float cd = Ve.cfg.clamp_dist, ratio = Ve.cfg.ratio;
