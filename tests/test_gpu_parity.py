@@ -523,6 +523,9 @@ BAND_CASES = [  # (H, W, bands, marcher, d2n)
     (70, 64, [(0, 36), (36, 70)], 'pyramid_recursive', True),          # H not a multiple of 4: last band ends at H
     (96, 96, [(0, 48), (48, 96)], 'recursive', False),
     (64, 64, [(0, 16), (16, 32), (32, 48), (48, 64)], 'trivial', True),
+    # pyramids whose coarsest scale divides the bands' 4-row alignment: two levels (compact and general form), ratio 4 in one step
+    (90, 64, [(0, 40), (40, 90)], 'pyramid_recursive', True, dict(coarse_steps=(3, 0))),
+    (76, 60, [(0, 24), (24, 52), (52, 76)], 'pyramid_recursive', False, dict(scale_list=[4, 1], march_step_list=[3, -1])),
 ]
 
 
@@ -534,12 +537,13 @@ def test_row_bands_equal_full_render(engine, fixture_decoder, case):
     full render's (different summation order only)."""
     import torch
     from distr import binding, fixture, functions
-    H, W, bands, marcher, d2n = BAND_CASES[case]
+    H, W, bands, marcher, d2n = BAND_CASES[case][:5]
+    pyr = BAND_CASES[case][5] if len(BAND_CASES[case]) > 5 else {}
     Ws, bs, latent = fixture_decoder
     K = fixture.make_intrinsic(H, W)
     R, T = fixture.make_camera(20.0, 15.0, 1.7, 5.0)
     dev = engine.device
-    cfg = binding.make_cfg((H, W), K, march_step=24, buffer_size=3, marcher=marcher, use_depth2normal=d2n)
+    cfg = binding.make_cfg((H, W), K, march_step=24, buffer_size=3, marcher=marcher, use_depth2normal=d2n, **pyr)
     wd, wq, wn = (torch.from_numpy(a).to(dev) for a in helpers.loss_weights(H, W, 3))
 
     def run(r0, r1):
@@ -568,6 +572,51 @@ def test_row_bands_equal_full_render(engine, fixture_decoder, case):
         tot = sum(p[1][k] for p in parts)
         rel = np.abs(tot - gfull[k]).max() / np.abs(gfull[k]).max()
         assert rel < 2e-5, (name, rel)
+
+
+@pytest.mark.gpu
+def test_general_form_of_the_default_pyramid_is_the_compact_form(engine, fixture_decoder):
+    """distr_render_cfg.num_levels = 3 / level_scale = [4, 2, 1] / level_steps (the general description, include/distr.h ABI 6) renders byte
+    for byte what coarse_steps = (a, b) renders -- outputs and gradients, tail launch included -- and [2, 1] the same against (s, 0)."""
+    from distr import fixture
+    _, _, latent = fixture_decoder
+    for (H, W, S) in ((70, 54, 40), (137, 137, 100)):
+        K = fixture.make_intrinsic(H, W)
+        R, T = fixture.make_camera(35, -10, 1.6, 5)
+        base = dict(march_step=S, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True, ratio=1.5)
+        for compact, general in ((dict(coarse_steps=(2, 4)), dict(scale_list=[4, 2, 1], march_step_list=[2, 4, -1])),
+                                 (dict(coarse_steps=(5, 0)), dict(scale_list=[2, 1], march_step_list=[5, -1]))):
+            a = helpers.hip_render(engine, H, W, K, R, T, latent, **base, **compact)
+            b = helpers.hip_render(engine, H, W, K, R, T, latent, **base, **general)
+            for k in ('zdepth', 'mask', 'min_sdf', 'depth', 'normal', 'g_latent', 'g_R', 'g_T'):
+                assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), (H, compact, k)
+
+
+PYRAMID_MENU = ([2, 1], [3, 1], [4, 1], [8, 1], [4, 2, 1], [6, 2, 1], [6, 3, 1], [8, 2, 1], [9, 3, 1], [8, 4, 2, 1], [12, 6, 2, 1], [12, 4, 2, 1], [16, 8, 4, 1], [64, 8, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_PYRAMIDS', '8'))))
+def test_random_pyramids_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
+    """Seeded random draws over the pyramid (2..4 levels, ratios 2..8 from a menu), its step counts, a ragged image size, buffer_size,
+    normal mode and camera: HIP vs oracle, zero mask flips (renderer.py:713-805 through include/distr.h's general description)."""
+    from distr import fixture
+    rs = np.random.RandomState(7000 + seed)
+    sl = list(PYRAMID_MENU[rs.randint(len(PYRAMID_MENU))])
+    H, W = int(rs.randint(24, 120)), int(rs.randint(24, 120))
+    msl = [int(rs.randint(1, 5)) for _ in sl[:-1]] + [-1]
+    S = sum(msl[:-1]) + int(rs.randint(6, 40))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 6)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher='pyramid_recursive',
+              use_depth2normal=bool(rs.randint(2)), scale_list=sl, march_step_list=msl)
+    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(1.3, 2.2)), float(rs.uniform(-30, 30)))
+    _, _, latent = fixture_decoder
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(*cam)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4)
+    print(seed, (H, W), sl, msl, S, res)
+    assert res['flips'] == 0
 
 
 @pytest.mark.gpu
