@@ -32,8 +32,10 @@ class Decoder(nn.Module):
         self.th = nn.Tanh()
 
     def inference(self, inp):
-        x = inp
         xyz = inp[:, -3:]
+        if inp.shape[1] > 3 and self.latent_dropout:        # deep_sdf_decoder.py:84-89 (the identity in eval mode)
+            inp = torch.cat([nn.functional.dropout(inp[:, :-3], p=0.2, training=self.training), xyz], 1)
+        x = inp
         last = self.num_layers - 2
         for l in range(self.num_layers - 1):
             if l in self.latent_in:

@@ -4,7 +4,7 @@ Host-side counterpart of `load_decoder` (core/utils/decoder_utils.py:7-51) + the
 construction of `Decoder.__init__` (core/graph/deep_sdf_decoder.py:19-73): takes a module or a
 state_dict, folds weight-norm (`lin{l}.weight_g/.weight_v` -> W = g * v / ||v||_row), validates that
 the architecture is the one the HIP kernels are specialised for (DeepSDF '8x512', latent 256,
-latent_in=[4], ReLU, final tanh, no LayerNorm / xyz_in_all / use_tanh / latent_dropout), and
+latent_in=[4], ReLU, final tanh, no LayerNorm / xyz_in_all / use_tanh; latent_dropout only in eval mode, where it is the identity), and
 returns one contiguous float32 array: for l in 0..8: W_l row-major (out,in) followed by b_l.
 The LDS/MFMA-fragment packing itself is done natively inside the library.
 """
@@ -101,8 +101,11 @@ def check_module_flags(decoder):
         raise UnsupportedDecoder('xyz_in_all decoders are not supported')
     if getattr(d, 'use_tanh', False):
         raise UnsupportedDecoder('use_tanh decoders are not supported')
-    if getattr(d, 'latent_dropout', False):
-        raise UnsupportedDecoder('latent_dropout decoders are not supported')
+    if getattr(d, 'latent_dropout', False) and getattr(d, 'training', False):
+        # F.dropout(latent, training=self.training), deep_sdf_decoder.py:84-87: the identity in eval mode (what every driver runs:
+        # SDFRenderer(is_eval=True) calls decoder.eval()), stochastic in training mode
+        raise UnsupportedDecoder('latent_dropout decoder in training mode: the fused kernels evaluate the deterministic (eval) network only '
+                                 '-- call decoder.eval() (SDFRenderer(is_eval=True) does)')
     li = tuple(getattr(d, 'latent_in', (4,)))
     if li != (4,):
         raise UnsupportedDecoder('latent_in=%s is not supported (only [4])' % (li,))

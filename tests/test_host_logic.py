@@ -126,6 +126,18 @@ def test_module_flags_rejected():
     d = Decoder(256, [512] * 8, latent_in=[4], norm_layers=list(range(8)), weight_norm=False)   # LayerNorm variant
     with pytest.raises(decoder_pack.UnsupportedDecoder):
         decoder_pack.pack_module(d)
+    d = Decoder(256, [512] * 8, latent_in=[4], use_tanh=True)
+    with pytest.raises(decoder_pack.UnsupportedDecoder):
+        decoder_pack.pack_module(d)
+    # latent_dropout (deep_sdf_decoder.py:84-87) is the identity in eval mode: accepted there, refused in training mode
+    d = Decoder(256, [512] * 8, latent_in=[4], latent_dropout=True)
+    with pytest.raises(decoder_pack.UnsupportedDecoder):
+        decoder_pack.pack_module(d.train())
+    plain = Decoder(256, [512] * 8, latent_in=[4])
+    plain.load_state_dict(d.state_dict())
+    assert np.array_equal(decoder_pack.pack_module(d.eval()), decoder_pack.pack_module(plain))
+    xx = torch.randn(7, 259)
+    assert torch.equal(d.inference(xx), plain.eval().inference(xx))
     d = Decoder(256, [512] * 8, latent_in=[4])
     assert decoder_pack.pack_module(d).size == 1839358
     x = torch.randn(5, 259)
