@@ -27,7 +27,11 @@ cp $F/cluster_phases.log $P/${R}_cluster_phases.log
   echo "#   DISTR_CLUSTER_SPREAD=1 DISTR_TEST_STRESS_ITERS=200 ... -k \"oversubscription or cluster_tiles_bit\"   (members of every cluster on different XCDs: the real mixed-XCD exchange)"
   grep -E "passed|failed|^real" $F/soak_spread.log
   echo "#   six times: python -m pytest tests/test_gpu_tail.py -q -x   (tail launch: bit identity, hint, absent workgroups, batch, oracle, two streams, member drop-out, XCD spread)"
-  grep -E "passed|failed|^real" $F/soak_tail.log ) > $P/${R}_soak.log
+  grep -E "passed|failed|^real" $F/soak_tail.log
+  if [ -f $F/soak_pyramids.log ]; then
+    echo "#   DISTR_TEST_RANDOM_PYRAMIDS=96 python -m pytest tests/test_gpu_parity.py -q -k \"random_pyramids\"   (96 seeded pyramids, 2..4 levels, ratios 2..8: HIP vs oracle, zero mask flips)"
+    grep -E "passed|failed|^real" $F/soak_pyramids.log
+  fi ) > $P/${R}_soak.log
 # the timed GPU test run: summary line, slowest tests, wall clock
 if [ -f $F/pytest_gpu.log ]; then ( grep -E "passed|failed" $F/pytest_gpu.log | tail -1; grep -E "^real" $F/pytest_gpu.log; echo; grep -E "^[0-9.]+s (call|setup)" $F/pytest_gpu.log ) > $P/${R}_pytest_gpu_durations.log; fi
 python $P/make_traffic.py $P/$R > /dev/null

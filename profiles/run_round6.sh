@@ -58,5 +58,6 @@ if [[ $PART == *c* ]]; then
   ( time DISTR_XCHG_SC1=1 DISTR_TEST_STRESS_ITERS=200 python -m pytest tests/test_gpu_parity.py -q -k "oversubscription or cluster_tiles_bit" ) > "$OUT/soak_sc1.log" 2>&1
   ( time DISTR_CLUSTER_SPREAD=1 DISTR_TEST_STRESS_ITERS=200 python -m pytest tests/test_gpu_parity.py -q -k "oversubscription or cluster_tiles_bit" ) > "$OUT/soak_spread.log" 2>&1
   ( time bash -c 'for i in 1 2 3 4 5 6; do python -m pytest tests/test_gpu_tail.py -q -x || exit 1; done' ) > "$OUT/soak_tail.log" 2>&1
+  ( time DISTR_TEST_RANDOM_PYRAMIDS=96 python -m pytest tests/test_gpu_parity.py -q -k "random_pyramids" ) > "$OUT/soak_pyramids.log" 2>&1
 fi
 ls -la "$OUT" | tail -60
