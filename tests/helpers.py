@@ -162,7 +162,7 @@ def write_deepsdf_experiment(root, state_dict, checkpoint='2000', module_prefix=
 # start of the session (tests/conftest.py: the tests that need them run LAST) while the other tests use the GPU; ctypes releases the GIL
 # inside the oracle. key -> (image side, camera of the C4 circle, march steps); all: pyramid_recursive, buffer 3, depth2normal, dense loss.
 BIG_ORACLE = {'c5_image0': (1024, 0, 100), 'c3': (512, 0, 50), 'c4_view1': (512, 1, 50), 'c4_view3': (512, 3, 50), 'c4_view5': (512, 5, 50),
-              'c4_view7': (512, 7, 50)}
+              'c4_view7': (512, 7, 50), 'c4_view2': (512, 2, 50), 'c4_view4': (512, 4, 50), 'c4_view6': (512, 6, 50)}
 _big = {'thread': None, 'results': {}, 'events': {}, 'errors': {}}
 
 
