@@ -118,7 +118,11 @@ def test_batch_16_views_of_137_equals_per_view(engine, fixture_decoder):
     dict(H=256, W=256, B=5, shared=False, flags=None, kw=dict(march_step=50, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)),
     dict(H=33, W=47, B=64, shared=True, flags=None, kw=dict(march_step=25, buffer_size=1, marcher='recursive', want_normal=False)),
     dict(H=128, W=96, B=2, shared=False, flags=None, band=(32, 64), kw=dict(march_step=30, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True)),
-], ids=['shapes4-pyramid-d2n', 'autograd-normals-flags', 'trivial', 'c2-size-5-shapes', 'max-batch-64', 'row-band'])
+    dict(H=75, W=61, B=5, shared=False, flags=[7, 6, 7, 3, 5], kw=dict(march_step=60, buffer_size=3, marcher='pyramid_recursive', use_depth2normal=True,
+                                                                         scale_list=[8, 4, 2, 1], march_step_list=[2, 1, 3, -1])),
+    dict(H=90, W=64, B=3, shared=True, flags=None, band=(40, 50), kw=dict(march_step=30, buffer_size=2, marcher='pyramid_recursive', use_depth2normal=False,
+                                                                             scale_list=[2, 1], march_step_list=[4, -1])),
+], ids=['shapes4-pyramid-d2n', 'autograd-normals-flags', 'trivial', 'c2-size-5-shapes', 'max-batch-64', 'row-band', 'four-level-pyramid', 'two-level-pyramid-band'])
 def test_batch_equals_per_view(engine, fixture_decoder, case):
     """Different shape codes per view (a batch of shapes, BASELINE.json configs[4]), all marchers, both normal modes, per-view
     flags, ragged sizes, the largest batch, a row band: byte equality with the stand-alone renders, forward and backward."""
