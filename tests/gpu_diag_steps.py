@@ -23,7 +23,7 @@ def tile_class(n, t16=4096, t32=8192):
     full, rem = (n // 16384) * 16384, n % 16384
     if n == 0:
         return 'empty'
-    small = '' if rem == 0 else ('16c8' if rem <= 512 else '16c4' if rem <= 1024 else '16c2' if rem <= 2048 else '16' if rem <= t16 else '32' if rem <= t32 else '64')
+    small = '' if rem == 0 else ('16c8' if rem <= 512 else '16c4' if rem <= 1024 else '16c2' if rem <= 2048 else '16' if rem <= t16 else '32' if rem <= t32 else '32+16' if rem <= t32 + t16 else '64')
     return ('%dx64r' % (full // 16384) if full else '') + ('+' if full and small else '') + small
 
 
