@@ -28,7 +28,10 @@ N > 1 (one rank per GPU over RCCL; nothing of this runs at N = 1, whose line is 
 Extra objects on the JSON line:
   roofline     the dominant kernel (fused march/MLP kernel k_march): algorithmic FLOP (3 146 752 per decoder
                evaluation, latent hoisted) / summed hipEvent kernel time on the launch stream, vs the 157.3 TFLOP/s
-               f32-MFMA peak (the instruction the kernel uses: v_mfma_f32_32x32x2_f32)
+               f32-MFMA peak (the instruction the kernel uses: v_mfma_f32_32x32x2_f32); `traffic` = fabric-side bytes per march launch,
+               MEASURED BY THIS RUN at N = 1 on the headline configuration (live_traffic: two short child runs under rocprofv3 --pmc
+               FETCH_SIZE / --pmc WRITE_SIZE, separate passes, ~6 s; --no-live-traffic or any failure: the committed PMC summary of the
+               same kernels, profiles/rNN_traffic.json, quoted only under a matching csrc digest -- `traffic_note` says which)
   split_bf16, split_f16   the same K steps in the two OPT-IN f32-equivalent arithmetics (distr_render_cfg.arith = 1 / 2: six bf16
                products, or three f16 products on LDS-resident planes, per f32 product), same protocol; reported beside `value`,
                never as it: `value` is exact f32, bit-identical to the oracle (--no-split-bf16-pass skips both passes)
@@ -237,6 +240,66 @@ C5_IMAGE_MS = 202.4                                                          # o
 C5_LOWER_HALF = 1.048                                                        # a row of the lower image half costs this x the mean row (upper: 0.952)
 
 
+def live_traffic(timeout_s=150.0):
+    """roofline.traffic measured by THIS run (the number used to be read from a committed summary): two short child runs of this
+    very script under `rocprofv3 --pmc <counter> --kernel-trace` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, no other trace domain, from
+    /tmp with TMPDIR=/tmp, as MI355X_MICROARCH.md's HBM section prescribes -- over the headline kernels only (3 timed steps + 1 warm-up, no CPU
+    baseline, no extra passes). Fabric-side bytes per march launch = (FETCH_SIZE x 2 [gfx950 counts 64 B per 128-B request for 16 B / lane
+    streaming loads] + WRITE_SIZE) KiB x 1024 / march launches. Returns (bytes_per_launch, info) or (None, reason): every failure (no rocprofv3,
+    a timeout -- the child's whole process group is killed --, an unreadable CSV) leaves the caller with the committed number and says why."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'this run is itself being profiled (no nested rocprofv3)'
+    child = [sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-split-bf16-pass', '--no-small-renders',
+             '--no-live-traffic']
+    env = dict(os.environ, TMPDIR='/tmp')
+    got, launches, t0 = {}, {}, time.time()
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='distr_pmc_', dir='/tmp')
+        try:
+            pr = subprocess.Popen([exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '--'] + child, cwd='/tmp', env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)       # (the session this Popen started: rocprofv3 and the child bench, nothing else)
+                except OSError:
+                    pass
+                pr.wait()
+                return None, 'rocprofv3 --pmc %s pass timed out after %.0f s' % (counter, timeout_s)
+            if rc != 0:
+                return None, 'rocprofv3 --pmc %s pass exited with %d' % (counter, rc)
+            total, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name') == counter and any(k in r.get('Kernel_Name', '') for k in ('k_step', 'k_march', 'k_tail')):
+                        total += float(r['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return None, 'rocprofv3 --pmc %s pass: no march kernel in the counter CSV' % counter
+            got[counter], launches[counter] = total, n
+        except Exception as e:       # noqa: BLE001 -- a measurement aid must never take the bench line down
+            return None, 'rocprofv3 --pmc %s pass failed: %r' % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if launches['FETCH_SIZE'] != launches['WRITE_SIZE']:
+        return None, 'the two PMC passes saw different numbers of march launches (%d / %d)' % (launches['FETCH_SIZE'], launches['WRITE_SIZE'])
+    n = launches['FETCH_SIZE']
+    bpl = (got['FETCH_SIZE'] * 2.0 + got['WRITE_SIZE']) * 1024.0 / n
+    return bpl, {'march_launches': n, 'fetch_size_kb_total': got['FETCH_SIZE'], 'write_size_kb_total': got['WRITE_SIZE'], 'wall_s': round(time.time() - t0, 1),
+                 'how': 'two child runs of `bench.py --steps 3 --warmup 1` (headline kernels only) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+                        '(+ --kernel-trace, separate passes); (FETCH_SIZE x 2 + WRITE_SIZE) KiB x 1024 / march launches'}
+
+
 def plan_only(args):
     """`bench.py --gpus N --plan-only [--workload c5]`: the partition an N-rank run starts from (before any in-run calibration) and the
     load it predicts for every rank, as ONE JSON line -- no GPU, no process group. The prediction is a static model fitted to
@@ -338,6 +401,9 @@ def main():
                          'c5: 4 shapes x 1024x1024 x 100 steps split over the GPUs in row bands, strong scaling')
     ap.add_argument('--plan-only', action='store_true',
                     help='print the partition of an N-rank run and the per-rank load a static cost model predicts for it (one JSON line; no GPU, no ranks)')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc, ~1 min at N = 1 on the headline '
+                         'configuration); the committed PMC summary of the same kernels is reported instead')
     ap.add_argument('--no-small-renders', action='store_true', help='skip extra.small_renders (C2, C1 and 137^2 / 100 steps timed beside the headline at N = 1)')
     args = ap.parse_args()
     if args.plan_only:
@@ -815,6 +881,13 @@ def main():
             traffic_hbm = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
+    traffic_static, traffic_live_info = traffic, None
+    if world == 1 and not args.no_live_traffic and not c5 and not args.items and args.arith == 'f32' and (H, MARCH_STEP) == (512, 50) \
+            and args.marcher == 'pyramid_recursive' and args.loss == 'dense' and args.fixture == 'f1':
+        torch.cuda.synchronize()
+        live, traffic_live_info = live_traffic()
+        if live is not None:
+            traffic = live
     rccl_info = collective_info(world, local)           # (collective: every rank takes part in the all-gather)
     partition = None
     if world > 1:
@@ -857,7 +930,10 @@ def main():
                          'frac': achieved / (PEAK_F32_MFMA_TFLOPS if args.arith == 'f32' else 2500.0), 'traffic': traffic,
                          'peak_note': 'f32-MFMA peak' if args.arith == 'f32' else 'bf16 / f16 MFMA dense peak; algorithmic FLOP counted once (the six bf16 / three f16 products per f32 product are not counted several times)',
                          'traffic_csrc_sha256': traffic_digest, 'csrc_sha256': built_from,
-                         'traffic_note': ('null: the committed PMC pass (%s) was taken on other kernels (csrc digest differs); re-run profiles/promote.sh' % os.path.relpath(tpath, ROOT)) if traffic_stale else 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
+                         'traffic_note': ('LIVE: measured by this run -- ' + traffic_live_info['how'] + '; fabric-side bytes (L2 misses: Infinity Cache + HBM), algorithmic bytes are ~32 B per decoder evaluation + the weights once, the excess is the 6.3 MB weight stream each XCD re-fetches per tile round') if isinstance(traffic_live_info, dict) else ('null: the committed PMC pass (%s) was taken on other kernels (csrc digest differs); re-run profiles/promote.sh' % os.path.relpath(tpath, ROOT)) if traffic_stale else 'STATIC: not measured by this run. Fabric-side bytes per march launch (FETCH_SIZE x 2 + WRITE_SIZE) read from the committed summary of a separate rocprofv3 --pmc pass over this same command (%s); algorithmic bytes are ~32 B per decoder evaluation, the excess is the 6.3 MB weight stream each XCD re-fetches from L2 / Infinity Cache per tile round' % os.path.relpath(tpath, ROOT),
+                         'traffic_live': traffic_live_info if isinstance(traffic_live_info, dict) else None,
+                         'traffic_live_failed': traffic_live_info if isinstance(traffic_live_info, str) else None,
+                         'traffic_static': traffic_static,
                          'traffic_hbm': traffic_hbm,
                          'traffic_hbm_note': 'null: not observable -- rocprofv3 on this stack exposes the L2\'s memory-side request counters only (every read request counts as '
                                              '"destined for DRAM", TCC_EA0_RDREQ_DRAM = TCC_EA0_RDREQ); Infinity-Cache hits are not separated from HBM reads. HBM traffic <= `traffic`; '

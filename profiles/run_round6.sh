@@ -10,7 +10,7 @@ PART=${2:-abc}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 R=$(pwd)
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass --no-small-renders"      # the headline (exact f32) kernels only
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-split-bf16-pass --no-small-renders --no-live-traffic"      # the headline (exact f32) kernels only
 if [[ $PART == *a* ]]; then
   python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
   ( cd /tmp && rocprofv3 -L > "$R/$OUT/rocprof_counters.txt" 2>&1 )

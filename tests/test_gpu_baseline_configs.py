@@ -546,3 +546,28 @@ def test_bench_rccl_multi_gpu():
     assert cb['value_switch_margin'] == 0.02
     if cb['value_is'] == 'balanced':
         assert cb['balanced_ms_per_step'] < (1.0 - cb['value_switch_margin']) * cb['unbalanced_ms_per_step']
+
+
+def test_bench_live_traffic_on_the_gpu():
+    """roofline.traffic as the default `python bench.py` measures it (bench.live_traffic: two child runs of the headline kernels under
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes): every march launch of the children is counted, the fabric-side bytes per launch
+    land where the committed PMC summary of the same kernels has them (profiles/rNN_traffic.json; 5 %: the weight stream re-fetched per XCD and
+    tile round dominates and does not depend on the run), far above the algorithmic ~27 MB and far below what HBM could deliver."""
+    import glob
+    import json
+    import shutil
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    if not (shutil.which('rocprofv3') or os.path.exists('/opt/rocm/bin/rocprofv3')):
+        pytest.skip('no rocprofv3 on this box')
+    v, info = bench.live_traffic()
+    assert isinstance(info, dict), info
+    # the child: 1 warm-up + 3 timed steps + the bracketed roofline pass + the forward / backward split, 50 march launches per forward
+    assert info['march_launches'] >= 4 * 50 and info['march_launches'] % 50 == 0
+    assert 100e6 < v < 400e6
+    from distr import binding
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic.json')))
+    tj = json.load(open(cands[-1]))
+    if tj.get('csrc_sha256') == binding.source_digest():
+        assert abs(v - tj['bytes_per_launch']) <= 0.05 * tj['bytes_per_launch'], (v, tj['bytes_per_launch'])

@@ -877,3 +877,38 @@ def test_build_is_split_into_parallel_units_and_checked():
     if os.path.exists(asm) and os.path.exists(binding.LIB_PATH) and os.path.getmtime(binding.LIB_PATH) >= os.path.getmtime(asm):
         res = binding.check_generated_code()          # (the build of this checkout, if it is there: raises on a finding)
         assert any('k_step' in n for n in res)
+
+
+def test_bench_live_traffic_failure_paths(monkeypatch, tmp_path):
+    """bench.live_traffic (roofline.traffic measured by the run itself: two child runs under rocprofv3 --pmc) never takes the bench line down:
+    without rocprofv3, or inside a profiled run (no nested profiler), it returns (None, reason) and the caller keeps the committed number. A
+    fake rocprofv3 that writes the counter CSV shows the arithmetic: (FETCH_SIZE x 2 + WRITE_SIZE) KiB x 1024 / march launches, march kernels only."""
+    import stat
+    import bench
+    monkeypatch.setenv('ROCPROFILER_TEST_MARK', '1')
+    v, why = bench.live_traffic()
+    assert v is None and 'profiled' in why
+    monkeypatch.delenv('ROCPROFILER_TEST_MARK')
+    for k in list(os.environ):
+        if k.startswith(('ROCPROF', 'ROCP_')):
+            monkeypatch.delenv(k)
+    monkeypatch.setenv('LD_PRELOAD', '')
+    import shutil
+    monkeypatch.setattr(shutil, 'which', lambda name: None)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, 'exists', lambda p: False if p == '/opt/rocm/bin/rocprofv3' else real_exists(p))
+    v, why = bench.live_traffic()
+    assert v is None and 'not found' in why
+    # a stand-in profiler: parses `--pmc <counter> ... -d <dir> --`, writes <dir>/x/1_counter_collection.csv, runs nothing
+    fake = tmp_path / 'rocprofv3'
+    fake.write_text('#!%s\nimport os, sys\na = sys.argv\nc = a[a.index("--pmc") + 1]\nd = a[a.index("-d") + 1]\n'
+                    'os.makedirs(os.path.join(d, "x"))\nv = {"FETCH_SIZE": 100.0, "WRITE_SIZE": 50.0}[c]\n'
+                    'rows = ["Kernel_Name,Counter_Name,Counter_Value"] + ["\\"void distr::k_step<true, 0>(A, B)\\",%%s,%%g" %% (c, v)] * 3 + '
+                    '["\\"void distr::k_march<1, 2, true, 0>(A, B)\\",%%s,%%g" %% (c, v), "\\"distr::k_bwd<2, 2, 0>(A)\\",%%s,1e9" %% c]\n'
+                    'open(os.path.join(d, "x", "1_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")\n' % sys.executable)
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(shutil, 'which', lambda name: str(fake))
+    monkeypatch.setattr(os.path, 'exists', real_exists)
+    v, info = bench.live_traffic()
+    assert isinstance(info, dict), info
+    assert info['march_launches'] == 4 and v == (4 * 100.0 * 2.0 + 4 * 50.0) * 1024.0 / 4
