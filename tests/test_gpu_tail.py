@@ -282,3 +282,43 @@ def test_clusters_spread_over_xcds(fixture_decoder, per_step_engine, knobs):
         assert _same(a, b) == [], (marcher, _same(a, b))
         st, _ = _stats(eng, binding.make_cfg((H, W), K, **kw), latent, R, T)
         assert st['cluster_fallbacks'] == 0, st
+
+
+TAIL_PYRAMIDS = (None, None, None, [2, 1], [8, 4, 2, 1], [6, 2, 1], [12, 6, 2, 1])
+
+
+@pytest.fixture(scope='module')
+def tail_engines(fixture_decoder):
+    return dict(hint=_engine(fixture_decoder), from0=_engine(fixture_decoder, DISTR_TAIL_FROM=0), from4=_engine(fixture_decoder, DISTR_TAIL_FROM=4),
+                from13=_engine(fixture_decoder, DISTR_TAIL_FROM=13))
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_TAIL', '6'))))      # (soak runs: more seeds)
+def test_random_configs_through_the_tail_launch(fixture_decoder, per_step_engine, tail_engines, seed):
+    """Seeded random draws (ragged sizes up to 150 px, 30..130 steps, both recursive marchers, pyramids of 2..4 levels, buffer sizes, ratios,
+    normal modes, cameras, perturbed shape codes): the render through the tail launch -- started where the previous render's hint puts it
+    (the random sweeps against the oracle render every configuration once and therefore never get there) and forced from step 0 / 4 / 13 --
+    equals the launch-per-step render byte for byte, outputs and gradients."""
+    from distr import fixture
+    rs = np.random.RandomState(9000 + seed)
+    _, _, latent0 = fixture_decoder
+    H, W = int(rs.randint(17, 150)), int(rs.randint(17, 150))
+    marcher = ['recursive', 'pyramid_recursive', 'pyramid_recursive'][rs.randint(3)]
+    S = int(rs.randint(30, 130))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 9)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher, use_depth2normal=bool(rs.randint(2)))
+    sl = TAIL_PYRAMIDS[rs.randint(len(TAIL_PYRAMIDS))]
+    if marcher == 'pyramid_recursive' and sl is not None:
+        kw['scale_list'] = list(sl)
+        kw['march_step_list'] = [int(rs.randint(1, 4)) for _ in sl[:-1]] + [-1]
+    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(1.3, 2.2)), float(rs.uniform(-20, 20)))
+    latent = (latent0 + 0.05 * rs.standard_normal(latent0.shape)).astype(np.float32)
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(*cam)
+    ref = helpers.hip_render(per_step_engine, H, W, K, R, T, latent, **kw)
+    first = helpers.hip_render(tail_engines['hint'], H, W, K, R, T, latent, **kw)       # (no hint yet: launch per step; leaves the hint)
+    assert _same(first, ref) == [], (seed, 'first', _same(first, ref))
+    import torch
+    torch.cuda.synchronize()
+    for name in ('hint', ('from0', 'from4', 'from13')[rs.randint(3)]):
+        a = helpers.hip_render(tail_engines[name], H, W, K, R, T, latent, **kw)
+        assert _same(a, ref) == [], (seed, name, (H, W), kw, _same(a, ref))
