@@ -68,7 +68,7 @@ def _raw_batch(engine, cfg, lats, Rs, Ts, flags, gz, gq, gd, gn):
     return {k: v.cpu().numpy() for k, v in out.items()}, stats
 
 
-def _check_batch(engine, fixture_decoder, H, W, B, shared, flags, band=None, **kw):
+def _check_batch(engine, fixture_decoder, H, W, B, shared, flags, band=None, require_valid=True, **kw):
     import torch
     from distr import binding, fixture
     _, _, latent = fixture_decoder
@@ -99,7 +99,7 @@ def _check_batch(engine, fixture_decoder, H, W, B, shared, flags, band=None, **k
             assert got[k][b].tobytes() == ref[k].tobytes(), (b, k, np.abs(got[k][b].astype(np.float64) - ref[k]).max())
         for k in ('num_in_sphere', 'num_point_evals', 'num_valid', 'num_grad_samples'):
             assert stats[b][k] == st[k], (b, k, stats[b][k], st[k])
-        assert stats[b]['num_valid'] > 0 or b > 0
+        assert stats[b]['num_valid'] > 0 or b > 0 or not require_valid
         evals += st['num_point_evals']
     return evals
 
@@ -127,6 +127,36 @@ def test_batch_equals_per_view(engine, fixture_decoder, case):
     """Different shape codes per view (a batch of shapes, BASELINE.json configs[4]), all marchers, both normal modes, per-view
     flags, ragged sizes, the largest batch, a row band: byte equality with the stand-alone renders, forward and backward."""
     _check_batch(engine, fixture_decoder, case['H'], case['W'], case['B'], case['shared'], case['flags'], band=case.get('band'), **case['kw'])
+
+
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('DISTR_TEST_RANDOM_BATCH', '4'))))      # (soak runs: more seeds)
+def test_random_batches_equal_per_view(engine, fixture_decoder, seed):
+    """Seeded random batches: 2..12 views, shared or per-view shape codes, random per-view no_grad flags, ragged sizes, every marcher, pyramids of
+    2..4 levels, both normal modes, now and then a row band -- every view byte-identical (outputs, gradients, counters) to its stand-alone render."""
+    rs = np.random.RandomState(12000 + seed)
+    H, W = int(rs.randint(17, 120)), int(rs.randint(17, 120))
+    B = int(rs.randint(2, 13))
+    marcher = ['recursive', 'pyramid_recursive', 'pyramid_recursive', 'trivial'][rs.randint(4)]
+    S = int(rs.randint(12, 90)) if marcher != 'trivial' else int(rs.randint(6, 14))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 6)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher)
+    mode = rs.randint(3)
+    if mode == 0:
+        kw['want_normal'] = False
+    else:
+        kw['use_depth2normal'] = bool(mode == 1)
+    sl = (None, None, [2, 1], [8, 4, 2, 1], [6, 2, 1])[rs.randint(5)]
+    if marcher == 'pyramid_recursive' and sl is not None:
+        kw['scale_list'] = list(sl)
+        kw['march_step_list'] = [int(rs.randint(1, 4)) for _ in sl[:-1]] + [-1]
+    band = None
+    if rs.randint(4) == 0 and (marcher != 'pyramid_recursive' or sl is None or sl == [2, 1]) and H >= 24:
+        r0 = 4 * int(rs.randint(0, H // 4 - 1))
+        rows = min(H - r0, 4 * int(rs.randint(1, 8)))
+        if r0 + rows < H:
+            rows -= rows % 4
+        band = (r0, max(rows, 4)) if r0 + max(rows, 4) <= H else None
+    flags = None if rs.randint(2) else [int(rs.choice([7, 6, 5, 3, 7, 7])) for _ in range(B)]
+    _check_batch(engine, fixture_decoder, H, W, B, bool(rs.randint(2)), flags, band=band, require_valid=False, **kw)     # (a thin band may miss the object, a short march may converge nowhere)
 
 
 def test_batch_argument_checks(engine, fixture_decoder):
