@@ -174,7 +174,8 @@ __device__ __forceinline__ void vfind(int32_t c, int32_t incl, int B, int g, int
 
 struct Sample { int32_t src; float zb; float coef; int32_t flags; float sdf; int32_t mblock; int32_t pad0, pad1; };
 
-// row source encoding: fine rows (level 0): pixel id (< 2^28); coarse rows: level<<28 | step<<24 | ray (< 2^24)
+// row source encoding: fine rows (level 0): the full-resolution march step that produced the row (the pixel is the row's own, k_bwd_prep
+// puts it into the Sample); coarse rows: level<<28 | step<<24 | ray (< 2^24)
 __device__ __forceinline__ int32_t src_coarse(int lvl, int step, int ray) { return (lvl << 28) | (step << 24) | ray; }
 __device__ __forceinline__ int src_level(int32_t src) { return src >> 28; }
 __device__ __forceinline__ int src_ray(int32_t src) { return (src >> 28) ? (src & 0x00ffffff) : (src & 0x0fffffff); }
@@ -550,6 +551,37 @@ __device__ __forceinline__ int topk_slot_pre(const View& V, const RayPre& st, fl
   return bs * (bs + 1) / 2 - used;
 }
 
+// The early break of the recursive march (renderer.py:562-567): when no ray is unfinished after L < buffer_size full-resolution steps, the
+// reference pads its lists to buffer_size rows by REPEATING step L-1's rows -- sdf, point and depth of every ray, real rows of the rays that
+// were evaluated at that step included -- and the selection (bs smallest |sdf|, earlier row wins ties) then takes copies of a ray's last row
+// where this library's selected-row buffer holds the rows behind it (usually pad rows). Values do not change (top-1 is the original), the
+// GRADIENT does: the copies are evaluated again, each carries the row's coefficient. Emulated on the buffer: with the last row at sorted
+// position p, n = min(bs - L, bs - 1 - p) copies follow it and the last n rows of the buffer drop out. Returns bs - L (0: no early break
+// below buffer_size steps, or not applicable) and L. Not applied to row bands: the break is a property of the WHOLE image's march, which a
+// band cannot see. Found by the random options soak of round 6 (cameras inside the sphere, buffer_size 5..8).
+__device__ __forceinline__ int early_dup(const View& V, const Consts* C, int& L) {
+  L = 0;
+  if (V.cfg.marcher == DISTR_MARCH_TRIVIAL || V.band) return 0;
+  const int bs = V.cfg.buffer_size;
+  for (int t = 0; t < bs && t < V.fine_steps; ++t)
+    if (C->cnt_live[t] + C->cnt_sticky[t] == 0) { L = t; return t >= 1 ? bs - t : 0; }
+  return 0;
+}
+// ... for one pixel: position of the duplicated row in its selected-row buffer (-1: none) and the number of copies selected
+__device__ __forceinline__ void early_dup_px(const View& V, const Consts* C, int px, int& p, int& n) {
+  p = -1; n = 0;
+  int L;
+  const int dup = early_dup(V, C, L);
+  if (dup <= 0) return;
+  const int bs = V.cfg.buffer_size;
+  const size_t P = (size_t)V.P;
+  for (int k = 0; k < bs; ++k) {
+    const int32_t src = V.tk_src[k * P + px];
+    if (src >= 0 && src_level(src) == 0 && src == L - 1) { p = k; break; }
+  }
+  if (p >= 0) n = (dup < bs - 1 - p) ? dup : (bs - 1 - p);
+}
+
 // per-ray state at the start of the full-resolution march (renderer.py:521-527, 795-804)
 DISTR_GLOBAL void __launch_bounds__(256) k_fine_init(View V0) {
   const View V = view_at(V0, blockIdx.y);
@@ -799,7 +831,7 @@ __device__ __forceinline__ bool march_tile(const MarchArgs& A, const DecoderDev&
           const float mn = st.m + clampf(s, -cd, cd) * ratio;
           V.m[(uint32_t)id] = mn;
           const float za = mn + st.init_now;
-          const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, id);  // src: level 0 | pixel
+          const int slot = topk_insert_pre(V, st, id, s, zd, V.pyramid ? za : mn, A.step);  // src: level 0 | march step (early_dup)
           if (slot >= 0) mblock = (int64_t)id * (V.cfg.buffer_size + 1) + slot;
           const float a = fabsf(s);
           if (a < st.minabs) V.minabs[(uint32_t)id] = a;
@@ -1004,7 +1036,7 @@ __device__ __forceinline__ void sticky_tile16(const MarchArgs& A, const DecoderD
           for (int k = 0; k < MAX_BS; ++k) { st.ks[k] = S.sk[k][tid]; st.sl[k] = S.ssl[k][tid]; }
           // only the lead writes the selected rows; every member mirrors the insertion on its LDS copy of the keys / slots: the slot says
           // where this step's mask block goes, and every member stores its own words of it (mlp_forward16_cl, MASK_OWN)
-          const int slot = lead ? topk_insert_pre<false>(Ve, st, id_, s, zd, Ve.pyramid ? za : mn, id_) : topk_slot_pre(Ve, st, s);
+          const int slot = lead ? topk_insert_pre<false>(Ve, st, id_, s, zd, Ve.pyramid ? za : mn, step) : topk_slot_pre(Ve, st, s);
           if (slot >= 0) {
             mblock = (long long)id_ * (Ve.cfg.buffer_size + 1) + slot;
             // the same insertion on the LDS copy: rows behind the new one move down, the new row takes its place
@@ -1233,7 +1265,7 @@ __device__ __forceinline__ void tile16_run(const MarchArgs& A, const DecoderDev&
         const float mn = sr.m + clampf(s, -cd, cd) * ratio;
         Ve.m[(uint32_t)id] = mn;
         const float za = mn + sr.init_now;
-        const int slot = topk_insert_pre<false>(Ve, sr, id, s, zd, Ve.pyramid ? za : mn, id);
+        const int slot = topk_insert_pre<false>(Ve, sr, id, s, zd, Ve.pyramid ? za : mn, t.step);
         if (slot >= 0) mblock = (long long)id * (Ve.cfg.buffer_size + 1) + slot;
         const float a = fabsf(s);
         if (a < sr.minabs) Ve.minabs[(uint32_t)id] = a;
@@ -1780,7 +1812,10 @@ DISTR_GLOBAL void __launch_bounds__(256) k_finalize(View V0, float* zdepth, uint
       const float m_row = V.pyramid ? (za0 - init_orig) : za0;
       float z = m_row + (1.0f - ratio) * clampf(s0, -cd, cd);
       if (C->vflags & VF_GRAD_DEPTH) {
-        for (int k = 0; k < V.cfg.buffer_size; ++k) {
+        int dp, dn;
+        early_dup_px(V, C, px, dp, dn);          // (the reference's op sequence runs over ITS selection: copies of the last row, early_dup)
+        for (int j = 0; j < V.cfg.buffer_size; ++j) {
+          const int k = (dn > 0 && j > dp) ? ((j - dn > dp) ? j - dn : dp) : j;
           const float sv = (V.tk_src[k * P + px] < 0) ? C->f_origin : V.tk_s[k * P + px];
           const float sc = clampf(sv, -cd, cd);
           z = z - sc * ratio;
@@ -2242,12 +2277,16 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V0, const float* g_zdepth
   const size_t P = (size_t)V.P;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // per-row coefficient of this pixel (0: no sample); pad rows accumulate into pad_acc
+  int dup_p = -1, dup_n = 0;       // early break below buffer_size steps: the ray's last row is selected 1 + dup_n times, the last dup_n rows drop out (early_dup)
+  if (in) early_dup_px(V, C, px, dup_p, dup_n);
   auto row_coef = [&](int k, int32_t& src, float& sv) -> float {
     if (!in) return 0.f;
     src = V.tk_src[k * P + px];
     sv = src < 0 ? C->f_origin : V.tk_s[k * P + px];
     float c = 0.f;
-    if (grad_depth && gz != 0.f) c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f);
+    const bool dropped = dup_n > 0 && k > dup_p && k + dup_n > bs - 1;
+    if (grad_depth && gz != 0.f && !dropped)
+      c += V.cfg.ratio * gz * (fabsf(sv) <= V.cfg.clamp_dist ? 1.f : 0.f) * ((k == dup_p) ? (float)(1 + dup_n) : 1.f);
     if (k == 0 && grad_mask) c += gq;
     return c;
   };
@@ -2282,7 +2321,8 @@ __global__ void __launch_bounds__(256) k_bwd_prep(View V0, const float* g_zdepth
     int wbase = base;
     for (int w = 0; w < wave; ++w) wbase += s_cnt[k][w];
     if (emit) {
-      Sample sm; sm.src = src; sm.zb = V.tk_zb[k * P + px]; sm.coef = c; sm.sdf = sv; sm.mblock = -1; sm.pad0 = 0; sm.pad1 = 0;
+      // (a fine row's src is its march step: the pixel is this one)
+      Sample sm; sm.src = (src_level(src) == 0) ? px : src; sm.zb = V.tk_zb[k * P + px]; sm.coef = c; sm.sdf = sv; sm.mblock = -1; sm.pad0 = 0; sm.pad1 = 0;
       if (V.save_masks) {
         const int lv = src_level(src);
         sm.mblock = (lv == 0) ? (int32_t)((int64_t)px * (bs + 1) + V.tk_slot[k * P + px])

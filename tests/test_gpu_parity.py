@@ -628,6 +628,85 @@ PYRAMID_MENU = ([2, 1], [3, 1], [4, 1], [8, 1], [4, 2, 1], [6, 2, 1], [6, 3, 1],
 
 
 @pytest.mark.gpu
+def test_early_break_matches_reference_golden(engine, fixture_decoder):
+    """G29: the reference's own outputs and gradients where its march breaks below buffer_size steps and the padded lists repeat the last
+    step's rows (renderer.py:562-567; oracle/gen_golden_early_break.py) -- HIP at G24's bars (gradients: 1e-3 or twice the reference's floor)."""
+    import test_oracle_vs_golden as tg
+    from distr import fixture
+    g = np.load(os.path.join(GOLDEN, 'g29_early_break.npz'))
+    Ws, bs, latent = fixture_decoder
+    assert fixture.weights_sha256(Ws, bs) == str(g['weights_sha256'])
+    H, W = int(g['H']), int(g['W'])
+    for name in sorted(tg.G29_CFG):
+        a = helpers.hip_render(engine, H, W, g['K'], g['R'], g['T'], g['latent'], **tg.g29_kw(g, name))
+        res = tg.check_g24(tg.g29_stable(a, g, name), g, name)
+        assert abs(a['loss'] - float(g[name + '.loss'])) <= 5e-5 * abs(float(g[name + '.loss'])), name
+        print('G29', name, {k: '%.1e' % v for k, v in res.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('marcher,bs,d2n', [('recursive', 7, True), ('recursive', 8, False), ('pyramid_recursive', 8, True), ('recursive', 3, True)])
+def test_early_break_below_buffer_size_steps(engine, cpu_oracle, orc, fixture_decoder, marcher, bs, d2n):
+    """renderer.py:562-567: when every ray has finished after L < buffer_size full-resolution steps the reference pads its lists by REPEATING
+    the last step's rows, and the selection then holds copies of a ray's last row -- evaluated again, each with the row's coefficient: same values,
+    other gradients (up to 40 % before this was restated in k_bwd_prep / k_finalize: early_dup). A camera inside the sphere next to the surface
+    with exact sphere tracing (ratio 1) ends the march after 4-6 steps. HIP vs oracle (the oracle equals the reference here: 2.5e-4 on the
+    gradient of such a case, measured in the build container); buffer_size 3 is the control (the march outlasts it)."""
+    from distr import fixture
+    H, W = 55, 79
+    _, _, latent = fixture_decoder
+    K = fixture.make_intrinsic(H, W)
+    R, T = fixture.make_camera(-73.8, -7.6, 0.475, 26.75)
+    kw = dict(march_step=30, buffer_size=bs, ratio=1.0, marcher=marcher, use_depth2normal=d2n, threshold=1.5e-3, radius=1.2, clamp_dist=0.2)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-6, tol_grad=1e-4, normal_p99=1e-5)
+    assert res['flips'] == 0 and int(b['mask'].sum()) > 500
+    # the premise: the oracle's march ended after 4 full-resolution steps (1 behind the coarse levels of the pyramid) -- below the large buffers
+    executed = len(list(b['state'].live_counts)) - (6 if marcher == 'pyramid_recursive' else 0)
+    assert executed == (1 if marcher == 'pyramid_recursive' else 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_OPTIONS', '6'))))      # (soak runs: more seeds)
+def test_random_options_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
+    """Seeded random draws over the renderer's OPTIONS (SDFRenderer.__init__ / render keywords, renderer.py:13-59, 943-999): threshold, sphere
+    radius, clamp_dist, a random rotation or axis permutation as transform_matrix, use_transform, normalize_normal, the three no_grad flags,
+    an off-centre principal point with fx != fy, cameras from inside the sphere to far outside, buffer sizes up to the maximum -- HIP vs oracle,
+    zero mask flips (the fixed option cases are pinned to the reference by G24 / G18; this sweeps their combinations)."""
+    from distr import fixture
+    rs = np.random.RandomState(21000 + seed)
+    H, W = int(rs.randint(17, 110)), int(rs.randint(17, 110))
+    marcher = ['recursive', 'pyramid_recursive', 'pyramid_recursive', 'trivial'][rs.randint(4)]
+    S = int(rs.randint(12, 70)) if marcher != 'trivial' else int(rs.randint(6, 16))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 9)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher, use_depth2normal=bool(rs.randint(2)),
+              threshold=float(10 ** rs.uniform(-5, -2.5)), radius=float(rs.uniform(0.85, 1.3)), clamp_dist=float(rs.uniform(0.03, 0.3)),
+              use_transform=bool(rs.randint(4) != 0), normalize_normal=bool(rs.randint(3) != 0),
+              grad_depth=bool(rs.randint(4) != 0), grad_mask=bool(rs.randint(4) != 0), grad_camera=bool(rs.randint(4) != 0))
+    t = rs.randint(3)
+    if t == 1:
+        perm = rs.permutation(3)
+        M = np.zeros((3, 3)); M[np.arange(3), perm] = rs.choice([-1.0, 1.0], 3)
+        kw['transform_matrix'] = M
+    elif t == 2:
+        q, _ = np.linalg.qr(rs.standard_normal((3, 3)))
+        kw['transform_matrix'] = q
+    if marcher == 'pyramid_recursive' and rs.randint(2):
+        kw['coarse_steps'] = (int(rs.randint(1, 4)), int(rs.randint(1, 4)))
+    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.choice([rs.uniform(0.3, 0.8), rs.uniform(1.2, 2.4), rs.uniform(1.2, 2.4)])), float(rs.uniform(-30, 30)))
+    _, _, latent = fixture_decoder
+    K = np.array(fixture.make_intrinsic(H, W), dtype=np.float64)
+    K[0, 0] *= rs.uniform(0.8, 1.25); K[1, 1] *= rs.uniform(0.8, 1.25)
+    K[0, 2] += rs.uniform(-0.15, 0.15) * W; K[1, 2] += rs.uniform(-0.15, 0.15) * H
+    R, T = fixture.make_camera(*cam)
+    a = helpers.hip_render(engine, H, W, K, R, T, latent, **kw)
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, K, R, T, latent, **kw)
+    res = helpers.compare(a, b, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4)
+    print(seed, (H, W), marcher, S, res)
+    assert res['flips'] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_PYRAMIDS', '8'))))
 def test_random_pyramids_match_oracle(engine, cpu_oracle, orc, fixture_decoder, seed):
     """Seeded random draws over the pyramid (2..4 levels, ratios 2..8 from a menu), its step counts, a ragged image size, buffer_size,

@@ -431,6 +431,54 @@ def test_oracle_two_level_pyramid_matches_reference_golden(name):
     print(name, check_g24(b, g, name))
 
 
+# G29 cases as cfg keyword arguments (oracle/gen_golden_early_break.py::CASES)
+G29_CFG = {
+    'recursive_bs7_d2n': dict(buffer_size=7, use_depth2normal=True, marcher='recursive'),
+    'recursive_bs8': dict(buffer_size=8, marcher='recursive'),
+    'pyramid_bs8_d2n': dict(buffer_size=8, use_depth2normal=True, marcher='pyramid_recursive'),
+    'recursive_bs3_d2n': dict(buffer_size=3, use_depth2normal=True, marcher='recursive'),
+}
+
+
+def g29_kw(g, name):
+    kw = dict(march_step=int(g['march_step']), ratio=float(g['ray_marching_ratio']), threshold=float(g['threshold']), radius=float(g['radius']), clamp_dist=0.2,
+              use_depth2normal=False)
+    kw.update(G29_CFG[name])
+    return kw
+
+
+def g29_stable(a, g, name):
+    """The render dict with the golden's own values at the pixels the REFERENCE moves by more than 1e-5 under 1e-7 weight noise (recorded per case:
+    a coarse ray stopping one step earlier moves its 2 x 2 children together; 22 pixels of the pyramid case, none elsewhere) and, for the
+    finite-difference normals, at their 4-neighbours -- those pixels are not a statement about this library."""
+    H, W = int(g['H']), int(g['W'])
+    u = g[name + '.unstable'].astype(bool)
+    if not u.any():
+        return a
+    un = u.copy()
+    un[1:] |= u[:-1]; un[:-1] |= u[1:]; un[:, 1:] |= u[:, :-1]; un[:, :-1] |= u[:, 1:]
+    b = dict(a)
+    d, q, n = np.array(a['depth'], copy=True).reshape(H, W), np.array(a['min_sdf'], copy=True).reshape(H, W), np.array(a['normal'], copy=True).reshape(H, W, 3)
+    d[u] = g[name + '.depth'][u]; q[u] = g[name + '.q'].reshape(H, W)[u]; n[un] = g[name + '.normal'][un]
+    b.update(depth=d, min_sdf=q, normal=n)
+    return b
+
+
+@pytest.mark.parametrize('name', sorted(G29_CFG))
+def test_oracle_early_break_matches_reference_golden(cpu_oracle, name):
+    """G29 (oracle/gen_golden_early_break.py): the march of a camera inside the sphere ends after 4 full-resolution steps (1 behind the pyramid's
+    coarse levels) -- below buffer_size 7 / 8 -- and the reference pads its lists by repeating the last step's rows (renderer.py:562-567): its
+    selection holds copies of a ray's last row, each with the row's gradient. Outputs and gradients of the reference itself, G24's bars;
+    buffer_size 3 is the control."""
+    import helpers
+    g = np.load(os.path.join(GOLDEN, 'g29_early_break.npz'))
+    H, W = int(g['H']), int(g['W'])
+    b = helpers.oracle_render(cpu_oracle, orc, H, W, g['K'], g['R'], g['T'], g['latent'], **g29_kw(g, name))
+    executed = len(list(b['state'].live_counts)) - (6 if 'pyramid' in name else 0)
+    assert executed == (1 if 'pyramid' in name else 4)          # the premise: the march broke below the large buffers
+    print(name, check_g24(g29_stable(b, g, name), g, name))
+
+
 G25_RUNS = [(n, m, d) for n in ('away', 'far', 'inside', 'nosurf') for (m, d) in (('recursive', False), ('pyramid_recursive', False), ('pyramid_recursive', True))]
 
 
