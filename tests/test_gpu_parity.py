@@ -882,6 +882,46 @@ def test_fused_warp_loss_matches_oracle_and_edge_cases(engine):
     assert np.isnan(loss1) and keep1.sum() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_WARP', '4'))))      # (soak runs: more seeds)
+def test_random_warp_losses_match_oracle(engine, seed):
+    """Seeded random view pairs of a synthetic sphere (ragged sizes, camera pairs from near-identical to 60 degrees apart, sphere size and offset,
+    depth-test threshold, off-centre intrinsics): distr_warp_loss_* against the torch restatement of renderer_warp.py:18-101 that G8 pins to the
+    reference -- kept set (<= 2 flips at the depth test), loss, sampled colours, gradients to the view-1 depth and the four camera tensors."""
+    import torch
+    from oracle import loss_oracle
+    from oracle.gen_synth import sphere_view, procedural_images
+    from distr import fixture
+    rs = np.random.RandomState(31000 + seed)
+    H, W = int(rs.randint(24, 160)), int(rs.randint(24, 160))
+    K = np.array(fixture.make_intrinsic(H, W), dtype=np.float64)
+    K[0, 0] *= rs.uniform(0.85, 1.2); K[1, 1] *= rs.uniform(0.85, 1.2); K[0, 2] += rs.uniform(-0.1, 0.1) * W; K[1, 2] += rs.uniform(-0.1, 0.1) * H
+    az, el, dist = float(rs.uniform(-180, 180)), float(rs.uniform(-40, 40)), float(rs.uniform(1.4, 2.2))
+    R1, T1 = fixture.make_camera(az, el, dist, float(rs.uniform(-10, 10)))
+    R2, T2 = fixture.make_camera(az + float(rs.uniform(-60, 60)), el + float(rs.uniform(-25, 25)), dist * float(rs.uniform(0.85, 1.2)), float(rs.uniform(-10, 10)))
+    rad, ctr = float(rs.uniform(0.35, 0.75)), tuple(float(v) for v in rs.uniform(-0.08, 0.08, 3))
+    z1, hit1 = sphere_view(K, R1, T1, H, W, rad, ctr)
+    z2, _ = sphere_view(K, R2, T2, H, W, rad, ctr)
+    img1, img2 = procedural_images(H, W)
+    thres = float(10 ** rs.uniform(-3.5, -1.5))
+    g = dict(H=H, W=W, K=K, R1=R1, T1=T1, R2=R2, T2=T2, thres_depth=thres, zdepth1=z1, mask1=hit1.astype(np.uint8), zdepth2=z2, img1=img1, img2=img2)
+    loss, keep, c1, c2, grads = _warp_hip(engine, g, 1.0)
+    t = lambda k: torch.from_numpy(np.asarray(g[k], np.float32)).clone().requires_grad_(True)
+    tz, tR1, tT1, tR2, tT2 = t('zdepth1'), t('R1'), t('T1'), t('R2'), t('T2')
+    ol, okeep, oc1, oc2 = loss_oracle.warp_loss(K, H, W, tz, torch.from_numpy(g['mask1']), torch.from_numpy(z2), torch.from_numpy(img1),
+                                                torch.from_numpy(img2), tR1, tT1, tR2, tT2, thres)
+    flips = int((keep.astype(bool) != okeep.numpy()).sum())
+    assert flips <= 2, (seed, flips)
+    if okeep.sum() == 0:
+        assert keep.sum() == 0 and (np.isnan(loss) or loss == 0.0)
+        return
+    assert abs(loss - float(ol)) <= 1e-5 + 2e-3 * flips, (seed, loss, float(ol))
+    if flips == 0:
+        ol.backward()
+        for a, v in zip(grads, (tz, tR1, tT1, tR2, tT2)):
+            assert np.abs(a.reshape(-1) - v.grad.numpy().reshape(-1)).max() <= 5e-4 * max(np.abs(v.grad.numpy()).max(), 1e-12), seed
+
+
 class _Cam(object):
     def __init__(self, ext):
         self.extrinsic = np.asarray(ext, np.float32)
