@@ -818,6 +818,38 @@ def test_fused_single_view_losses_match_oracle(engine, size):
     assert all(a.tobytes() == b.tobytes() for a, b in zip((terms, gd, gn, gq), again))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_LOSSES', '4'))))      # (soak runs: more seeds)
+def test_random_single_view_losses_match_oracle(engine, seed):
+    """Seeded random inputs of the fused single-view losses (loss_utils.py:27-172): ragged sizes, mask densities from empty to full (every
+    set of the four terms can be empty), missing ground-truth depth, zero normals, random weights and threshold -- terms and the three input
+    gradients against the torch restatement G7 pins to the reference."""
+    import torch
+    from oracle import loss_oracle
+    rs = np.random.RandomState(41000 + seed)
+    H, W = int(rs.randint(5, 200)), int(rs.randint(5, 200))
+    pm, pg, pd = (float(rs.choice([0.0, 1.0, rs.uniform(0.02, 0.98), rs.uniform(0.02, 0.98)])) for _ in range(3))
+    thr = float(10 ** rs.uniform(-5, -3))
+    g = dict(threshold=thr, depth=(1 + rs.rand(H, W)).astype(np.float32), normal=rs.standard_normal((H, W, 3)).astype(np.float32),
+             mask=(rs.rand(H, W) < pm).astype(np.uint8), min_sdf=(4 * thr * rs.standard_normal((H, W))).astype(np.float32),
+             gt_depth=np.where(rs.rand(H, W) < pd, 1 + rs.rand(H, W), 0).astype(np.float32),
+             gt_normal=rs.standard_normal((H, W, 3)).astype(np.float32), gt_mask=(rs.rand(H, W) < pg).astype(np.uint8))
+    g['normal'][rs.rand(H, W) < 0.1] = 0
+    g['gt_normal'][rs.rand(H, W) < 0.05] = 0
+    w = [float(v) for v in rs.uniform(0.1, 10.0, 4)]
+    terms, gd, gn, gq = _single_loss_hip(engine, g, w)
+    d, n, q = (torch.from_numpy(g[k]).clone().requires_grad_(True) for k in ('depth', 'normal', 'min_sdf'))
+    ref = loss_oracle.single_view_losses(d, n, torch.from_numpy(g['mask']), q, torch.from_numpy(g['gt_depth']),
+                                         torch.from_numpy(g['gt_normal']), torch.from_numpy(g['gt_mask']), thr)
+    total = sum(wi * t for wi, t in zip(w, ref))
+    if total.requires_grad:
+        total.backward()
+    assert np.allclose(terms, [float(t) for t in ref], rtol=5e-5, atol=1e-9), (seed, terms, [float(t) for t in ref])
+    for a, t in ((gd, d), (gn, n), (gq, q)):
+        rg = t.grad.numpy() if t.grad is not None else np.zeros_like(a)
+        assert np.abs(a - rg).max() <= 2e-5 * max(np.abs(rg).max(), 1e-20), seed
+
+
 def _warp_hip(engine, g, g_loss):
     import torch
     from distr import binding, functions
