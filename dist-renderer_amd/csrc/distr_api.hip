@@ -254,15 +254,20 @@ int check_cfg(distr_ctx* ctx, const distr_render_cfg* c) {
   if (c->H < 1 || c->W < 1 || (int64_t)c->H * c->W >= (1 << 26)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad image size %dx%d", c->H, c->W);
   if (c->buffer_size < 1 || c->buffer_size > MAX_BS) return fail(ctx, DISTR_ERR_UNSUPPORTED, "buffer_size %d not in [1,%d]", c->buffer_size, MAX_BS);
   if (c->marcher < 0 || c->marcher > 2) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown marcher %d", c->marcher);
-  int fine = c->march_step;
+  int fine = c->march_step, coarse_rows = 0;
   if (c->marcher == DISTR_MARCH_PYRAMID_RECURSIVE) {
     Pyramid py;
     if (const char* why = pyramid_of(*c, py)) return fail(ctx, DISTR_ERR_UNSUPPORTED, "%s", why);
-    for (int l = 1; l < py.nlev; ++l) fine -= py.steps[l];
+    for (int l = 1; l < py.nlev; ++l) { fine -= py.steps[l]; coarse_rows += py.steps[l]; }
     if (c->rows != 0 && c->rows != c->H && 4 % py.scale[py.nlev - 1] != 0)
       return fail(ctx, DISTR_ERR_UNSUPPORTED, "row bands (row0 a multiple of 4) need a pyramid whose coarsest scale divides 4");
   }
   if (fine < 1 || fine > MAX_STEPS) return fail(ctx, DISTR_ERR_INVALID_ARG, "march_step %d leaves %d full-resolution steps (need 1..%d)", c->march_step, fine, MAX_STEPS);
+  // fewer marched rows than selected rows: the reference's torch.topk raises ("selected index k out of range", renderer.py:314-318) unless an
+  // early break happens to pad the lists (:562-567) -- refused here, where the reference fails at render time
+  if (coarse_rows + fine < c->buffer_size)
+    return fail(ctx, DISTR_ERR_INVALID_ARG, "buffer_size %d exceeds the %d rows a ray's march produces (march_step %d): the reference's top-k selection raises there",
+                c->buffer_size, coarse_rows + fine, c->march_step);
   if (!(c->radius > 0.f) || !(c->threshold >= 0.f)) return fail(ctx, DISTR_ERR_INVALID_ARG, "bad radius/threshold");
   if (c->arith != DISTR_ARITH_F32 && c->arith != DISTR_ARITH_BF16X6 && c->arith != DISTR_ARITH_F16X3) return fail(ctx, DISTR_ERR_INVALID_ARG, "unknown arith %d", c->arith);
   if (c->arith == DISTR_ARITH_F16X3 && ctx->has_decoder && !ctx->h3_ok)

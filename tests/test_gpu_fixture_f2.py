@@ -134,19 +134,20 @@ F2_PYRAMIDS = (None, None, [2, 1], [8, 4, 2, 1], [6, 2, 1], [3, 1])
 @pytest.mark.parametrize('seed', range(int(os.environ.get('DISTR_TEST_RANDOM_F2', '4'))))      # (soak runs: more seeds)
 def test_f2_random_configs_match_oracle(engine_f2, oracle_f2, orc, f2, seed):
     """Seeded random draws on the NON-CONVEX fixture (its lin4 has non-zero xyz columns; rays graze the plate and the torus' hole): image size
-    up to 200 px (every tile class from cluster tiles to 64-ray rounds), steps, buffer_size, ratio, marcher, pyramid, normal mode, camera and a
+    up to 200 px (every tile class from cluster tiles to 64-ray rounds), steps, buffer_size (to 8), ratio, marcher, pyramid, normal mode, camera (one in four INSIDE the sphere) and a
     perturbed shape code -- HIP vs oracle, zero mask flips, depth <= 1e-5."""
     from distr import fixture
     rs = np.random.RandomState(4000 + seed)
     H, W = int(rs.randint(17, 200)), int(rs.randint(17, 200))
     marcher = ['recursive', 'pyramid_recursive', 'pyramid_recursive', 'trivial'][rs.randint(4)]
     S = int(rs.randint(12, 80)) if marcher != 'trivial' else int(rs.randint(6, 14))
-    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 6)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher, use_depth2normal=bool(rs.randint(2)))
+    kw = dict(march_step=S, buffer_size=int(rs.randint(1, 9)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher=marcher, use_depth2normal=bool(rs.randint(2)))
+    kw['buffer_size'] = min(kw['buffer_size'], S)            # (fewer rows than selected rows: refused, the reference's top-k raises)
     sl = F2_PYRAMIDS[rs.randint(len(F2_PYRAMIDS))]
     if marcher == 'pyramid_recursive' and sl is not None:
         kw['scale_list'] = list(sl)
         kw['march_step_list'] = [int(rs.randint(1, 4)) for _ in sl[:-1]] + [-1]
-    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(1.3, 2.2)), float(rs.uniform(-20, 20)))
+    cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(0.3, 0.8) if rs.randint(4) == 0 else rs.uniform(1.3, 2.2)), float(rs.uniform(-20, 20)))
     latent = (f2[2] + 0.02 * rs.standard_normal(f2[2].shape)).astype(np.float32)
     K = fixture.make_intrinsic(H, W)
     R, T = fixture.make_camera(*cam)

@@ -683,6 +683,7 @@ def test_random_options_match_oracle(engine, cpu_oracle, orc, fixture_decoder, s
               threshold=float(10 ** rs.uniform(-5, -2.5)), radius=float(rs.uniform(0.85, 1.3)), clamp_dist=float(rs.uniform(0.03, 0.3)),
               use_transform=bool(rs.randint(4) != 0), normalize_normal=bool(rs.randint(3) != 0),
               grad_depth=bool(rs.randint(4) != 0), grad_mask=bool(rs.randint(4) != 0), grad_camera=bool(rs.randint(4) != 0))
+    kw['buffer_size'] = min(kw['buffer_size'], S)            # (fewer rows than selected rows: refused, the reference's top-k raises)
     t = rs.randint(3)
     if t == 1:
         perm = rs.permutation(3)
@@ -751,6 +752,23 @@ def test_coarsest_level_without_a_hit(engine, cpu_oracle, orc, fixture_decoder, 
         assert np.isfinite(np.asarray(a[k])).all() and np.isfinite(np.asarray(b[k])).all(), k
     res = helpers.compare(a, b, H, W, tol_depth=1e-5, tol_grad=1e-3, normal_p99=1e-4)
     assert res['flips'] == 0
+
+
+@pytest.mark.gpu
+def test_buffer_size_above_the_marched_rows_is_refused(engine, fixture_decoder):
+    """march_step 6 with buffer_size 8: the reference's torch.topk raises at render time (renderer.py:314-318, k above the number of rows);
+    here check_cfg refuses the configuration (DISTR_ERR_INVALID_ARG) for every marcher -- found by the F2 random sweep ('trivial' with 6 / 7 steps
+    and buffer_size 8: the kernels and the oracle each did something, not the same thing). A pyramid's coarse rows count."""
+    from distr import binding, fixture
+    K = fixture.make_intrinsic(48, 48)
+    for marcher, S, bs, ok in (('trivial', 6, 8, False), ('recursive', 7, 8, False), ('trivial', 8, 8, True), ('pyramid_recursive', 7, 8, False),
+                               ('pyramid_recursive', 8, 8, True), ('recursive', 5, 5, True)):
+        cfg = binding.make_cfg((48, 48), K, march_step=S, buffer_size=bs, marcher=marcher)
+        if ok:
+            engine.ctx.workspace_bytes(cfg)
+        else:
+            with pytest.raises(binding.DistrError):
+                engine.ctx.workspace_bytes(cfg)
 
 
 @pytest.mark.gpu
