@@ -56,9 +56,11 @@ def run(dec, latent, K, R, T, ckw, rkw, img_hw=(H, W)):
     wd, wq, wn = gg.loss_weights(h, w, 5)
     mb = mask.bool()
     L = (depth * torch.from_numpy(wd))[mb].sum() + (mq * torch.from_numpy(wq)).sum() + (normal * torch.from_numpy(wn)).sum()
-    L.backward()
+    if L.requires_grad:
+        L.backward()
     return dict(depth=depth.detach().numpy(), normal=normal.detach().numpy(), mask=mask.numpy(), q=mq.detach().numpy(), loss=np.float64(L.item()),
-                g_latent=lat.grad.numpy(), g_R=Rt.grad.numpy(), g_T=Tt.grad.numpy(), hw=np.array([h, w]))
+                g_latent=(lat.grad if lat.grad is not None else torch.zeros_like(lat)).numpy(), g_R=(Rt.grad if Rt.grad is not None else torch.zeros_like(Rt)).numpy(),
+                g_T=(Tt.grad if Tt.grad is not None else torch.zeros_like(Tt)).numpy(), hw=np.array([h, w]))
 
 
 def main():
