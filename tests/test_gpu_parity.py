@@ -721,6 +721,11 @@ def test_random_pyramids_match_oracle(engine, cpu_oracle, orc, fixture_decoder, 
     kw = dict(march_step=S, buffer_size=int(rs.randint(1, 6)), ratio=float(rs.choice([1.0, 1.5, 2.0])), marcher='pyramid_recursive',
               use_depth2normal=bool(rs.randint(2)), scale_list=sl, march_step_list=msl)
     cam = (float(rs.uniform(-180, 180)), float(rs.uniform(-60, 60)), float(rs.uniform(1.3, 2.2)), float(rs.uniform(-30, 30)))
+    if int(os.environ.get('DISTR_TEST_PYRAMIDS_WIDE', '0')):     # (soak: cameras inside the sphere and buffer sizes to 8 -- the early-break regime -- on top)
+        rs2 = np.random.RandomState(77000 + seed)
+        kw['buffer_size'] = int(rs2.randint(1, 9))
+        if rs2.randint(3) == 0:
+            cam = (cam[0], cam[1], float(rs2.uniform(0.3, 0.8)), cam[3])
     _, _, latent = fixture_decoder
     K = fixture.make_intrinsic(H, W)
     R, T = fixture.make_camera(*cam)
